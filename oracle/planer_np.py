@@ -1,0 +1,314 @@
+"""CPU oracle for planer's per-layer forward pass.  TEST INFRASTRUCTURE ONLY.
+
+This file is a numpy restatement of the algorithm of the reference
+(Image-Py/planer v0.34, /root/reference/planer/{layer,util,net,io}.py) for the
+hot path named in BASELINE.json.  It exists so that the HIP path can be checked
+against something that runs anywhere (the reference itself cannot travel to
+the GPU box).  Only tests/, __graft_entry__.smoke() and bench.py's
+`cpu_baseline` leg may import it; the product package `planer_amd` never does.
+
+Parity pinning: the reference ships no tests and no golden vectors
+(SURVEY.md §4), so this oracle is pinned against OUTPUTS OF THE REFERENCE
+ITSELF captured in the build container by tools/capture_golden.py and
+committed under tests/golden/ (tests/test_oracle_golden.py re-checks every
+vector on every run).
+
+Every function cites the reference lines it follows.  Arithmetic is float32
+numpy / OpenBLAS sgemm exactly like the reference, so oracle-vs-reference
+differences are at most sgemm blocking noise (~1e-6 relative).
+"""
+import json
+import os
+import time
+import zipfile
+from concurrent.futures import ThreadPoolExecutor
+from io import BytesIO
+
+import numpy as np
+
+__all__ = ["conv2d", "dense", "matmul", "batchnorm", "relu", "leakyrelu",
+           "sigmoid", "maxpool", "avgpool", "upsample", "concat", "add",
+           "gap", "flatten", "ret", "OPS", "OracleNet", "read_net"]
+
+
+# --------------------------------------------------------------------------
+# helpers
+# --------------------------------------------------------------------------
+def _zero_pad_hw(x, pads):
+    """util.pad (util.py:4-10): constant zero padding of H and W.
+
+    The reference enlarges by 2*pads[0] / 2*pads[1] (util.py:8), i.e. it only
+    works for symmetric pads (top==bottom, left==right); asymmetric pads give
+    silently wrong results there, so they are rejected here.
+    """
+    pt, pl, pb, pr = [int(p) for p in pads]
+    if (pt, pl) != (pb, pr):
+        raise ValueError("asymmetric pads are undefined in the reference")
+    if pt == 0 and pl == 0:
+        return x                                   # util.py:5
+    n, c, h, w = x.shape
+    out = np.zeros((n, c, h + 2 * pt, w + 2 * pl), dtype=x.dtype)
+    out[:, :, pt:pt + h, pl:pl + w] = x
+    return out
+
+
+def _out_size(size, pad_sum, k, d, s):
+    """util.py:25-26: (size + pads - (k-1)*d - 1 + s) // s."""
+    return (size + pad_sum - (k - 1) * d - 1 + s) // s
+
+
+# --------------------------------------------------------------------------
+# conv / dense
+# --------------------------------------------------------------------------
+def conv2d(x, K, B=None, group=1, strides=(1, 1), dilations=(1, 1),
+           pads=(0, 0, 0, 0)):
+    """layer.Conv2d (layer.py:22-26) via util.conv_for (util.py:17-44).
+
+    im2col into a (Cin, kh*kw, N, Ho, Wo) scratch (one strided slab copy per
+    filter tap, issued from a 9-worker thread pool like util.py:18,34-39),
+    then one sgemm (Cout x Cin*kh*kw) @ (Cin*kh*kw x N*Ho*Wo) (util.py:41-43;
+    batched over `group`), result viewed back as NCHW (util.py:44 -- a
+    transposed, non-contiguous view), bias added in place (layer.py:26).
+    """
+    sh, sw = [int(v) for v in strides]
+    dh, dw = [int(v) for v in dilations]
+    cout, cin_g, kh, kw = K.shape
+    n, cin, h, w = x.shape
+    xp = _zero_pad_hw(x, pads)
+    ho = _out_size(h, pads[0] + pads[2], kh, dh, sh)
+    wo = _out_size(w, pads[1] + pads[3], kw, dw, sw)
+    cnhw = xp.transpose(1, 0, 2, 3)                # util.py:30
+    col = np.empty((cin, kh * kw, n, ho, wo), dtype=x.dtype)
+
+    def tap(i, r, c):
+        col[:, i] = cnhw[:, :, r:r + ho * sh:sh, c:c + wo * sw:sw]
+
+    with ThreadPoolExecutor(max_workers=9) as pool:
+        futs = [pool.submit(tap, a * kw + b, a * dh, b * dw)
+                for a in range(kh) for b in range(kw)]
+    for f in futs:
+        f.result()                                 # (reference never checks)
+    if group == 1:
+        out = np.matmul(K.reshape(cout, -1), col.reshape(cin * kh * kw, -1))
+    else:
+        out = np.matmul(K.reshape(group, cout // group, -1),
+                        col.reshape(group, cin_g * kh * kw, -1))
+    out = out.reshape(cout, n, ho, wo).transpose(1, 0, 2, 3)
+    if B is not None:
+        np.add(out, B.reshape(1, -1, 1, 1), out=out)
+    return out
+
+
+def dense(x, K, B, shp=None):
+    """layer.Dense (layer.py:15-18): x @ K.T + B ; `shp` is ignored."""
+    y = np.matmul(x, K.T)
+    y += B.reshape(1, -1)
+    return y
+
+
+def matmul(x, y):
+    """layer.MatMul (layer.py:20)."""
+    return np.matmul(x, y)
+
+
+# --------------------------------------------------------------------------
+# elementwise
+# --------------------------------------------------------------------------
+def batchnorm(x, K, B):
+    """layer.BatchNorm (layer.py:125-127): x*K + B, K/B pre-folded (1,C,1,1)."""
+    y = x * K
+    y += B
+    return y
+
+
+def relu(x):
+    """layer.ReLU (layer.py:44-46): x *= (x>0) IN PLACE; returns x itself."""
+    return np.multiply(x, x > 0, out=x)
+
+
+def leakyrelu(x, alpha=0.2):
+    """layer.LeakyReLU (layer.py:48-51): x*((x>0)*(1-alpha)+alpha)."""
+    a = np.array(alpha, x.dtype)
+    b = np.array(1 - alpha, x.dtype)
+    y = (x > 0) * b
+    y += a
+    y *= x
+    return y
+
+
+def sigmoid(x):
+    """layer.Sigmoid (layer.py:61-64): 1/(1+exp(-x))."""
+    with np.errstate(over="ignore"):
+        t = np.exp(-x)
+    t += 1
+    return np.divide(1, t, out=t)
+
+
+def add(a, b):
+    """layer.Add (layer.py:93-95)."""
+    return a + b
+
+
+# --------------------------------------------------------------------------
+# pooling / resampling / shape
+# --------------------------------------------------------------------------
+def _pool(x, op, win, pads, strides, init):
+    """util.pool (util.py:79-92): zero-pad, accumulator filled with `init`,
+    one strided pass per window tap."""
+    kh, kw = [int(v) for v in win]
+    sh, sw = [int(v) for v in strides]
+    n, c, h, w = x.shape
+    xp = _zero_pad_hw(x, pads)
+    ho = (h + pads[0] + pads[2] - kh + sh) // sh   # util.py:84
+    wo = (w + pads[1] + pads[3] - kw + sw) // sw   # util.py:85
+    acc = np.full((n, c, ho, wo), init, dtype=x.dtype)
+    for r in range(kh):
+        for q in range(kw):
+            op(xp[:, :, r:r + ho * sh:sh, q:q + wo * sw:sw], acc, out=acc)
+    return acc
+
+
+def maxpool(x, w=(2, 2), pads=(0, 0, 0, 0), strides=(2, 2)):
+    """layer.Maxpool (layer.py:71-72) -> util.maxpool (util.py:94-95):
+    ZERO padding (not -inf) and an accumulator initialised to -1e4."""
+    return _pool(x, np.maximum, w, pads, strides, -1e4)
+
+
+def avgpool(x, w=(2, 2), pads=(0, 0, 0, 0), strides=(2, 2)):
+    """layer.AveragePool (layer.py:74-75) -> util.avgpool (util.py:97-100):
+    sum / (kh*kw), padding counted."""
+    y = _pool(x, np.add, w, pads, strides, 0)
+    y /= int(w[0]) * int(w[1])
+    return y
+
+
+def gap(x):
+    """layer.GlobalAveragePool (layer.py:77-78)."""
+    return x.mean(axis=(-2, -1), keepdims=True)
+
+
+def upsample(x, k, mode="nearest"):
+    """layer.UpSample (layer.py:80-82) -> util.upsample_nearest
+    (util.py:184-192).  `k` is a tensor whose last two entries are the integer
+    H/W factors.  With UpSample's defaults util.offset() yields shift 0
+    (util.py:212 passes the misspelt 'half-pixcel', so no transform applies),
+    i.e. plain block replication."""
+    if mode != "nearest":
+        raise NotImplementedError("oracle covers nearest only (hot path)")
+    fh, fw = [int(v) for v in np.asarray(k)[-2:].astype(int).tolist()]
+    n, c, h, w = x.shape
+    out = np.empty((n, c, h * fh, w * fw), dtype=x.dtype)
+    for r in range(fh):
+        for q in range(fw):
+            out[:, :, r::fh, q::fw] = x
+    return out
+
+
+def concat(*xs, axis=0):
+    """layer.Concatenate (layer.py:90-91); default axis is 0 as there."""
+    return np.concatenate(xs, axis=axis)
+
+
+def flatten(x):
+    """layer.Flatten (layer.py:59)."""
+    return x.reshape((x.shape[0], -1))
+
+
+def ret(*x):
+    """layer.Return (layer.py:260)."""
+    return x
+
+
+OPS = {"conv": conv2d, "dense": dense, "matmul": matmul,
+       "batchnorm": batchnorm, "relu": relu, "leakyrelu": leakyrelu,
+       "sigmoid": sigmoid, "add": add, "maxpool": maxpool,
+       "averagepool": avgpool, "gap": gap, "upsample": upsample,
+       "concat": concat, "flatten": flatten, "return": ret}
+
+
+# --------------------------------------------------------------------------
+# graph interpreter (net.py) and loader (io.py)
+# --------------------------------------------------------------------------
+class OracleNet:
+    """net.Net (net.py:5-101) restated: same IR, same evaluation order, same
+    liveness-based freeing and the same `__call__` unwrapping rule."""
+
+    def __init__(self):
+        self.weights, self.inits, self.input = [], [], []
+        self.layer, self.flow, self.life, self.timer = [], [], {}, {}
+        self._ops = {}
+
+    def load_json(self, inputs, inits, body, flow, debug=False):
+        # net.py:10-24
+        self._ops = {name: (kind, OPS[kind], dict(para))
+                     for name, kind, para in body}
+        self.life = {}
+        for i, (src, _, _) in enumerate(flow):
+            for key in ([src] if isinstance(src, str) else src):
+                self.life[key] = i                  # last reader, net.py:16-19
+        self.weights = [np.zeros(shape, dtype=dt) for _, shape, dt in inits]
+        self.input, self.inits = inputs, [i[0] for i in inits]
+        self.layer, self.flow = body, flow
+
+    def load_weights(self, blob):
+        # net.py:83-88: consecutive raw bytes, in `inits` order
+        raw, pos = np.asarray(blob).view(np.uint8).ravel(), 0
+        for wt in self.weights:
+            dst = wt.reshape(-1).view(np.uint8)
+            dst[:] = raw[pos:pos + dst.size]
+            pos += dst.size
+
+    def forward(self, *xs):
+        # net.py:37-72
+        env = {"None": None}
+        env.update(zip(self.inits, self.weights))
+        env.update(zip(self.input, xs))
+        out_key = None
+        for i, (src, names, dst) in enumerate(self.flow):
+            names = names if isinstance(names, list) else [names]
+            for pos, name in enumerate(names):
+                keys = src if pos == 0 else dst     # chained layers, net.py:46
+                args = ([env[keys]] if isinstance(keys, str)
+                        else [env.get(k) for k in keys])
+                for k in set(src if isinstance(src, list) else [src]):
+                    if k in env and self.life[k] <= i:
+                        del env[k]                  # net.py:51-53
+                kind, fn, para = self._ops[name]
+                t0 = time.time()
+                val = fn(*args, **para)
+                if isinstance(dst, str):
+                    env[dst] = val
+                else:
+                    env.update(zip(dst, val))       # net.py:61-62
+                self.timer[kind] = self.timer.get(kind, 0) + time.time() - t0
+            out_key = dst
+        return env[out_key]
+
+    def __call__(self, *xs):
+        # net.py:94-101 (numpy backend: no conversions)
+        if isinstance(xs[0], dict):
+            xs = [xs[0][k] for k in self.input]
+        rst = self.forward(*xs)
+        return rst[0] if len(rst) == 1 else rst
+
+
+def read_net(path):
+    """io.read_net (io.py:8-34) for the .pla zip and .json+.npy forms."""
+    path = path.replace(".onnx", "")
+    if os.path.exists(path + ".pla"):
+        with zipfile.ZipFile(path + ".pla") as z:
+            base = os.path.split(path)[1]
+            graph = json.loads(z.read(base + ".json"))
+            blob = np.load(BytesIO(z.read(base + ".npy")))
+    elif os.path.exists(path + ".json"):
+        with open(path + ".json") as f:
+            graph = json.load(f)
+        blob = np.load(path + ".npy")
+    else:
+        print("model %s not found!" % path)         # io.py:30-31
+        return None
+    net = OracleNet()
+    net.load_json(graph["input"], graph["inits"], graph["layers"],
+                  graph["flow"])
+    net.load_weights(blob)
+    return net

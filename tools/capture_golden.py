@@ -1,0 +1,120 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running the REFERENCE (imported from
+/root/reference, which exists only in the build container).
+
+Only arrays are written: seeded inputs, parameters and the reference's
+outputs.  Whole-net outputs that are too big are stored as a deterministic
+sample (tests/cases.sample_index) plus float64 sums.  Weights are never
+stored: they are regenerated from the seeded IR generators, and the SHA-256
+of each blob is recorded so generator drift is detected.
+
+Run from the repo root:  python tools/capture_golden.py
+"""
+import json
+import os
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["HOME"] = tempfile.mkdtemp(prefix="planer_home_")  # ~/.planer_zoo
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import planer  # noqa: E402  (the reference)
+
+from planer_amd.irgen import customnet, resnet18, yolov3, blob_sha256  # noqa: E402
+from tests.cases import layer_cases, sample_index  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def run_layers():
+    store, meta = {}, {}
+    for name, kind, args, params in layer_cases():
+        fn = planer.layer_map[kind]
+        ins = [a.copy() for a in args]
+        out = fn(*ins, **params)
+        outs = out if isinstance(out, tuple) else (out,)
+        for i, a in enumerate(args):
+            store["%s/in%d" % (name, i)] = a
+        for i, o in enumerate(outs):
+            store["%s/out%d" % (name, i)] = np.ascontiguousarray(o)
+        meta[name] = {"kind": kind, "params": params, "n_in": len(args),
+                      "n_out": len(outs),
+                      # ReLU aliasing (layer.py:46): output IS the input object
+                      "inplace": bool(outs[0] is ins[0])}
+    store["__meta__"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, "layers.npz"), **store)
+    print("layers.npz:", len(meta), "cases")
+
+
+def ref_net(graph, blob):
+    net = planer.Net()
+    net.load_json(graph["input"], graph["inits"], graph["layers"], graph["flow"])
+    net.load_weights(blob)
+    return net
+
+
+def pack(outs):
+    d = {}
+    for i, o in enumerate(outs):
+        o = np.ascontiguousarray(o)
+        idx = sample_index(o.size)
+        d["out%d_shape" % i] = np.array(o.shape)
+        d["out%d_sample" % i] = o.reshape(-1)[idx]
+        d["out%d_sum" % i] = np.array([o.astype(np.float64).sum(),
+                                       np.abs(o.astype(np.float64)).sum()])
+        d["out%d_absmax" % i] = np.array(np.abs(o).max())
+    return d
+
+
+def run_nets():
+    g, b = customnet.build()
+    x = customnet.make_input(1)
+    y = ref_net(g, b)(x.copy())
+    np.savez_compressed(os.path.join(OUT, "customnet_b1.npz"),
+                        sha=np.array(blob_sha256(b)), **pack([y]))
+    # no trailing `return` layer: batch-1 output loses its batch dim (net.py:101)
+    g2 = dict(g, layers=g["layers"][:-1], flow=g["flow"][:-1])
+    y2 = ref_net(g2, b)(x.copy())
+    np.savez_compressed(os.path.join(OUT, "customnet_b1_noreturn.npz"), **pack([y2]))
+
+    g, b = resnet18.build()
+    for n in (1, 2):
+        x = resnet18.make_input(n)
+        y = ref_net(g, b)(x.copy())
+        np.savez_compressed(os.path.join(OUT, "resnet18_b%d.npz" % n),
+                            sha=np.array(blob_sha256(b)), logits=np.ascontiguousarray(y))
+    # per-stage activations for N=2 (sampled) via a truncated flow
+    x = resnet18.make_input(2)
+    stages = {}
+    for key in ("stem_r", "pool", "l11_o", "l21_o", "l31_o", "l41_o", "gap"):
+        cut = [i for i, f in enumerate(g["flow"]) if f[2] == key][0]
+        sub = dict(g, flow=g["flow"][:cut + 1])
+        net = ref_net(sub, b)
+        o = np.ascontiguousarray(net.forward(x.copy()))
+        idx = sample_index(o.size)
+        stages[key + "_shape"] = np.array(o.shape)
+        stages[key + "_sample"] = o.reshape(-1)[idx]
+        stages[key + "_absmax"] = np.array(np.abs(o).max())
+    np.savez_compressed(os.path.join(OUT, "resnet18_b2_stages.npz"), **stages)
+
+    g, b = yolov3.build()
+    x = yolov3.make_input(1)
+    y = ref_net(g, b)(x.copy())
+    np.savez_compressed(os.path.join(OUT, "yolov3_b1.npz"),
+                        sha=np.array(blob_sha256(b)), **pack(list(y)))
+    # reduced-size YOLO (160x160) keeps the CPU suite fast
+    x = yolov3.make_input(1, size=160)
+    y = ref_net(g, b)(x.copy())
+    np.savez_compressed(os.path.join(OUT, "yolov3_b1_160.npz"), **pack(list(y)))
+    print("nets done")
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    run_layers()
+    run_nets()
+    for f in sorted(os.listdir(OUT)):
+        print("%8d  %s" % (os.path.getsize(os.path.join(OUT, f)), f))
