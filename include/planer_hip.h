@@ -1,0 +1,167 @@
+/*
+ * planer_hip.h -- C ABI of libplaner_hip.so, the MI355X (gfx950) backend for
+ * planer's per-layer forward pass.
+ *
+ * The reference (Image-Py/planer v0.34) is pure Python; its "backend" is any
+ * module that quacks like numpy, swapped in by planer.core() (__init__.py:22-38).
+ * Its only native/GPU call site is cupy.cudnn.convolution_forward
+ * (util.py:66-77).  This header is what a ctypes binding for a HIP backend
+ * binds instead; every entry point cites the reference function it replaces.
+ * INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions
+ *  - every function returns an int status (PL_OK == 0) and never throws;
+ *    pl_last_error() returns a thread-local message for the last failure.
+ *  - all tensors are dense fp32, logical layout NCHW, weights OIHW, exactly as
+ *    the reference's numpy arrays (layer.py / util.py).
+ *  - all pointers named x/y/w/... are DEVICE pointers obtained from pl_alloc;
+ *    sizes are element counts unless a name says bytes.
+ *  - all work is enqueued on the context's HIP stream and is asynchronous with
+ *    respect to the host; pl_sync() waits for it.
+ */
+#ifndef PLANER_HIP_H
+#define PLANER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PL_OK 0
+#define PL_EINVAL 1       /* bad argument (null pointer, negative size ...)      */
+#define PL_EUNSUPPORTED 2 /* valid in ONNX terms but undefined in the reference, */
+                          /* e.g. asymmetric pads (util.py:8), group !| C        */
+#define PL_ENOMEM 3
+#define PL_EHIP 4         /* a HIP runtime call failed; see pl_last_error()      */
+#define PL_ERCCL 5        /* an RCCL call failed                                 */
+
+/* activation codes for the fused conv epilogue */
+#define PL_ACT_NONE 0
+#define PL_ACT_RELU 1
+#define PL_ACT_LEAKY 2
+
+typedef struct pl_ctx pl_ctx;     /* one device + one stream + one memory pool */
+typedef struct pl_graph pl_graph; /* a captured forward pass (hipGraphExec)     */
+typedef struct pl_event pl_event; /* hipEvent on the context stream             */
+
+/* ---- runtime --------------------------------------------------------- */
+const char *pl_last_error(void);
+int pl_version(void);
+int pl_device_count(int *count);
+int pl_ctx_create(int device, pl_ctx **out);
+int pl_ctx_destroy(pl_ctx *ctx);
+int pl_ctx_info(pl_ctx *ctx, int *device, int *cu_count, size_t *hbm_bytes,
+                char *arch_name, size_t arch_name_len);
+int pl_sync(pl_ctx *ctx); /* wait for the context stream */
+
+/* memory: replaces numpy/cupy array allocation (np.zeros, util.py:31-32,88) */
+int pl_alloc(pl_ctx *ctx, size_t bytes, void **out); /* pooled, stream-ordered */
+int pl_free(pl_ctx *ctx, void *ptr);
+int pl_pool_stats(pl_ctx *ctx, size_t *bytes_reserved, size_t *bytes_in_use);
+int pl_pool_trim(pl_ctx *ctx);                       /* hipFree cached blocks */
+/* np.asarray / .get() of net.py:96-100 */
+int pl_h2d(pl_ctx *ctx, void *dst, const void *src_host, size_t bytes);
+int pl_d2h(pl_ctx *ctx, void *dst_host, const void *src, size_t bytes); /* syncs */
+int pl_d2d(pl_ctx *ctx, void *dst, const void *src, size_t bytes);
+int pl_memset(pl_ctx *ctx, void *dst, int byte, size_t bytes);
+
+/* timing: fills Net.timer (net.py:55,67-70) with device time */
+int pl_event_create(pl_ctx *ctx, pl_event **out);
+int pl_event_record(pl_ctx *ctx, pl_event *ev);
+int pl_event_elapsed_ms(pl_event *start, pl_event *stop, float *ms); /* syncs on stop */
+int pl_event_destroy(pl_event *ev);
+
+/* whole-forward capture: the HIP-native replacement for interpreting the flow
+ * in Python on every call (net.py:37-72).  Between begin/end every launch and
+ * pool allocation on the context is recorded instead of executed. */
+int pl_capture_begin(pl_ctx *ctx);
+int pl_capture_end(pl_ctx *ctx, pl_graph **out);
+int pl_graph_launch(pl_graph *g);
+int pl_graph_destroy(pl_graph *g);
+
+/* ---- MFMA-bound ops --------------------------------------------------- */
+/* layer.Conv2d (layer.py:22-26) == util.conv_for (util.py:17-44) + bias add.
+ * Implicit-GEMM: (Cout x Cin/g*kh*kw) @ im2col(x), K ordered (cin,kh,kw) like
+ * K.reshape(Cout,-1); output Ho = (H+pt+pb-(kh-1)*dh-1+sh)/sh (util.py:25-26).
+ * Requires pt==pb and pl==pr (util.pad, util.py:8) else PL_EUNSUPPORTED.
+ * bias may be NULL. */
+int pl_conv2d_f32(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W,
+                  const float *w, int Cout, int kh, int kw, const float *bias,
+                  float *y, int sh, int sw, int dh, int dw, int pt, int pl,
+                  int pb, int pr, int group);
+
+/* Conv2d with the layers that follow it folded into the epilogue, used by
+ * the compiled plan:  y = act( (conv(x,w)+bias) * scale[c] + shift[c] + res )
+ * i.e. conv -> batchnorm (layer.py:125-127) -> add (layer.py:93-95) ->
+ * relu/leakyrelu (layer.py:44-51).  scale/shift/res/bias may each be NULL. */
+int pl_conv2d_fused_f32(pl_ctx *ctx, const float *x, int N, int Cin, int H,
+                        int W, const float *w, int Cout, int kh, int kw,
+                        const float *bias, float *y, int sh, int sw, int dh,
+                        int dw, int pt, int pl, int pb, int pr, int group,
+                        const float *scale, const float *shift,
+                        const float *res, int act, double alpha);
+
+/* Force one tile configuration for the conv kernel (tuning / tests).
+ * cfg < 0 restores the built-in heuristic. split_k <= 0 means automatic. */
+int pl_conv2d_set_config(pl_ctx *ctx, int cfg, int split_k);
+int pl_conv2d_num_configs(void);
+int pl_conv2d_config_name(int cfg, char *buf, size_t len);
+
+/* layer.Dense (layer.py:15-18): y[M,N] = x[M,K] @ w[N,K]^T + bias[N]  (trans_b=1)
+ * layer.MatMul (layer.py:20):   y[M,N] = a[M,K] @ b[K,N]              (trans_b=0) */
+int pl_gemm_f32(pl_ctx *ctx, const float *a, int M, int K, const float *b,
+                int N, int trans_b, const float *bias, float *y);
+
+/* ---- HBM-bound ops ----------------------------------------------------- */
+/* layer.BatchNorm (layer.py:125-127): y = x*scale[c] + shift[c], x (outer,C,inner) */
+int pl_scale_shift_f32(pl_ctx *ctx, const float *x, float *y, const float *scale,
+                       const float *shift, int outer, int C, int inner);
+/* layer.ReLU (layer.py:44-46): y = x*(x>0); the reference works in place (y==x) */
+int pl_relu_f32(pl_ctx *ctx, const float *x, float *y, size_t n);
+/* layer.LeakyReLU (layer.py:48-51): y = x*((x>0)*(1-alpha)+alpha) */
+int pl_leakyrelu_f32(pl_ctx *ctx, const float *x, float *y, size_t n, double alpha);
+/* layer.Sigmoid (layer.py:61-64): y = 1/(1+exp(-x)) */
+int pl_sigmoid_f32(pl_ctx *ctx, const float *x, float *y, size_t n);
+/* layer.Add (layer.py:93-95), same-shape and per-channel-broadcast forms */
+int pl_add_f32(pl_ctx *ctx, const float *a, const float *b, float *y, size_t n);
+int pl_add_channel_f32(pl_ctx *ctx, const float *a, const float *b_c, float *y,
+                       int outer, int C, int inner);
+/* layer.Maxpool / AveragePool (layer.py:71-75) -> util.pool (util.py:79-100):
+ * zero padding, max accumulator initialised to -1e4; avg divides by kh*kw.
+ * mode 0 = max, 1 = average. pads must be symmetric. */
+int pl_pool2d_f32(pl_ctx *ctx, const float *x, float *y, int NC, int H, int W,
+                  int kh, int kw, int sh, int sw, int pt, int pl, int pb, int pr,
+                  int mode);
+/* layer.UpSample nearest (layer.py:80-82, util.py:184-192): block replication */
+int pl_upsample_nearest_f32(pl_ctx *ctx, const float *x, float *y, int NC, int H,
+                            int W, int fh, int fw);
+/* layer.Concatenate (layer.py:90-91) building block: copy `rows` rows of
+ * `width` floats from src (row pitch src_pitch) to dst (row pitch dst_pitch) */
+int pl_copy2d_f32(pl_ctx *ctx, float *dst, size_t dst_pitch, const float *src,
+                  size_t src_pitch, size_t width, size_t rows);
+/* layer.GlobalAveragePool (layer.py:77-78): y[r] = mean(x[r, 0:inner]) */
+int pl_gap_f32(pl_ctx *ctx, const float *x, float *y, int rows, int inner);
+/* split-K combine + epilogue (internal to conv, exported for tests) */
+int pl_splitk_reduce_f32(pl_ctx *ctx, const float *ws, int splits, float *y,
+                         int N, int C, int inner, const float *bias,
+                         const float *scale, const float *shift,
+                         const float *res, int act, double alpha);
+
+/* ---- multi-GPU (RCCL over xGMI): one process per GPU -------------------- */
+/* The reference has no distributed code.  The forward pass shards by batch
+ * with no collectives; the ONE exchange is the weight blob broadcast at load
+ * time (net.load_weights, net.py:83-88). */
+#define PL_UNIQUE_ID_BYTES 128
+int pl_comm_unique_id(void *id_out);                /* rank 0 */
+int pl_comm_init_rank(pl_ctx *ctx, int world, int rank, const void *id);
+int pl_comm_bcast(pl_ctx *ctx, void *buf, size_t bytes, int root);
+int pl_comm_allreduce_max_f32(pl_ctx *ctx, float *buf, size_t n); /* in place, device */
+int pl_comm_allgather(pl_ctx *ctx, const void *send, void *recv, size_t bytes_per_rank);
+int pl_comm_destroy(pl_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLANER_HIP_H */

@@ -1,0 +1,121 @@
+"""ctypes binding of libplaner_hip.so (C ABI: include/planer_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or no
+MI355X is visible, every device operation raises.  The numpy path lives in
+the reference itself (and in oracle/ for tests), never in this package.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, byref, c_char_p, c_double, c_float, c_int,
+                    c_size_t, c_void_p)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libplaner_hip.so")
+
+PL_OK, PL_EINVAL, PL_EUNSUPPORTED, PL_ENOMEM, PL_EHIP, PL_ERCCL = range(6)
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+UNIQUE_ID_BYTES = 128
+
+_P = c_void_p
+_I = c_int
+_Z = c_size_t
+
+# name -> argtypes (restype is int unless listed in _RESTYPE)
+SIGNATURES = {
+    "pl_last_error": [],
+    "pl_version": [],
+    "pl_device_count": [POINTER(c_int)],
+    "pl_ctx_create": [_I, POINTER(_P)],
+    "pl_ctx_destroy": [_P],
+    "pl_ctx_info": [_P, POINTER(c_int), POINTER(c_int), POINTER(c_size_t), c_char_p, _Z],
+    "pl_sync": [_P],
+    "pl_alloc": [_P, _Z, POINTER(_P)],
+    "pl_free": [_P, _P],
+    "pl_pool_stats": [_P, POINTER(c_size_t), POINTER(c_size_t)],
+    "pl_pool_trim": [_P],
+    "pl_h2d": [_P, _P, _P, _Z],
+    "pl_d2h": [_P, _P, _P, _Z],
+    "pl_d2d": [_P, _P, _P, _Z],
+    "pl_memset": [_P, _P, _I, _Z],
+    "pl_event_create": [_P, POINTER(_P)],
+    "pl_event_record": [_P, _P],
+    "pl_event_elapsed_ms": [_P, _P, POINTER(c_float)],
+    "pl_event_destroy": [_P],
+    "pl_capture_begin": [_P],
+    "pl_capture_end": [_P, POINTER(_P)],
+    "pl_graph_launch": [_P],
+    "pl_graph_destroy": [_P],
+    "pl_conv2d_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P] + [_I] * 9,
+    "pl_conv2d_fused_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P] + [_I] * 9
+                           + [_P, _P, _P, _I, c_double],
+    "pl_conv2d_set_config": [_P, _I, _I],
+    "pl_conv2d_num_configs": [],
+    "pl_conv2d_config_name": [_I, c_char_p, _Z],
+    "pl_gemm_f32": [_P, _P, _I, _I, _P, _I, _I, _P, _P],
+    "pl_scale_shift_f32": [_P, _P, _P, _P, _P, _I, _I, _I],
+    "pl_relu_f32": [_P, _P, _P, _Z],
+    "pl_leakyrelu_f32": [_P, _P, _P, _Z, c_double],
+    "pl_sigmoid_f32": [_P, _P, _P, _Z],
+    "pl_add_f32": [_P, _P, _P, _P, _Z],
+    "pl_add_channel_f32": [_P, _P, _P, _P, _I, _I, _I],
+    "pl_pool2d_f32": [_P, _P, _P] + [_I] * 12,
+    "pl_upsample_nearest_f32": [_P, _P, _P, _I, _I, _I, _I, _I],
+    "pl_copy2d_f32": [_P, _P, _Z, _P, _Z, _Z, _Z],
+    "pl_gap_f32": [_P, _P, _P, _I, _I],
+    "pl_splitk_reduce_f32": [_P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _I, c_double],
+    "pl_comm_unique_id": [_P],
+    "pl_comm_init_rank": [_P, _I, _I, _P],
+    "pl_comm_bcast": [_P, _P, _Z, _I],
+    "pl_comm_allreduce_max_f32": [_P, _P, _Z],
+    "pl_comm_allgather": [_P, _P, _P, _Z],
+    "pl_comm_destroy": [_P],
+}
+_RESTYPE = {"pl_last_error": c_char_p}
+
+_lib = None
+
+
+class HipBackendError(RuntimeError):
+    pass
+
+
+def load(path=None):
+    """dlopen the library and declare every prototype; raises if absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or os.environ.get("PLANER_HIP_LIB", LIB_PATH)
+    if not os.path.exists(path):
+        raise HipBackendError(
+            "libplaner_hip.so not found at %s -- build it with "
+            "`python -m planer_amd._build` (needs hipcc, gfx950). "
+            "planer_amd has no CPU fallback." % path)
+    lib = ctypes.CDLL(path)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a symbol is missing
+        fn.argtypes = args
+        fn.restype = _RESTYPE.get(name, c_int)
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc == PL_OK:
+        return
+    msg = load().pl_last_error()
+    msg = msg.decode() if msg else "status %d" % rc
+    if rc == PL_EINVAL:
+        raise ValueError(msg)
+    if rc == PL_EUNSUPPORTED:
+        raise NotImplementedError(msg)
+    if rc == PL_ENOMEM:
+        raise MemoryError(msg)
+    raise HipBackendError(msg)
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args))
+
+
+__all__ = ["load", "check", "call", "HipBackendError", "SIGNATURES", "LIB_PATH",
+           "byref", "c_void_p", "c_int", "c_size_t", "c_float"]

@@ -1,0 +1,95 @@
+// Shared internals of libplaner_hip.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <map>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/planer_hip.h"
+
+void pl_set_error(const char *fmt, ...);
+
+#define PL_HIP(expr)                                                          \
+    do {                                                                      \
+        hipError_t e_ = (expr);                                               \
+        if (e_ != hipSuccess) {                                               \
+            pl_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,        \
+                         hipGetErrorString(e_));                              \
+            return PL_EHIP;                                                   \
+        }                                                                     \
+    } while (0)
+
+#define PL_REQUIRE(cond, code, ...)                                           \
+    do {                                                                      \
+        if (!(cond)) {                                                        \
+            pl_set_error(__VA_ARGS__);                                        \
+            return (code);                                                    \
+        }                                                                     \
+    } while (0)
+
+// Launch-error check that is legal during stream capture.
+#define PL_LAUNCH_CHECK()                                                     \
+    do {                                                                      \
+        hipError_t e_ = hipGetLastError();                                    \
+        if (e_ != hipSuccess) {                                               \
+            pl_set_error("%s:%d: kernel launch -> %s", __FILE__, __LINE__,    \
+                         hipGetErrorString(e_));                              \
+            return PL_EHIP;                                                   \
+        }                                                                     \
+    } while (0)
+
+struct pl_graph;
+
+// One device, one stream, one caching pool.  All pool state is guarded by mu.
+struct pl_ctx {
+    int device = 0;
+    int cu_count = 0;
+    size_t hbm_bytes = 0;
+    std::string arch;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+
+    // caching pool: every block ever hipMalloc'ed by this context
+    std::unordered_map<void *, size_t> block_size;
+    std::multimap<size_t, void *> free_blocks;
+    std::unordered_set<void *> live;         // blocks currently handed out
+    size_t reserved = 0, in_use = 0;
+
+    // capture state: blocks handed out while capturing belong to the graph
+    bool capturing = false;
+    std::unordered_set<void *> cap_blocks;
+    std::multimap<size_t, void *> cap_free;
+    std::unordered_set<void *> graph_owned;  // pl_free on these is a no-op
+
+    // conv tuning overrides
+    int conv_cfg = -1;
+    int conv_split_k = 0;
+
+    // RCCL (dlopen'ed on first use)
+    void *comm = nullptr;
+    int world = 1, rank = 0;
+};
+
+struct pl_graph {
+    pl_ctx *ctx = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    std::vector<void *> blocks;
+};
+
+struct pl_event {
+    pl_ctx *ctx = nullptr;
+    hipEvent_t ev = nullptr;
+};
+
+struct CtxGuard {  // make the context's device current for this call
+    explicit CtxGuard(pl_ctx *c) { (void)hipSetDevice(c->device); }
+};
+
+static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }

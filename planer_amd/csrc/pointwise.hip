@@ -1,0 +1,347 @@
+// HBM-bound kernels of planer's forward pass: BatchNorm, ReLU, LeakyReLU,
+// Sigmoid, Add, Maxpool/AveragePool, nearest UpSample, Concat copies, global
+// average pool and the split-K combine.  Each moves its algorithmic bytes
+// once: 16-byte vector loads/stores, grid capped near 8 blocks per CU with a
+// grid-stride loop, wave64 shuffles for the one reduction.
+#include "common.h"
+#include "device_utils.h"
+
+namespace {
+
+constexpr int TPB = 256;
+
+inline unsigned stream_grid(pl_ctx *ctx, size_t work_items) {
+    size_t blocks = (work_items + TPB - 1) / TPB;
+    size_t cap = (size_t)(ctx->cu_count > 0 ? ctx->cu_count : 256) * 8;
+    if (blocks > cap) blocks = cap;
+    return blocks ? (unsigned)blocks : 1u;
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- unary / binary elementwise -----------------------------------------
+struct OpRelu {
+    __device__ float operator()(float x) const { return relu_ref(x); }
+};
+struct OpLeaky {
+    float a, b;
+    __device__ float operator()(float x) const { return leaky_ref(x, a, b); }
+};
+struct OpSigmoid {
+    // 1/(1+exp(-x)) with an accurate expf; exp overflow gives inf -> result 0
+    __device__ float operator()(float x) const { return __fdiv_rn(1.f, __fadd_rn(expf(-x), 1.f)); }
+};
+
+template <class Op>
+__global__ void __launch_bounds__(TPB) unary_vec4(const float4 *x, float4 *y, size_t n4, Op op) {
+    size_t stride = (size_t)gridDim.x * TPB;
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n4; i += stride) {
+        float4 v = x[i];
+        v.x = op(v.x); v.y = op(v.y); v.z = op(v.z); v.w = op(v.w);
+        y[i] = v;
+    }
+}
+
+template <class Op>
+__global__ void __launch_bounds__(TPB) unary_scalar(const float *x, float *y, size_t n, Op op) {
+    size_t stride = (size_t)gridDim.x * TPB;
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n; i += stride) y[i] = op(x[i]);
+}
+
+template <class Op>
+int launch_unary(pl_ctx *ctx, const float *x, float *y, size_t n, Op op) {
+    PL_REQUIRE(ctx && (n == 0 || (x && y)), PL_EINVAL, "elementwise: null argument");
+    if (!n) return PL_OK;
+    CtxGuard g(ctx);
+    size_t n4 = 0;
+    if (aligned16(x) && aligned16(y)) {
+        n4 = n / 4;
+        if (n4) unary_vec4<<<stream_grid(ctx, n4), TPB, 0, ctx->stream>>>((const float4 *)x, (float4 *)y, n4, op);
+    }
+    size_t done = n4 * 4;
+    if (done < n) unary_scalar<<<stream_grid(ctx, n - done), TPB, 0, ctx->stream>>>(x + done, y + done, n - done, op);
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
+
+__global__ void __launch_bounds__(TPB) add_vec4(const float4 *a, const float4 *b, float4 *y, size_t n4) {
+    size_t stride = (size_t)gridDim.x * TPB;
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n4; i += stride) {
+        float4 u = a[i], v = b[i];
+        y[i] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+    }
+}
+
+__global__ void __launch_bounds__(TPB) add_scalar(const float *a, const float *b, float *y, size_t n) {
+    size_t stride = (size_t)gridDim.x * TPB;
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n; i += stride) y[i] = a[i] + b[i];
+}
+
+// ---- per-channel affine (BatchNorm) and channel-broadcast add -------------
+// x viewed as (outer, C, inner); one block row per (outer, c) plane chunk so
+// the channel lookup is uniform per block instead of a division per element.
+template <bool HAS_SCALE>
+__global__ void __launch_bounds__(TPB) affine_plane(const float *x, float *y, const float *scale,
+                                                    const float *shift, int C, int inner, FastDiv divC) {
+    // blockIdx.y = plane (outer*C + c), blockIdx.x strides over the plane
+    const unsigned plane = blockIdx.y;
+    const unsigned c = plane - divC.div(plane) * (unsigned)C;
+    const float s = HAS_SCALE ? scale[c] : 1.f;
+    const float t = shift ? shift[c] : 0.f;
+    const float *xp = x + (size_t)plane * inner;
+    float *yp = y + (size_t)plane * inner;
+    for (int i = blockIdx.x * TPB + threadIdx.x; i < inner; i += gridDim.x * TPB) {
+        float v = xp[i];
+        if (HAS_SCALE) v = __fmul_rn(v, s);
+        yp[i] = __fadd_rn(v, t);
+    }
+}
+
+// flat form for small planes (e.g. 7x7): 4 consecutive elements per thread
+template <bool HAS_SCALE>
+__global__ void __launch_bounds__(TPB) affine_flat(const float *x, float *y, const float *scale,
+                                                   const float *shift, size_t n, int C, FastDiv divInner,
+                                                   FastDiv divC) {
+    size_t stride = (size_t)gridDim.x * TPB;
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n; i += stride) {
+        unsigned plane = divInner.div((unsigned)i);
+        unsigned c = plane - divC.div(plane) * (unsigned)C;
+        float v = x[i];
+        if (HAS_SCALE) v = __fmul_rn(v, scale[c]);
+        y[i] = __fadd_rn(v, shift ? shift[c] : 0.f);
+    }
+}
+
+template <bool HAS_SCALE>
+int launch_affine(pl_ctx *ctx, const float *x, float *y, const float *scale, const float *shift,
+                  int outer, int C, int inner) {
+    PL_REQUIRE(ctx && x && y, PL_EINVAL, "affine: null argument");
+    PL_REQUIRE(outer >= 0 && C > 0 && inner > 0, PL_EINVAL, "affine: bad shape");
+    size_t n = (size_t)outer * C * inner;
+    if (!n) return PL_OK;
+    PL_REQUIRE(n < (1ull << 32), PL_EUNSUPPORTED, "affine: tensor too large");
+    CtxGuard g(ctx);
+    size_t planes = (size_t)outer * C;
+    if (inner >= 1024 && planes <= 65535) {
+        dim3 grid(cdiv(inner, TPB * 4) ? cdiv(inner, TPB * 4) : 1, (unsigned)planes);
+        affine_plane<HAS_SCALE><<<grid, TPB, 0, ctx->stream>>>(x, y, scale, shift, C, inner, FastDiv(C));
+    } else {
+        affine_flat<HAS_SCALE><<<stream_grid(ctx, n), TPB, 0, ctx->stream>>>(x, y, scale, shift, n, C,
+                                                                         FastDiv(inner), FastDiv(C));
+    }
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
+
+// ---- pooling ---------------------------------------------------------------
+// util.pool (util.py:79-92): zero padding; max accumulator starts at -1e4.
+template <int MODE>
+__global__ void __launch_bounds__(TPB) pool2d_kernel(const float *x, float *y, unsigned total, int H, int W,
+                                                     int Ho, int Wo, int kh, int kw, int sh, int sw, int pt,
+                                                     int pl, FastDiv divWo, FastDiv divHo) {
+    unsigned stride = gridDim.x * TPB;
+    for (unsigned i = blockIdx.x * TPB + threadIdx.x; i < total; i += stride) {
+        unsigned row, ow, nc, oh;
+        divWo.divmod(i, row, ow);
+        divHo.divmod(row, nc, oh);
+        const float *xp = x + (size_t)nc * H * W;
+        float acc = MODE == 0 ? -1e4f : 0.f;
+        int h0 = (int)oh * sh - pt, w0 = (int)ow * sw - pl;
+        for (int r = 0; r < kh; ++r) {
+            int hi = h0 + r;
+            bool hok = (unsigned)hi < (unsigned)H;
+            for (int q = 0; q < kw; ++q) {
+                int wi = w0 + q;
+                float v = (hok && (unsigned)wi < (unsigned)W) ? xp[(size_t)hi * W + wi] : 0.f;
+                acc = MODE == 0 ? fmaxf(v, acc) : acc + v;
+            }
+        }
+        if (MODE == 1) acc = __fdiv_rn(acc, (float)(kh * kw));
+        y[i] = acc;
+    }
+}
+
+// ---- nearest upsample --------------------------------------------------------
+__global__ void __launch_bounds__(TPB) upsample_kernel(const float *x, float *y, unsigned total, int H, int W,
+                                                       int OH, int OW, FastDiv divOW, FastDiv divOH,
+                                                       FastDiv divFh, FastDiv divFw) {
+    unsigned stride = gridDim.x * TPB;
+    for (unsigned i = blockIdx.x * TPB + threadIdx.x; i < total; i += stride) {
+        unsigned row, ow, nc, oh;
+        divOW.divmod(i, row, ow);
+        divOH.divmod(row, nc, oh);
+        y[i] = x[((size_t)nc * H + divFh.div(oh)) * W + divFw.div(ow)];
+    }
+}
+
+// ---- strided row copy (concat) -------------------------------------------------
+__global__ void __launch_bounds__(TPB) copy2d_vec4(float4 *dst, size_t dst_pitch4, const float4 *src,
+                                                   size_t src_pitch4, unsigned width4, unsigned total4,
+                                                   FastDiv divW) {
+    unsigned stride = gridDim.x * TPB;
+    for (unsigned i = blockIdx.x * TPB + threadIdx.x; i < total4; i += stride) {
+        unsigned r, c;
+        divW.divmod(i, r, c);
+        dst[(size_t)r * dst_pitch4 + c] = src[(size_t)r * src_pitch4 + c];
+    }
+}
+
+__global__ void __launch_bounds__(TPB) copy2d_scalar(float *dst, size_t dst_pitch, const float *src,
+                                                     size_t src_pitch, unsigned width, unsigned total,
+                                                     FastDiv divW) {
+    unsigned stride = gridDim.x * TPB;
+    for (unsigned i = blockIdx.x * TPB + threadIdx.x; i < total; i += stride) {
+        unsigned r, c;
+        divW.divmod(i, r, c);
+        dst[(size_t)r * dst_pitch + c] = src[(size_t)r * src_pitch + c];
+    }
+}
+
+// ---- global average pool: one wave64 per (n,c) row ------------------------------
+__global__ void __launch_bounds__(TPB) gap_kernel(const float *x, float *y, int rows, int inner, float inv) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * TPB + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * TPB) >> 6;
+    for (int r = wave; r < rows; r += nwaves) {
+        const float *xp = x + (size_t)r * inner;
+        float s = 0.f;
+        for (int i = lane; i < inner; i += 64) s += xp[i];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if (lane == 0) y[r] = s * inv;
+    }
+}
+
+// ---- split-K combine + fused conv tail ---------------------------------------------
+__global__ void __launch_bounds__(TPB) splitk_reduce_kernel(const float *ws, int splits, size_t slab, float *y,
+                                                            unsigned total, int C, FastDiv divInner,
+                                                            FastDiv divC, Epilogue ep) {
+    unsigned stride = gridDim.x * TPB;
+    for (unsigned i = blockIdx.x * TPB + threadIdx.x; i < total; i += stride) {
+        float v = ws[i];
+        for (int z = 1; z < splits; ++z) v += ws[(size_t)z * slab + i];
+        unsigned plane = divInner.div(i);
+        unsigned c = plane - divC.div(plane) * (unsigned)C;
+        y[i] = apply_epilogue(ep, v, (int)c, i);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int pl_relu_f32(pl_ctx *ctx, const float *x, float *y, size_t n) { return launch_unary(ctx, x, y, n, OpRelu{}); }
+
+int pl_leakyrelu_f32(pl_ctx *ctx, const float *x, float *y, size_t n, double alpha) {
+    // layer.py:49: a = array(alpha, f32), b = array(1-alpha, f32)
+    return launch_unary(ctx, x, y, n, OpLeaky{(float)alpha, (float)(1.0 - alpha)});
+}
+
+int pl_sigmoid_f32(pl_ctx *ctx, const float *x, float *y, size_t n) { return launch_unary(ctx, x, y, n, OpSigmoid{}); }
+
+int pl_add_f32(pl_ctx *ctx, const float *a, const float *b, float *y, size_t n) {
+    PL_REQUIRE(ctx && (n == 0 || (a && b && y)), PL_EINVAL, "pl_add_f32: null argument");
+    if (!n) return PL_OK;
+    CtxGuard g(ctx);
+    size_t n4 = 0;
+    if (aligned16(a) && aligned16(b) && aligned16(y)) {
+        n4 = n / 4;
+        if (n4) add_vec4<<<stream_grid(ctx, n4), TPB, 0, ctx->stream>>>((const float4 *)a, (const float4 *)b, (float4 *)y, n4);
+    }
+    size_t done = n4 * 4;
+    if (done < n) add_scalar<<<stream_grid(ctx, n - done), TPB, 0, ctx->stream>>>(a + done, b + done, y + done, n - done);
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
+
+int pl_scale_shift_f32(pl_ctx *ctx, const float *x, float *y, const float *scale, const float *shift,
+                       int outer, int C, int inner) {
+    PL_REQUIRE(scale, PL_EINVAL, "pl_scale_shift_f32: null scale");
+    return launch_affine<true>(ctx, x, y, scale, shift, outer, C, inner);
+}
+
+int pl_add_channel_f32(pl_ctx *ctx, const float *a, const float *b_c, float *y, int outer, int C, int inner) {
+    PL_REQUIRE(b_c, PL_EINVAL, "pl_add_channel_f32: null b");
+    return launch_affine<false>(ctx, a, y, nullptr, b_c, outer, C, inner);
+}
+
+int pl_pool2d_f32(pl_ctx *ctx, const float *x, float *y, int NC, int H, int W, int kh, int kw, int sh, int sw,
+                  int pt, int pl, int pb, int pr, int mode) {
+    PL_REQUIRE(ctx && x && y, PL_EINVAL, "pl_pool2d_f32: null argument");
+    PL_REQUIRE(NC >= 0 && H > 0 && W > 0 && kh > 0 && kw > 0 && sh > 0 && sw > 0, PL_EINVAL, "pl_pool2d_f32: bad shape");
+    PL_REQUIRE(mode == 0 || mode == 1, PL_EINVAL, "pl_pool2d_f32: mode must be 0 (max) or 1 (avg)");
+    // util.pad grows each side by pads[0]/pads[1] only (util.py:8)
+    PL_REQUIRE(pt == pb && pl == pr, PL_EUNSUPPORTED, "asymmetric pads are undefined in the reference (util.py:8)");
+    int Ho = (H + pt + pb - kh + sh) / sh, Wo = (W + pl + pr - kw + sw) / sw;  // util.py:84-85
+    PL_REQUIRE(Ho > 0 && Wo > 0, PL_EINVAL, "pl_pool2d_f32: empty output");
+    size_t total = (size_t)NC * Ho * Wo;
+    if (!total) return PL_OK;
+    PL_REQUIRE(total < (1ull << 32) && (size_t)NC * H * W < (1ull << 32), PL_EUNSUPPORTED, "pool: tensor too large");
+    CtxGuard g(ctx);
+    unsigned grid = stream_grid(ctx, total);
+    if (mode == 0)
+        pool2d_kernel<0><<<grid, TPB, 0, ctx->stream>>>(x, y, (unsigned)total, H, W, Ho, Wo, kh, kw, sh, sw, pt, pl, FastDiv(Wo), FastDiv(Ho));
+    else
+        pool2d_kernel<1><<<grid, TPB, 0, ctx->stream>>>(x, y, (unsigned)total, H, W, Ho, Wo, kh, kw, sh, sw, pt, pl, FastDiv(Wo), FastDiv(Ho));
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
+
+int pl_upsample_nearest_f32(pl_ctx *ctx, const float *x, float *y, int NC, int H, int W, int fh, int fw) {
+    PL_REQUIRE(ctx && x && y, PL_EINVAL, "pl_upsample_nearest_f32: null argument");
+    PL_REQUIRE(NC >= 0 && H > 0 && W > 0 && fh > 0 && fw > 0, PL_EINVAL, "pl_upsample_nearest_f32: bad shape");
+    size_t total = (size_t)NC * H * fh * W * fw;
+    if (!total) return PL_OK;
+    PL_REQUIRE(total < (1ull << 32), PL_EUNSUPPORTED, "upsample: tensor too large");
+    CtxGuard g(ctx);
+    upsample_kernel<<<stream_grid(ctx, total), TPB, 0, ctx->stream>>>(x, y, (unsigned)total, H, W, H * fh, W * fw,
+                                                                  FastDiv(W * fw), FastDiv(H * fh), FastDiv(fh), FastDiv(fw));
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
+
+int pl_copy2d_f32(pl_ctx *ctx, float *dst, size_t dst_pitch, const float *src, size_t src_pitch, size_t width,
+                  size_t rows) {
+    PL_REQUIRE(ctx && (width * rows == 0 || (dst && src)), PL_EINVAL, "pl_copy2d_f32: null argument");
+    PL_REQUIRE(dst_pitch >= width && src_pitch >= width, PL_EINVAL, "pl_copy2d_f32: pitch < width");
+    size_t total = width * rows;
+    if (!total) return PL_OK;
+    PL_REQUIRE(total < (1ull << 32), PL_EUNSUPPORTED, "copy2d: tensor too large");
+    CtxGuard g(ctx);
+    if (aligned16(dst) && aligned16(src) && width % 4 == 0 && dst_pitch % 4 == 0 && src_pitch % 4 == 0) {
+        unsigned w4 = (unsigned)(width / 4), t4 = (unsigned)(total / 4);
+        copy2d_vec4<<<stream_grid(ctx, t4), TPB, 0, ctx->stream>>>((float4 *)dst, dst_pitch / 4, (const float4 *)src,
+                                                                 src_pitch / 4, w4, t4, FastDiv(w4));
+    } else {
+        copy2d_scalar<<<stream_grid(ctx, total), TPB, 0, ctx->stream>>>(dst, dst_pitch, src, src_pitch, (unsigned)width,
+                                                                     (unsigned)total, FastDiv((unsigned)width));
+    }
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
+
+int pl_gap_f32(pl_ctx *ctx, const float *x, float *y, int rows, int inner) {
+    PL_REQUIRE(ctx && x && y, PL_EINVAL, "pl_gap_f32: null argument");
+    PL_REQUIRE(rows >= 0 && inner > 0, PL_EINVAL, "pl_gap_f32: bad shape");
+    if (!rows) return PL_OK;
+    CtxGuard g(ctx);
+    gap_kernel<<<stream_grid(ctx, (size_t)rows * 64), TPB, 0, ctx->stream>>>(x, y, rows, inner, 1.f / (float)inner);
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
+
+int pl_splitk_reduce_f32(pl_ctx *ctx, const float *ws, int splits, float *y, int N, int C, int inner,
+                         const float *bias, const float *scale, const float *shift, const float *res, int act,
+                         double alpha) {
+    PL_REQUIRE(ctx && ws && y && splits >= 1, PL_EINVAL, "pl_splitk_reduce_f32: bad argument");
+    size_t total = (size_t)N * C * inner;
+    if (!total) return PL_OK;
+    PL_REQUIRE(total < (1ull << 32), PL_EUNSUPPORTED, "splitk reduce: tensor too large");
+    CtxGuard g(ctx);
+    Epilogue ep{bias, scale, shift, res, act, (float)alpha, (float)(1.0 - alpha)};
+    splitk_reduce_kernel<<<stream_grid(ctx, total), TPB, 0, ctx->stream>>>(ws, splits, total, y, (unsigned)total, C,
+                                                                        FastDiv(inner), FastDiv(C), ep);
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
+
+}  // extern "C"

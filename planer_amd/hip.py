@@ -1,0 +1,250 @@
+"""The array backend handed to `core()`: device arrays on one MI355X.
+
+The reference's backend is "any module that quacks like numpy"
+(__init__.py:22-38).  This module is the HIP counterpart for planer_amd: it
+offers what Net/layers need from a backend -- `asarray` (host -> device,
+net.py:96-98), `asnumpy` / `DeviceArray.get()` (device -> host, net.py:100)
+-- and nothing more; it is not a numpy clone.
+"""
+import ctypes
+import os
+
+import numpy
+
+from . import _lib
+from ._lib import byref, c_int, c_size_t, c_void_p
+
+float32 = numpy.float32
+
+_default_ctx = None
+
+
+class Context:
+    """One device + one HIP stream + one caching pool (pl_ctx)."""
+
+    def __init__(self, device=0):
+        lib = _lib.load()
+        h = c_void_p()
+        _lib.check(lib.pl_ctx_create(int(device), byref(h)))
+        self.handle = h
+        self.device = int(device)
+        dev, cus, hbm = c_int(), c_int(), c_size_t()
+        name = ctypes.create_string_buffer(64)
+        _lib.check(lib.pl_ctx_info(h, byref(dev), byref(cus), byref(hbm), name, 64))
+        self.cu_count, self.hbm_bytes, self.arch = cus.value, hbm.value, name.value.decode()
+        self.comm = None
+
+    def synchronize(self):
+        _lib.call("pl_sync", self.handle)
+
+    def pool_stats(self):
+        r, u = c_size_t(), c_size_t()
+        _lib.call("pl_pool_stats", self.handle, byref(r), byref(u))
+        return r.value, u.value
+
+    def trim(self):
+        _lib.call("pl_pool_trim", self.handle)
+
+    def set_conv_config(self, cfg=-1, split_k=0):
+        _lib.call("pl_conv2d_set_config", self.handle, int(cfg), int(split_k))
+
+    def close(self):
+        if self.handle is not None:
+            _lib.load().pl_ctx_destroy(self.handle)
+            self.handle = None
+
+
+def device_count():
+    n = c_int()
+    _lib.call("pl_device_count", byref(n))
+    return n.value
+
+
+def context():
+    """Process-wide default context.  One process drives one GPU: the device
+    is PLANER_HIP_DEVICE, else LOCAL_RANK (torchrun-style launch), else 0."""
+    global _default_ctx
+    if _default_ctx is None:
+        dev = os.environ.get("PLANER_HIP_DEVICE", os.environ.get("LOCAL_RANK", "0"))
+        _default_ctx = Context(int(dev))
+    return _default_ctx
+
+
+def set_context(ctx):
+    global _default_ctx
+    _default_ctx = ctx
+
+
+def synchronize():
+    context().synchronize()
+
+
+class Event:
+    def __init__(self, ctx=None):
+        self.ctx = ctx or context()
+        h = c_void_p()
+        _lib.call("pl_event_create", self.ctx.handle, byref(h))
+        self.handle = h
+
+    def record(self):
+        _lib.call("pl_event_record", self.ctx.handle, self.handle)
+        return self
+
+    def elapsed_ms(self, stop):
+        ms = ctypes.c_float()
+        _lib.call("pl_event_elapsed_ms", self.handle, stop.handle, byref(ms))
+        return ms.value
+
+    def __del__(self):
+        try:
+            if self.handle is not None:
+                _lib.load().pl_event_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class DeviceArray:
+    """Dense, C-contiguous array in HBM.  Views (reshape, a[i]) share the
+    owner's allocation and keep it alive; the owner returns its block to the
+    context pool when it is garbage collected, which is what implements the
+    reference's liveness-based freeing of intermediates (net.py:51-53)."""
+
+    __slots__ = ("shape", "dtype", "ptr", "ctx", "base", "host", "_owned", "__weakref__")
+
+    def __init__(self, shape, dtype=numpy.float32, ctx=None, ptr=None, base=None, host=None):
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = numpy.dtype(dtype)
+        self.ctx = ctx or (base.ctx if base is not None else context())
+        self.base, self.host, self._owned = base, host, False
+        if ptr is None:
+            p = c_void_p()
+            _lib.call("pl_alloc", self.ctx.handle, max(self.nbytes, 1), byref(p))
+            self.ptr, self._owned = p.value, True
+        else:
+            self.ptr = int(ptr)
+
+    # -- numpy-like metadata ------------------------------------------------
+    @property
+    def size(self):
+        n = 1
+        for s in self.shape:
+            n *= s
+        return n
+
+    @property
+    def nbytes(self):
+        return self.size * self.dtype.itemsize
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    def __len__(self):
+        if not self.shape:
+            raise TypeError("len() of unsized object")
+        return self.shape[0]
+
+    def __repr__(self):
+        return "DeviceArray(shape=%s, dtype=%s, dev=%d)" % (self.shape, self.dtype, self.ctx.device)
+
+    # -- views ----------------------------------------------------------------
+    def _view(self, shape, offset_bytes=0):
+        owner = self.base if self.base is not None else self
+        return DeviceArray(shape, self.dtype, self.ctx, self.ptr + offset_bytes, owner)
+
+    def reshape(self, *shape):
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list)):
+            shape = tuple(shape[0])
+        shape = [int(s) for s in shape]
+        if -1 in shape:
+            known = 1
+            for s in shape:
+                if s != -1:
+                    known *= s
+            shape[shape.index(-1)] = self.size // known if known else 0
+        n = 1
+        for s in shape:
+            n *= s
+        if n != self.size:
+            raise ValueError("cannot reshape array of size %d into shape %s" % (self.size, tuple(shape)))
+        v = self._view(shape)
+        if self.host is not None:
+            v.host = self.host.reshape(shape)
+        return v
+
+    def __getitem__(self, i):
+        """a[i] for an integer i: the i-th slab along axis 0 (net.py:101)."""
+        if not isinstance(i, (int, numpy.integer)):
+            raise TypeError("DeviceArray supports integer indexing only")
+        n = self.shape[0]
+        i = i + n if i < 0 else i
+        if not 0 <= i < n:
+            raise IndexError(i)
+        step = self.nbytes // n if n else 0
+        return self._view(self.shape[1:], i * step)
+
+    # -- transfers ----------------------------------------------------------------
+    def get(self):
+        """Device -> host copy (synchronises the stream), cupy's `.get()`."""
+        out = numpy.empty(self.shape, self.dtype)
+        if out.nbytes:
+            _lib.call("pl_d2h", self.ctx.handle, out.ctypes.data, self.ptr, out.nbytes)
+        return out
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.get()
+        return a if dtype is None else a.astype(dtype)
+
+    def set(self, host):
+        host = numpy.ascontiguousarray(host, dtype=self.dtype)
+        if host.shape != self.shape:
+            raise ValueError("shape mismatch %s vs %s" % (host.shape, self.shape))
+        if host.nbytes:
+            _lib.call("pl_h2d", self.ctx.handle, self.ptr, host.ctypes.data, host.nbytes)
+        return self
+
+    def copy_from(self, other):
+        if other.nbytes != self.nbytes:
+            raise ValueError("size mismatch")
+        _lib.call("pl_d2d", self.ctx.handle, self.ptr, other.ptr, self.nbytes)
+        return self
+
+    def copy(self):
+        return DeviceArray(self.shape, self.dtype, self.ctx).copy_from(self)
+
+    def __del__(self):
+        try:
+            if self._owned and self.ptr and self.ctx.handle is not None:
+                _lib.load().pl_free(self.ctx.handle, self.ptr)
+        except Exception:
+            pass
+
+
+ndarray = DeviceArray
+
+
+def empty(shape, dtype=numpy.float32, ctx=None):
+    if isinstance(shape, (int, numpy.integer)):
+        shape = (shape,)
+    return DeviceArray(shape, dtype, ctx)
+
+
+def zeros(shape, dtype=numpy.float32, ctx=None):
+    a = empty(shape, dtype, ctx)
+    if a.nbytes:
+        _lib.call("pl_memset", a.ctx.handle, a.ptr, 0, a.nbytes)
+    return a
+
+
+def asarray(a, dtype=None, ctx=None):
+    """Host ndarray -> DeviceArray (net.py:96-98); DeviceArrays pass through."""
+    if isinstance(a, DeviceArray):
+        return a
+    host = numpy.ascontiguousarray(a, dtype=dtype)
+    return DeviceArray(host.shape, host.dtype, ctx).set(host)
+
+
+def asnumpy(a, **key):
+    """DeviceArray -> host ndarray (what core() installs as np.asnumpy,
+    __init__.py:36); host arrays pass through."""
+    return a.get() if isinstance(a, DeviceArray) else numpy.asarray(a)

@@ -1,0 +1,286 @@
+"""planer's operator table on MI355X.
+
+Same contract as the reference's `layer_map` (layer.py:262-281): every entry
+is `f(*arrays, **json_params)` with the reference's positional order, keyword
+names and defaults, and `wrap(f, kind)(**params)` gives the Layer objects
+`Net` instantiates (layer.py:6-13).  Here every function takes and returns
+`DeviceArray`s and enqueues hand-written HIP kernels through the C ABI
+(include/planer_hip.h); nothing in this module computes on the host.
+
+Ops of the reference's table that no BASELINE config reaches are listed in
+`NOT_ON_DEVICE` and raise NotImplementedError instead of silently running on
+the CPU.
+"""
+import numpy
+
+from . import _lib
+from .hip import DeviceArray, empty
+
+ACT_NONE, ACT_RELU, ACT_LEAKY = _lib.ACT_NONE, _lib.ACT_RELU, _lib.ACT_LEAKY
+
+
+def wrap(f, layername="layer"):
+    """layer.wrap (layer.py:6-13): bind json params to an operator."""
+    class Layer:
+        name = layername
+
+        def __init__(self, **key):
+            self.key = key
+
+        def para(self):
+            return self.key
+
+        def forward(self, *x):
+            return f(*x, **self.key)
+
+        __call__ = forward
+    Layer.__name__ = "Layer_" + layername
+    return Layer
+
+
+# ---- helpers -----------------------------------------------------------------
+def _f32(*arrays):
+    for a in arrays:
+        if a is not None:
+            if not isinstance(a, DeviceArray):
+                raise TypeError("expected DeviceArray, got %s (use planer_amd.asarray)" % type(a).__name__)
+            if a.dtype != numpy.float32:
+                raise NotImplementedError("the HIP path computes in float32, got %s" % a.dtype)
+
+
+def _ptr(a):
+    return None if a is None else a.ptr
+
+
+def _host_values(t):
+    """Small parameter tensors (UpSample's scale vector) are read on the host;
+    weights keep a host mirror so this never synchronises the stream."""
+    if isinstance(t, DeviceArray):
+        return t.host if t.host is not None else t.get()
+    return numpy.asarray(t)
+
+
+def conv_out_hw(h, w, kh, kw, strides, dilations, pads):
+    """util.py:25-26"""
+    ho = (h + pads[0] + pads[2] - (kh - 1) * dilations[0] - 1 + strides[0]) // strides[0]
+    wo = (w + pads[1] + pads[3] - (kw - 1) * dilations[1] - 1 + strides[1]) // strides[1]
+    return ho, wo
+
+
+# ---- MFMA-bound ------------------------------------------------------------------
+def Conv2d(x, K, B=None, group=1, strides=(1, 1), dilations=(1, 1), pads=(0, 0, 0, 0)):
+    """layer.Conv2d (layer.py:22-26): implicit-GEMM conv + bias on fp32 MFMA."""
+    return ConvFused(x, K, B, group=group, strides=strides, dilations=dilations, pads=pads)
+
+
+def ConvFused(x, K, B=None, scale=None, shift=None, res=None, group=1, strides=(1, 1),
+              dilations=(1, 1), pads=(0, 0, 0, 0), act=ACT_NONE, alpha=0.0):
+    """Conv2d with BatchNorm / Add / (Leaky)ReLU folded into its epilogue:
+    act((conv(x,K)+B)*scale + shift + res).  Emitted by Net's plan compiler for
+    the chains conv->batchnorm->[add]->[relu|leakyrelu]; not a reference op."""
+    _f32(x, K, B, scale, shift, res)
+    n, cin, h, w = x.shape
+    cout, cin_g, kh, kw = K.shape
+    if cin_g * group != cin:
+        raise ValueError("conv: weight %s does not match input %s with group=%d" % (K.shape, x.shape, group))
+    pads = [int(p) for p in pads]
+    strides = [int(s) for s in strides]
+    dilations = [int(d) for d in dilations]
+    ho, wo = conv_out_hw(h, w, kh, kw, strides, dilations, pads)
+    y = empty((n, cout, ho, wo), ctx=x.ctx)
+    if res is not None and res.size != y.size:
+        raise ValueError("fused residual shape %s != conv output %s" % (res.shape, y.shape))
+    _lib.call("pl_conv2d_fused_f32", x.ctx.handle, x.ptr, n, cin, h, w, K.ptr, cout, kh, kw,
+              _ptr(B), y.ptr, strides[0], strides[1], dilations[0], dilations[1],
+              pads[0], pads[1], pads[2], pads[3], int(group),
+              _ptr(scale), _ptr(shift), _ptr(res), int(act), float(alpha))
+    return y
+
+
+def Dense(x, K, B, shp=None):
+    """layer.Dense (layer.py:15-18): x @ K.T + B; `shp` is ignored there too."""
+    _f32(x, K, B)
+    m, k = x.shape
+    n = K.shape[0]
+    y = empty((m, n), ctx=x.ctx)
+    _lib.call("pl_gemm_f32", x.ctx.handle, x.ptr, m, k, K.ptr, n, 1, _ptr(B), y.ptr)
+    return y
+
+
+def MatMul(x, y):
+    """layer.MatMul (layer.py:20) for 2-D operands."""
+    _f32(x, y)
+    if x.ndim != 2 or y.ndim != 2:
+        raise NotImplementedError("MatMul on the HIP path handles 2-D operands")
+    m, k = x.shape
+    n = y.shape[1]
+    out = empty((m, n), ctx=x.ctx)
+    _lib.call("pl_gemm_f32", x.ctx.handle, x.ptr, m, k, y.ptr, n, 0, None, out.ptr)
+    return out
+
+
+# ---- HBM-bound ---------------------------------------------------------------------
+def BatchNorm(x, K, B):
+    """layer.BatchNorm (layer.py:125-127): x*K + B with K,B folded (1,C,1,1)."""
+    _f32(x, K, B)
+    c = x.shape[1]
+    if K.size != c or B.size != c:
+        raise ValueError("batchnorm: K/B must hold one value per channel")
+    inner = x.size // (x.shape[0] * c) if x.size else 1
+    y = empty(x.shape, ctx=x.ctx)
+    _lib.call("pl_scale_shift_f32", x.ctx.handle, x.ptr, y.ptr, K.ptr, B.ptr, x.shape[0], c, max(inner, 1))
+    return y
+
+
+def ReLU(x):
+    """layer.ReLU (layer.py:44-46): in place, returns the SAME array object."""
+    _f32(x)
+    _lib.call("pl_relu_f32", x.ctx.handle, x.ptr, x.ptr, x.size)
+    return x
+
+
+def LeakyReLU(x, alpha=0.2):
+    """layer.LeakyReLU (layer.py:48-51), out of place."""
+    _f32(x)
+    y = empty(x.shape, ctx=x.ctx)
+    _lib.call("pl_leakyrelu_f32", x.ctx.handle, x.ptr, y.ptr, x.size, float(alpha))
+    return y
+
+
+def Sigmoid(x):
+    """layer.Sigmoid (layer.py:61-64), out of place."""
+    _f32(x)
+    y = empty(x.shape, ctx=x.ctx)
+    _lib.call("pl_sigmoid_f32", x.ctx.handle, x.ptr, y.ptr, x.size)
+    return y
+
+
+def Add(x1, x2):
+    """layer.Add (layer.py:93-95): same shape, or a (1|N,C,1,1) operand
+    broadcast over the other (the two forms planer graphs contain)."""
+    _f32(x1, x2)
+    if x1.shape == x2.shape:
+        y = empty(x1.shape, ctx=x1.ctx)
+        _lib.call("pl_add_f32", x1.ctx.handle, x1.ptr, x2.ptr, y.ptr, x1.size)
+        return y
+    big, small = (x1, x2) if x1.size >= x2.size else (x2, x1)
+    if (big.ndim >= 2 and small.ndim == big.ndim and small.shape[0] == 1
+            and small.shape[1] == big.shape[1] and small.size == big.shape[1]):
+        c = big.shape[1]
+        y = empty(big.shape, ctx=big.ctx)
+        _lib.call("pl_add_channel_f32", big.ctx.handle, big.ptr, small.ptr, y.ptr,
+                  big.shape[0], c, big.size // (big.shape[0] * c))
+        return y
+    raise NotImplementedError("add: broadcast %s + %s is not on the HIP path" % (x1.shape, x2.shape))
+
+
+def _pool(x, w, pads, strides, mode):
+    _f32(x)
+    n, c, h, wd = x.shape
+    kh, kw = int(w[0]), int(w[1])
+    sh, sw = int(strides[0]), int(strides[1])
+    pads = [int(p) for p in pads]
+    ho = (h + pads[0] + pads[2] - kh + sh) // sh        # util.py:84
+    wo = (wd + pads[1] + pads[3] - kw + sw) // sw       # util.py:85
+    y = empty((n, c, ho, wo), ctx=x.ctx)
+    _lib.call("pl_pool2d_f32", x.ctx.handle, x.ptr, y.ptr, n * c, h, wd, kh, kw, sh, sw,
+              pads[0], pads[1], pads[2], pads[3], mode)
+    return y
+
+
+def Maxpool(x, w=(2, 2), pads=(0, 0, 0, 0), strides=(2, 2)):
+    """layer.Maxpool (layer.py:71-72): zero padding, accumulator starts at -1e4."""
+    return _pool(x, w, pads, strides, 0)
+
+
+def AveragePool(x, w=(2, 2), pads=(0, 0, 0, 0), strides=(2, 2)):
+    """layer.AveragePool (layer.py:74-75): padding counted in the mean."""
+    return _pool(x, w, pads, strides, 1)
+
+
+def GlobalAveragePool(x):
+    """layer.GlobalAveragePool (layer.py:77-78): mean over H,W, keepdims."""
+    _f32(x)
+    n, c = x.shape[:2]
+    inner = x.size // (n * c) if x.size else 1
+    y = empty((n, c) + (1,) * (x.ndim - 2), ctx=x.ctx)
+    _lib.call("pl_gap_f32", x.ctx.handle, x.ptr, y.ptr, n * c, max(inner, 1))
+    return y
+
+
+def UpSample(x, k, mode="nearest"):
+    """layer.UpSample (layer.py:80-82): nearest-neighbour integer up-scaling,
+    factors = last two entries of the tensor `k`."""
+    _f32(x)
+    if mode != "nearest":
+        raise NotImplementedError("upsample mode %r is not on the HIP path" % mode)
+    kv = _host_values(k)
+    if kv.size == 0:
+        raise ValueError("upsample needs scales (the reference's size-only branch is broken, layer.py:81)")
+    fh, fw = [int(v) for v in kv[-2:].astype(int).tolist()]
+    n, c, h, w = x.shape
+    y = empty((n, c, h * fh, w * fw), ctx=x.ctx)
+    _lib.call("pl_upsample_nearest_f32", x.ctx.handle, x.ptr, y.ptr, n * c, h, w, fh, fw)
+    return y
+
+
+def Concatenate(*xs, axis=0):
+    """layer.Concatenate (layer.py:90-91); default axis 0 as in the reference."""
+    _f32(*xs)
+    nd = xs[0].ndim
+    axis = axis + nd if axis < 0 else axis
+    lead, trail = xs[0].shape[:axis], xs[0].shape[axis + 1:]
+    for a in xs:
+        if a.shape[:axis] != lead or a.shape[axis + 1:] != trail:
+            raise ValueError("concat: shapes differ off the axis: %s" % [b.shape for b in xs])
+    outer = int(numpy.prod(lead, dtype=numpy.int64)) if lead else 1
+    tail = int(numpy.prod(trail, dtype=numpy.int64)) if trail else 1
+    total = sum(a.shape[axis] for a in xs)
+    y = empty(lead + (total,) + trail, ctx=xs[0].ctx)
+    off, pitch = 0, total * tail
+    for a in xs:
+        width = a.shape[axis] * tail
+        if width and outer:
+            _lib.call("pl_copy2d_f32", y.ctx.handle, y.ptr + off * 4, pitch, a.ptr, width, width, outer)
+        off += width
+    return y
+
+
+def Flatten(x):
+    """layer.Flatten (layer.py:59): a view."""
+    return x.reshape((x.shape[0], -1))
+
+
+def Identity(x):
+    return x
+
+
+def Return(*x):
+    """layer.Return (layer.py:260)."""
+    return x
+
+
+def _missing(kind):
+    def op(*a, **k):
+        raise NotImplementedError(
+            "planer op %r has no HIP kernel in planer_amd yet (no BASELINE config uses it); "
+            "there is deliberately no CPU fallback" % kind)
+    op.__name__ = "missing_" + kind
+    return op
+
+
+NOT_ON_DEVICE = ["softmax", "hardsigmoid", "squeeze", "const", "resize", "pad", "convtranspose",
+                 "sub", "reducemean", "exp", "log", "mul", "pow", "tile", "lstm", "reducemax",
+                 "reducemin", "reducesum", "div", "unsqueeze", "shape", "gather", "reshape",
+                 "split", "tanh", "constantofshape", "slice", "expand", "cast", "range", "equal",
+                 "where", "scatternd", "instancenormalization", "clip", "greater", "nonzero",
+                 "greaterorequal", "topk", "sqrt", "erf", "reciprocal", "transpose", "logsoftmax"]
+
+layer_map = {"dense": Dense, "conv": Conv2d, "relu": ReLU, "leakyrelu": LeakyReLU,
+             "batchnorm": BatchNorm, "flatten": Flatten, "sigmoid": Sigmoid,
+             "maxpool": Maxpool, "averagepool": AveragePool, "upsample": UpSample,
+             "concat": Concatenate, "add": Add, "gap": GlobalAveragePool, "matmul": MatMul,
+             "identity": Identity, "return": Return,
+             # plan-compiler internal
+             "conv_fused": ConvFused}
+layer_map.update({k: _missing(k) for k in NOT_ON_DEVICE})

@@ -1,0 +1,289 @@
+"""planer's graph executor (`Net`) on MI355X.
+
+Public surface and IR semantics are the reference's (net.py:5-101):
+`load_json(inputs, inits, body, flow)`, `load_weights(uint8 blob)`,
+`forward`, `__call__` (dict or positional inputs, host ndarray in -> host
+ndarray out, the `rst[0] if len(rst)==1` unwrapping), `run`, `timeit`,
+`timer`, liveness-based freeing of intermediates, chained layers and
+multi-output steps.
+
+What is new underneath (MI355X-first, no counterpart in the reference):
+  * weights live in ONE device allocation (256-byte aligned slots) so the
+    multi-GPU weight exchange is a single RCCL broadcast;
+  * `forward` enqueues one hand-written HIP kernel per layer on the context
+    stream and never synchronises;
+  * `__call__` on device-resident inputs runs a *compiled plan*: the flow is
+    peephole-fused (conv -> batchnorm -> [add] -> [relu|leakyrelu] become one
+    MFMA kernel with a fused epilogue), executed once to warm the memory
+    pool, then captured into a hipGraph that is replayed with a single C call
+    per forward pass.
+"""
+import os
+import time
+
+import numpy
+
+from . import _lib
+from . import hip
+from .hip import DeviceArray
+from .layer import layer_map, wrap
+from .plan import fuse_flow
+
+_ALIGN = 256
+
+
+def _as_list(v):
+    return list(v) if isinstance(v, (list, tuple)) else [v]
+
+
+class _Program:
+    """A flow ready to interpret: layer objects, steps and last-use table."""
+
+    def __init__(self, body, flow):
+        self.objs = {name: wrap(layer_map[kind], kind)(**para) for name, kind, para in body}
+        self.flow = flow
+        self.life = {}
+        for i, step in enumerate(flow):
+            for k in _as_list(step[0]):
+                self.life[k] = i                     # net.py:16-19
+
+
+def prog_body(prog):
+    return [(name, obj.name) for name, obj in prog.objs.items()]
+
+
+class _Plan:
+    """One captured forward pass for one input signature."""
+
+    def __init__(self, inputs, outputs, graph, ctx, fused_steps):
+        self.inputs, self.outputs, self.graph, self.ctx = inputs, outputs, graph, ctx
+        self.fused_steps = fused_steps
+
+    def launch(self):
+        _lib.call("pl_graph_launch", self.graph)
+
+    def __del__(self):
+        try:
+            self.outputs = self.inputs = None      # drop buffers before their graph
+            if self.graph is not None:
+                _lib.load().pl_graph_destroy(self.graph)
+        except Exception:
+            pass
+
+
+class Net:
+    def __init__(self, ctx=None):
+        self.weights, self.body, self.flow = [], [], []
+        self.life, self.timer = {}, {}
+        self.input, self.inits, self.layer = [], [], []
+        self.ctx = ctx
+        self.use_graph = os.environ.get("PLANER_HIP_GRAPH", "1") != "0"
+        self.use_fusion = os.environ.get("PLANER_HIP_FUSE", "1") != "0"
+        self.profile = os.environ.get("PLANER_HIP_PROFILE", "0") == "1"
+        self.device_timer = {}       # kind -> ms of device time (profile mode)
+        self.last_events = []        # [(layer name, kind, ms)] of the last profiled forward
+        self._blob = None
+        self._slots = []             # (offset, nbytes) per weight inside the blob
+        self._program = None
+        self._plans = {}
+
+    # ---- loading ----------------------------------------------------------------
+    def load_json(self, inputs, inits, body, flow, debug=False):
+        """net.py:10-24.  Unknown layer kinds raise KeyError like the reference."""
+        self.ctx = self.ctx or hip.context()
+        if debug:
+            for i in body:
+                print(i)
+        self._program = _Program(body, flow)
+        self.body = list(self._program.objs.items())
+        self.life = self._program.life
+        self.input, self.inits = inputs, [i[0] for i in inits]
+        self.layer, self.flow = body, flow
+        # one device allocation for every weight; slots padded to 256 B
+        self._slots, off = [], 0
+        for _, shape, dt in inits:
+            nbytes = int(numpy.prod(shape, dtype=numpy.int64)) * numpy.dtype(dt).itemsize
+            self._slots.append((off, nbytes))
+            off += (nbytes + _ALIGN - 1) // _ALIGN * _ALIGN
+        self._blob = hip.zeros((max(off, 1),), numpy.uint8, self.ctx)
+        self._host = numpy.zeros(max(off, 1), numpy.uint8)
+        self.weights = []
+        for (o, nbytes), (_, shape, dt) in zip(self._slots, inits):
+            host = self._host[o:o + nbytes].view(dt).reshape(shape)
+            self.weights.append(DeviceArray(shape, dt, self.ctx, self._blob.ptr + o, self._blob, host))
+        self._plans = {}
+
+    def load_weights(self, data):
+        """net.py:83-88: `data` holds the raw bytes of every init back to back."""
+        raw = numpy.ascontiguousarray(data).view(numpy.uint8).ravel()
+        need = sum(n for _, n in self._slots)
+        if raw.size < need:
+            raise ValueError("weight blob has %d bytes, the graph needs %d" % (raw.size, need))
+        pos = 0
+        for o, n in self._slots:
+            self._host[o:o + n] = raw[pos:pos + n]
+            pos += n
+        self._blob.set(self._host)
+        self._plans = {}
+
+    def weight_blob(self):
+        """The single device allocation holding all weights (RCCL broadcast unit)."""
+        return self._blob
+
+    def refresh_host_mirror(self):
+        """Re-read the host mirror after the device blob was written by a broadcast."""
+        self._host[:] = self._blob.get()
+
+    def half(self):
+        raise NotImplementedError("planer_amd computes the hot path in float32 only (BASELINE metric)")
+
+    def show(self):
+        raise NotImplementedError("plot_net is missing from the reference snapshot too (net.py:90-92)")
+
+    def info(self, obj):
+        if isinstance(obj, (list, tuple)):
+            return [self.info(i) for i in obj]
+        return obj.shape if hasattr(obj, "shape") else obj
+
+    # ---- eager interpreter ---------------------------------------------------------
+    def _interpret(self, prog, xs, debug=False, shapes=None, profile=False):
+        """net.py:37-72: one kernel launch (or view) per layer, in flow order."""
+        env = {"None": None}
+        env.update(zip(self.inits, self.weights))
+        env.update(zip(self.input, xs))
+        events, out_key = [], None
+        for i, (src, names, dst) in enumerate(prog.flow):
+            for pos, name in enumerate(_as_list(names)):
+                keys = src if pos == 0 else dst                  # chained layers
+                args = [env[keys]] if isinstance(keys, str) else [env.get(k) for k in keys]
+                for k in set(_as_list(src)):
+                    if k in env and prog.life[k] <= i:
+                        del env[k]                               # release dead inputs
+                obj = prog.objs[name]
+                if debug:
+                    print(name, obj.name, ":", obj.para())
+                    print("\t--> ", keys, ":", self.info(args))
+                t0 = time.time()
+                if profile:
+                    e0 = hip.Event(self.ctx).record()
+                val = obj(*args)
+                if profile:
+                    events.append((name, obj.name, e0, hip.Event(self.ctx).record()))
+                del args
+                if isinstance(dst, str):
+                    env[dst] = val
+                else:
+                    env.update(zip(dst, val))
+                if debug:
+                    for k in _as_list(dst):
+                        print("\t<-- ", k, ":", self.info(env[k]))
+                if shapes is not None:
+                    for k in _as_list(dst):
+                        shapes[k] = getattr(env[k], "shape", None)
+                self.timer[obj.name] = self.timer.get(obj.name, 0) + time.time() - t0
+                del val
+            out_key = dst
+        if profile:
+            self.last_events = []
+            for name, kind, e0, e1 in events:
+                ms = e0.elapsed_ms(e1)
+                self.last_events.append((name, kind, ms))
+                self.device_timer[kind] = self.device_timer.get(kind, 0.0) + ms
+        return env[out_key]
+
+    def forward(self, *x, debug=False):
+        """Per-layer execution of the flow exactly as written (no fusion)."""
+        return self._interpret(self._program, x, debug=debug, profile=self.profile)
+
+    def timeit(self, status="start"):
+        """net.py:74-77"""
+        if status == "start":
+            self.timer, self.device_timer = {}, {}
+        if status == "end":
+            for k in self.timer:
+                print(k, self.timer[k])
+
+    def run(self, output=None, input={}):
+        """onnxruntime-style entry (net.py:79-81)"""
+        rst = self(input)
+        return rst if isinstance(rst, tuple) else (rst,)
+
+    # ---- plan compiler -----------------------------------------------------------------
+    def _fuse(self, shapes):
+        body, flow, nfused = fuse_flow(self.layer, self.flow, self.inits, shapes)
+        return _Program(body, flow), nfused
+
+    def compile(self, *xs):
+        """Build (or fetch) the captured plan for these device inputs."""
+        key = tuple((a.shape, str(a.dtype)) for a in xs)
+        plan = self._plans.get(key)
+        if plan is not None:
+            return plan
+        ctx = self.ctx
+        statics = [DeviceArray(a.shape, a.dtype, ctx).copy_from(a) for a in xs]
+        shapes = {k: a.shape for k, a in zip(self.input, xs)}
+        shapes.update({k: w.shape for k, w in zip(self.inits, self.weights)})
+        # 1) unfused eager pass: validates the graph and records every shape.
+        #    ReLU works in place, so feed it copies, not the static inputs.
+        timer = dict(self.timer)
+        self._interpret(self._program, [s.copy() for s in statics], shapes=shapes)
+        prog, nfused = (self._fuse(shapes) if self.use_fusion else (self._program, 0))
+        # 2) fused eager pass warms the pool with exactly the blocks the capture will ask for
+        self._interpret(prog, [s.copy() for s in statics])
+        ctx.synchronize()
+        # 3) capture
+        #    A static input is only copied first if a step could overwrite it in place.
+        kinds = {b[0]: b[1] for b in prog_body(prog)}
+        inplace = set()
+        for src, names, dst in prog.flow:
+            if kinds.get(_as_list(names)[0]) in ("relu", "flatten", "identity", "return"):
+                inplace.update(_as_list(src))
+        _lib.call("pl_capture_begin", ctx.handle)
+        try:
+            work = []
+            for k, s in zip(self.input, statics):
+                if k in inplace:
+                    s = DeviceArray(s.shape, s.dtype, ctx).copy_from(s)
+                work.append(s)
+            out = self._interpret(prog, work)
+            del work
+        except Exception:
+            g = _lib.c_void_p()
+            _lib.load().pl_capture_end(ctx.handle, _lib.byref(g))
+            if g.value:
+                _lib.load().pl_graph_destroy(g)
+            raise
+        g = _lib.c_void_p()
+        _lib.call("pl_capture_end", ctx.handle, _lib.byref(g))
+        self.timer = timer
+        plan = _Plan(statics, out, g, ctx, nfused)
+        self._plans[key] = plan
+        return plan
+
+    def _replay(self, xs):
+        plan = self.compile(*xs)
+        for s, a in zip(plan.inputs, xs):
+            if a is not s:
+                s.copy_from(a)
+        plan.launch()
+        out = plan.outputs
+        # hand back private copies: the plan's buffers are rewritten by the next replay
+        if isinstance(out, tuple):
+            return tuple(o.copy() if isinstance(o, DeviceArray) else o for o in out)
+        return out.copy() if isinstance(out, DeviceArray) else out
+
+    # ---- entry point ---------------------------------------------------------------------
+    def __call__(self, *x, **key):
+        """net.py:94-101."""
+        if type(x[0]) is dict:
+            x = [x[0][i] for i in self.input]
+        host = [isinstance(i, numpy.ndarray) for i in x]
+        need = any(host)
+        if need:
+            x = [hip.asarray(i, ctx=self.ctx) if b else i for i, b in zip(x, host)]
+        graphable = (self.use_graph and not key.get("debug") and not self.profile
+                     and all(isinstance(i, DeviceArray) for i in x))
+        rst = self._replay(list(x)) if graphable else self.forward(*x, **key)
+        if need:
+            rst = tuple(i.get() for i in rst) if isinstance(rst, tuple) else rst.get()
+        return rst[0] if len(rst) == 1 else rst

@@ -1,0 +1,71 @@
+"""C-ABI checks that need no GPU: the library loads, exports every symbol
+include/planer_hip.h declares, the ctypes table matches the header, and the
+product refuses to run without a device (no CPU fallback)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from planer_amd import _lib
+from tests.conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "planer_hip.h")
+
+
+def header_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pl_[a-z0-9_]+)\s*\(", text)))
+
+
+def _built():
+    return os.path.exists(_lib.LIB_PATH)
+
+
+def test_header_and_ctypes_table_agree():
+    assert header_functions() == sorted(_lib.SIGNATURES)
+
+
+@pytest.mark.skipif(not _built(), reason="libplaner_hip.so not built")
+def test_library_exports_every_declared_symbol():
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r"\bT (pl_[a-z0-9_]+)$", out, flags=re.M))
+    missing = [f for f in header_functions() if f not in exported]
+    assert not missing, missing
+    lib = _lib.load()            # declares argtypes for every entry: AttributeError if absent
+    assert lib.pl_version() >= 100
+    assert lib.pl_conv2d_num_configs() >= 4
+
+
+@pytest.mark.skipif(not _built(), reason="libplaner_hip.so not built")
+def test_no_device_means_loud_failure():
+    import ctypes
+    lib = _lib.load()
+    n = ctypes.c_int(-1)
+    rc = lib.pl_device_count(ctypes.byref(n))
+    if rc == 0 and n.value > 0:
+        pytest.skip("a GPU is visible here")
+    import planer_amd
+    from planer_amd.irgen import customnet
+    g, b = customnet.build()
+    with pytest.raises(_lib.HipBackendError):
+        planer_amd.from_graph(g, b)
+
+
+def test_core_has_one_backend():
+    import numpy
+    import planer_amd
+    assert planer_amd.core("hip", silent=True) is planer_amd.hip
+    assert planer_amd.core(planer_amd.hip, silent=True) is planer_amd.hip
+    with pytest.raises(ValueError):
+        planer_amd.core(numpy)
+
+
+def test_product_never_imports_oracle_or_torch():
+    pkg = os.path.join(ROOT, "planer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+(oracle|torch)\b", src, flags=re.M), f

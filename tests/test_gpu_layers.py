@@ -1,0 +1,142 @@
+"""Per-layer parity on a real MI355X: HIP kernels (through the C ABI) vs the
+vectors captured from the reference and vs the oracle.  Tolerance: 1e-4
+relative to max|ref| per tensor (north_star), set in tests/conftest.RTOL."""
+import numpy as np
+import pytest
+
+from oracle import planer_np as onp
+from tests.cases import layer_cases
+from tests.conftest import RTOL, assert_close
+
+pytestmark = pytest.mark.gpu
+CASES = layer_cases()
+
+
+@pytest.fixture(scope="module")
+def pa():
+    import planer_amd
+    planer_amd.hip.context()          # raises loudly without a GPU / library
+    return planer_amd
+
+
+def run_hip(pa, kind, args, params):
+    dev = [pa.asarray(a.copy()) for a in args]
+    out = pa.layer_map[kind](*dev, **params)
+    outs = out if isinstance(out, tuple) else (out,)
+    return dev, outs
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_layer_vs_reference_vectors(pa, case, golden_layers):
+    name, kind, args, params = case
+    z, meta = golden_layers
+    dev, outs = run_hip(pa, kind, args, params)
+    assert len(outs) == meta[name]["n_out"]
+    for i, o in enumerate(outs):
+        ref = z["%s/out%d" % (name, i)]
+        assert o.shape == ref.shape
+        assert_close(o.get(), ref, RTOL, name)
+    # ReLU aliasing: the reference returns its (mutated) input object
+    assert bool(outs[0] is dev[0]) == meta[name]["inplace"]
+
+
+EXACT = ["relu", "leakyrelu_0.1", "leakyrelu_default", "add", "batchnorm", "maxpool_k2s2", "maxpool_k3s2p1_neg",
+         "maxpool_k3s2p1", "maxpool_clamp_-1e4", "upsample_x2", "upsample_2x3", "concat_axis1", "concat_axis0_3",
+         "flatten", "add_bcast_channel"]
+
+
+@pytest.mark.parametrize("name", EXACT)
+def test_copy_and_compare_ops_are_bit_exact(pa, name, golden_layers):
+    """Ops without accumulation must reproduce the reference bit for bit."""
+    z, meta = golden_layers
+    _, kind, args, params = [c for c in CASES if c[0] == name][0]
+    _, outs = run_hip(pa, kind, args, params)
+    np.testing.assert_array_equal(outs[0].get(), z["%s/out0" % name])
+
+
+def test_conv_every_tile_config_and_split_k(pa):
+    """All tile shapes of the implicit-GEMM kernel and the split-K path agree with the oracle."""
+    lib = pa._lib.load()
+    ctx = pa.hip.context()
+    rng = np.random.default_rng(7)
+    shapes = [((3, 24, 14, 14), (40, 24, 3, 3), dict(strides=[1, 1], pads=[1, 1, 1, 1])),
+              ((2, 3, 33, 35), (20, 3, 7, 7), dict(strides=[2, 2], pads=[3, 3, 3, 3])),
+              ((2, 64, 7, 7), (130, 64, 1, 1), dict(strides=[1, 1], pads=[0, 0, 0, 0]))]
+    try:
+        for xs, ks, p in shapes:
+            x = rng.standard_normal(xs).astype(np.float32)
+            k = (rng.standard_normal(ks) * 0.1).astype(np.float32)
+            b = rng.standard_normal(ks[0]).astype(np.float32)
+            ref = np.ascontiguousarray(onp.conv2d(x, k, b, **p))
+            for cfg in range(lib.pl_conv2d_num_configs()):
+                for split in (1, 2, 3):
+                    ctx.set_conv_config(cfg, split)
+                    y = pa.Conv2d(pa.asarray(x), pa.asarray(k), pa.asarray(b), **p).get()
+                    assert_close(y, ref, RTOL, "cfg %d split %d %s" % (cfg, split, xs))
+    finally:
+        ctx.set_conv_config(-1, 0)
+
+
+def test_conv_fused_epilogue_matches_layer_by_layer(pa):
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((2, 16, 12, 12)).astype(np.float32)
+    k = (rng.standard_normal((24, 16, 3, 3)) * 0.1).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, (1, 24, 1, 1)).astype(np.float32)
+    sh = rng.standard_normal((1, 24, 1, 1)).astype(np.float32)
+    res = rng.standard_normal((2, 24, 12, 12)).astype(np.float32)
+    ctx = pa.hip.context()
+    for split in (1, 2):
+        ctx.set_conv_config(-1, split)
+        for act, alpha in ((0, 0.0), (1, 0.0), (2, 0.1)):
+            y = pa.ConvFused(pa.asarray(x), pa.asarray(k), None, pa.asarray(sc), pa.asarray(sh), pa.asarray(res),
+                             pads=[1, 1, 1, 1], act=act, alpha=alpha).get()
+            ref = onp.add(onp.batchnorm(np.ascontiguousarray(onp.conv2d(x, k, pads=[1, 1, 1, 1])), sc, sh), res)
+            ref = onp.relu(ref) if act == 1 else (onp.leakyrelu(ref, alpha) if act == 2 else ref)
+            assert_close(y, ref, RTOL)
+    ctx.set_conv_config(-1, 0)
+
+
+def test_config2_single_conv_full_size(pa):
+    """BASELINE config 2: Conv2d 3->64 k3 s1 p1 on (8,3,224,224), vs the oracle."""
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((8, 3, 224, 224)).astype(np.float32)
+    k = (rng.standard_normal((64, 3, 3, 3)) * 0.1).astype(np.float32)
+    b = rng.standard_normal(64).astype(np.float32)
+    y = pa.Conv2d(pa.asarray(x), pa.asarray(k), pa.asarray(b), strides=[1, 1], pads=[1, 1, 1, 1]).get()
+    assert y.shape == (8, 64, 224, 224)
+    assert_close(y, np.ascontiguousarray(onp.conv2d(x, k, b, pads=[1, 1, 1, 1])), RTOL)
+
+
+def test_conv_linearity_at_resnet_layer_size(pa):
+    """Size-independent property: conv(a*x1 + x2) == a*conv(x1) + conv(x2)."""
+    rng = np.random.default_rng(11)
+    k = pa.asarray((rng.standard_normal((128, 128, 3, 3)) * 0.03).astype(np.float32))
+    x1 = rng.standard_normal((32, 128, 28, 28)).astype(np.float32)
+    x2 = rng.standard_normal((32, 128, 28, 28)).astype(np.float32)
+    f = lambda a: pa.Conv2d(pa.asarray(a), k, strides=[1, 1], pads=[1, 1, 1, 1]).get()
+    assert_close(f(2.5 * x1 + x2), 2.5 * f(x1) + f(x2), RTOL)
+
+
+def test_unsupported_inputs_fail_loudly(pa):
+    x = pa.asarray(np.zeros((1, 4, 8, 8), np.float32))
+    k = pa.asarray(np.zeros((4, 4, 3, 3), np.float32))
+    with pytest.raises(NotImplementedError):          # asymmetric pads: undefined in the reference
+        pa.Conv2d(x, k, pads=[1, 1, 0, 0])
+    with pytest.raises(NotImplementedError):
+        pa.Maxpool(x, w=[2, 2], pads=[1, 0, 0, 0])
+    with pytest.raises(NotImplementedError):
+        pa.layer_map["softmax"](x)
+    with pytest.raises((ValueError, NotImplementedError)):
+        pa.Conv2d(x, pa.asarray(np.zeros((4, 3, 3, 3), np.float32)))
+
+
+def test_empty_and_ragged(pa):
+    e = pa.asarray(np.zeros((0, 4, 8, 8), np.float32))
+    assert pa.ReLU(e).shape == (0, 4, 8, 8)
+    k = pa.asarray(np.ones((4, 4, 3, 3), np.float32))
+    assert pa.Conv2d(e, k, pads=[1, 1, 1, 1]).shape == (0, 4, 8, 8)
+    # unaligned views: a[1] of an odd-sized tensor starts 4*35 bytes in
+    a = np.random.default_rng(5).standard_normal((3, 5, 7)).astype(np.float32)
+    d = pa.asarray(a)
+    np.testing.assert_array_equal(pa.LeakyReLU(d[1], 0.1).get(), onp.leakyrelu(a[1].copy(), 0.1))
+    np.testing.assert_array_equal(pa.Add(d[1], d[2]).get(), a[1] + a[2])

@@ -1,0 +1,135 @@
+"""Whole-net parity on a real MI355X against vectors captured from the
+reference (tests/golden) and against the oracle at BASELINE's full sizes."""
+import numpy as np
+import pytest
+
+from oracle import planer_np as onp
+from planer_amd.irgen import customnet, resnet18, save_model, yolov3
+from tests.cases import sample_index
+from tests.conftest import RTOL, assert_close, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pa():
+    import planer_amd
+    planer_amd.hip.context()
+    return planer_amd
+
+
+def check_packed(outs, z, tol=RTOL):
+    for i, o in enumerate(outs):
+        o = np.ascontiguousarray(o)
+        assert tuple(z["out%d_shape" % i]) == o.shape
+        idx = sample_index(o.size)
+        err = np.abs(o.reshape(-1)[idx] - z["out%d_sample" % i]).max() / float(z["out%d_absmax" % i])
+        assert err <= tol, err
+        s = z["out%d_sum" % i]
+        assert abs(o.astype(np.float64).sum() - s[0]) <= tol * s[1]
+
+
+@pytest.mark.parametrize("graph_mode", [False, True])
+def test_customnet_config1(pa, graph_mode):
+    g, b = customnet.build()
+    net = pa.from_graph(g, b)
+    net.use_graph = graph_mode
+    x = customnet.make_input(1)
+    y = net(x)                                   # host in -> host out
+    assert isinstance(y, np.ndarray) and y.shape == (1, 128, 64, 64)
+    check_packed([y], load_golden("customnet_b1.npz"))
+    # without the trailing `return`, a batch-1 output loses its batch dim (net.py:101)
+    g2 = dict(g, layers=g["layers"][:-1], flow=g["flow"][:-1])
+    net2 = pa.from_graph(g2, b)
+    net2.use_graph = graph_mode
+    y2 = net2(x)
+    assert y2.shape == (128, 64, 64)
+    check_packed([y2], load_golden("customnet_b1_noreturn.npz"))
+
+
+@pytest.mark.parametrize("n", [1, 2])
+@pytest.mark.parametrize("mode", ["eager", "fused_graph", "unfused_graph"])
+def test_resnet18_logits(pa, n, mode):
+    g, b = resnet18.build()
+    net = pa.from_graph(g, b)
+    net.use_graph = mode != "eager"
+    net.use_fusion = mode == "fused_graph"
+    x = resnet18.make_input(n)
+    ref = load_golden("resnet18_b%d.npz" % n)["logits"]
+    for _ in range(2):                           # second call replays the captured graph
+        y = net(x)
+        assert y.shape == (n, 1000)
+        assert_close(y, ref, RTOL)
+    d = net(pa.asarray(x))                       # device in -> device out, no sync
+    assert isinstance(d, pa.DeviceArray)
+    assert_close(d.get(), ref, RTOL)
+
+
+def test_resnet18_stage_activations(pa):
+    g, b = resnet18.build()
+    z = load_golden("resnet18_b2_stages.npz")
+    x = resnet18.make_input(2)
+    for key in ("stem_r", "pool", "l11_o", "l21_o", "l31_o", "l41_o", "gap"):
+        cut = [i for i, f in enumerate(g["flow"]) if f[2] == key][0]
+        net = pa.from_graph(dict(g, flow=g["flow"][:cut + 1]), b)
+        o = net.forward(pa.asarray(x)).get()
+        assert o.shape == tuple(z[key + "_shape"])
+        idx = sample_index(o.size)
+        err = np.abs(o.reshape(-1)[idx] - z[key + "_sample"]).max() / float(z[key + "_absmax"])
+        assert err <= RTOL, (key, err)
+
+
+def test_resnet18_batch32_vs_oracle(pa):
+    """BASELINE config 3 at full size: batch 32, fused + graph path vs the CPU oracle."""
+    g, b = resnet18.build()
+    x = resnet18.make_input(32)
+    net = pa.from_graph(g, b)
+    y = net(x)
+    ref = onp.OracleNet()
+    ref.load_json(g["input"], g["inits"], g["layers"], g["flow"])
+    ref.load_weights(b)
+    assert_close(y, ref(x.copy()), RTOL)
+    # shards are independent (BN is folded): rows of a batch equal single-image runs
+    one = net(x[5:6])
+    assert_close(one, y[5:6], RTOL)
+
+
+@pytest.mark.parametrize("size,gold", [(160, "yolov3_b1_160.npz"), (416, "yolov3_b1.npz")])
+def test_yolov3_heads(pa, size, gold):
+    g, b = yolov3.build()
+    net = pa.from_graph(g, b)
+    x = yolov3.make_input(1, size=size)
+    y = net(x)
+    assert isinstance(y, tuple) and len(y) == 3
+    check_packed(list(y), load_golden(gold))
+    net.use_graph = False
+    check_packed(list(net(x)), load_golden(gold))
+
+
+def test_read_net_formats_and_api(pa, tmp_path, capsys):
+    g, b = customnet.build()
+    x = customnet.make_input(1)
+    save_model(str(tmp_path / "cn"), g, b)
+    save_model(str(tmp_path / "cz"), g, b, pla=True)
+    n1 = pa.read_net(str(tmp_path / "cn"))
+    n2 = pa.InferenceSession(str(tmp_path / "cz"))
+    y1, y2 = n1(x), n2({"x": x})                 # dict input (net.py:95)
+    np.testing.assert_array_equal(y1, y2)
+    assert n1.run(None, {"x": x})[0].shape == (1, 128, 64, 64)   # onnxruntime shim (net.py:79-81)
+    assert pa.read_net(str(tmp_path / "nope")) is None
+    assert "not found" in capsys.readouterr().out
+    n1.use_graph = False
+    n1.timeit("start")
+    n1(x)
+    assert set(n1.timer) == {"conv", "relu", "maxpool", "upsample", "concat", "sigmoid", "return"}
+    n1.profile = True
+    n1(x)
+    assert n1.device_timer["conv"] > 0
+
+
+def test_relu_mutates_its_input_like_the_reference(pa):
+    x = np.random.default_rng(1).standard_normal((2, 3, 4, 4)).astype(np.float32)
+    d = pa.asarray(x)
+    r = pa.ReLU(d)
+    assert r is d
+    np.testing.assert_array_equal(d.get(), onp.relu(x.copy()))
