@@ -1,0 +1,171 @@
+"""Batch-sharded multi-GPU execution: one process per GPU, RCCL over xGMI.
+
+The reference is a single-process library with no distributed code.  Its
+forward pass shards naturally by batch -- every op is per image and BatchNorm
+is pre-folded to a per-channel affine (io.py:76-91), so shards never talk.
+The only exchange is at load time: rank 0 reads the weight file and ONE RCCL
+broadcast of the uint8 blob (net.load_weights, net.py:83-88) fills every
+other rank's copy.  No collective runs in the forward pass.
+
+Launch model: `python -m torch.distributed.run --nproc-per-node N ...` (or any
+launcher that sets RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT); the launcher
+is only a process spawner -- this module does not import torch.  The 128-byte
+RCCL unique id travels through a file in /tmp (all ranks share one node).
+"""
+import os
+import time
+
+import numpy
+
+from . import _lib
+
+
+def shard_range(total, world, rank):
+    """Contiguous batch slice of `rank`: the first `total % world` ranks take
+    one extra image."""
+    base, extra = divmod(int(total), int(world))
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def env_world():
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+            int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0"))))
+
+
+def _rendezvous_path():
+    explicit = os.environ.get("PLANER_RDZV_FILE")
+    if explicit:
+        return explicit
+    tag = "%s_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"),
+                        os.getppid())
+    return os.path.join(os.environ.get("TMPDIR", "/tmp"), "planer_amd_rdzv_" + tag)
+
+
+def exchange_bytes(payload, rank, path=None, timeout=300.0, fresh_after=None):
+    """Rank 0 publishes `payload` (bytes) atomically; the others poll for it.
+    A file older than `fresh_after` (epoch seconds) is a leftover of an
+    earlier job that reused the pid/port and is ignored."""
+    path = path or _rendezvous_path()
+    if rank == 0:
+        tmp = "%s.%d.tmp" % (path, os.getpid())
+        with open(tmp, "wb") as f:
+            f.write(payload)
+        os.replace(tmp, path)
+        return payload
+    fresh_after = time.time() - 600.0 if fresh_after is None else fresh_after
+    deadline = time.time() + timeout
+    while time.time() < deadline:
+        try:
+            if os.path.getmtime(path) >= fresh_after:
+                with open(path, "rb") as f:
+                    data = f.read()
+                if data:
+                    return data
+        except OSError:
+            pass
+        time.sleep(0.02)
+    raise TimeoutError("rank %d: no rendezvous file %s" % (rank, path))
+
+
+class Communicator:
+    """What the sharded path needs from a transport.  `RcclCommunicator` is
+    the product; tests drive the same host logic over torch.distributed/gloo."""
+    rank, world = 0, 1
+
+    def bcast_device(self, arr, root=0):
+        raise NotImplementedError
+
+    def barrier(self):
+        raise NotImplementedError
+
+    def max_over_ranks(self, value):
+        raise NotImplementedError
+
+    def load_weights(self, net, blob, root=0):
+        """Rank `root` uploads the blob; everyone else receives the device
+        copy by broadcast, then refreshes the host mirror of the small
+        parameter tensors (UpSample scales are read on the host)."""
+        if self.rank == root:
+            net.load_weights(blob)
+        self.bcast_device(net.weight_blob(), root)
+        if self.rank != root:
+            net.refresh_host_mirror()
+        self.barrier()
+
+
+class SingleProcess(Communicator):
+    def bcast_device(self, arr, root=0):
+        return arr
+
+    def barrier(self):
+        pass
+
+    def max_over_ranks(self, value):
+        return float(value)
+
+
+class RcclCommunicator(Communicator):
+    def __init__(self, ctx, rank, world, rdzv_path=None):
+        from . import hip
+        self.ctx, self.rank, self.world = ctx, rank, world
+        lib = _lib.load()
+        uid = (_lib.ctypes.c_char * _lib.UNIQUE_ID_BYTES)()
+        if rank == 0:
+            _lib.check(lib.pl_comm_unique_id(uid))
+        data = exchange_bytes(bytes(uid.raw), rank, rdzv_path)
+        uid = (_lib.ctypes.c_char * _lib.UNIQUE_ID_BYTES).from_buffer_copy(data[:_lib.UNIQUE_ID_BYTES])
+        _lib.check(lib.pl_comm_init_rank(ctx.handle, world, rank, uid))
+        self._scratch = hip.zeros((4,), numpy.float32, ctx)
+        ctx.comm = self
+
+    def bcast_device(self, arr, root=0):
+        _lib.call("pl_comm_bcast", self.ctx.handle, arr.ptr, arr.nbytes, root)
+        return arr
+
+    def max_over_ranks(self, value):
+        self._scratch.set(numpy.full(4, value, numpy.float32))
+        _lib.call("pl_comm_allreduce_max_f32", self.ctx.handle, self._scratch.ptr, 4)
+        return float(self._scratch.get()[0])
+
+    def barrier(self):
+        self.max_over_ranks(0.0)           # an all-reduce is a barrier; .get() syncs the stream
+
+    def allgather_rows(self, local):
+        """(rows, ...) per rank -> (world*rows, ...) on every rank (equal shards)."""
+        from . import hip
+        out = hip.empty((self.world * local.shape[0],) + local.shape[1:], local.dtype, self.ctx)
+        _lib.call("pl_comm_allgather", self.ctx.handle, local.ptr, out.ptr, local.nbytes)
+        return out
+
+    def close(self):
+        _lib.load().pl_comm_destroy(self.ctx.handle)
+
+
+def init(ctx=None):
+    """Communicator for this process from the launcher's environment."""
+    from . import hip
+    rank, world, _ = env_world()
+    ctx = ctx or hip.context()
+    if world == 1:
+        return SingleProcess()
+    return RcclCommunicator(ctx, rank, world)
+
+
+def timed_steps(comm, step, sync, steps, warmup):
+    """The bench contract: W untimed steps, then exactly K timed steps
+    bracketed by barrier + device sync on both sides; returns the MAX over
+    ranks of the elapsed seconds."""
+    for _ in range(warmup):
+        step()
+    sync()
+    comm.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    comm.barrier()
+    sync()
+    return comm.max_over_ranks(elapsed)
