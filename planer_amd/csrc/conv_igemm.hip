@@ -50,6 +50,7 @@ struct ConvArgs {
     int mtiles, ntiles, tiles;  // per group
     int splits, k_per_split;
     size_t slab;      // N*Cout*HoWo
+    int x_bytes, w_bytes;
     FastDiv divKhw, divKw, divHoWo, divWo, divMt;
     Epilogue ep;
 };
@@ -65,7 +66,7 @@ struct Cfg {
     static constexpr int LDA = BM + 2;                  // k-major A tile, padded
     static constexpr int LDB = BN;
     static constexpr int A_ELEMS = BK * LDA, B_ELEMS = BK * LDB;
-    static constexpr int LDS_BYTES = 2 * (A_ELEMS + B_ELEMS) * 4;
+    static constexpr int LDS_BYTES = 2 * (A_ELEMS + B_ELEMS) * 4 + 2 * BK * 8;  // + per-k lookup table
     // B gather: thread owns column tid%BN and rows tid/BN + i*ROWS_PER_PASS
     static_assert(THREADS % BN == 0 || BN % THREADS == 0, "BN vs threads");
     static constexpr int ROWS_PER_PASS = THREADS / BN;  // BN <= 256
@@ -79,8 +80,9 @@ struct Cfg {
 template <class C, bool AVEC>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *As = smem;                       // [2][BK][LDA]
-    float *Bs = smem + 2 * C::A_ELEMS;      // [2][BK][LDB]
+    float *As = smem;                                   // [2][BK][LDA]
+    float *Bs = smem + 2 * C::A_ELEMS;                  // [2][BK][LDB]
+    int2 *Lut = reinterpret_cast<int2 *>(smem + 2 * (C::A_ELEMS + C::B_ELEMS));  // [2][BK]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -104,66 +106,92 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
     const int split = blockIdx.y;
     const int kbeg = split * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
-
-    const float *wg = p.w + (size_t)g * p.cout_g * p.K;    // this group's filter rows
-    const float *xg = p.x + (size_t)g * p.cin_g * p.HW;    // this group's first input channel
+    const int nchunks = (kend - kbeg + C::BK - 1) / C::BK;
 
     // ---- per-thread gather column (fixed for the whole K loop) -------------
     const int jl = tid % C::BN;
     const int krow0 = tid / C::BN;
     const int j = col0 + jl;
     const bool jok = j < p.cols;
-    int hbase = 0, wbase = 0;
-    size_t xoff = 0;
+    // invalid column: hbase so negative that every row test fails
+    int hbase = -(1 << 20), wbase = 0, cbase = 0;
     if (jok) {
         unsigned n, pix, ho, wo;
         p.divHoWo.divmod((unsigned)j, n, pix);
         p.divWo.divmod(pix, ho, wo);
         hbase = (int)ho * p.sh - p.pt;
         wbase = (int)wo * p.sw - p.pl;
-        xoff = (size_t)n * p.Cin * p.HW;
+        cbase = (int)n * p.Cin * p.HW + (int)g * p.cin_g * p.HW + hbase * p.W + wbase;
     }
-    const float *xcol = xg + xoff;
+
+    // Staging loads are buffer loads through wave-uniform descriptors built
+    // from kernel arguments: the hardware range check returns 0 for an
+    // out-of-range offset, so padding halo, K tail, row tail and column tail
+    // are all "offset = OOB" -- no per-lane branch, no select on the loaded
+    // value, nothing that makes hipcc wait vmcnt(0) in the middle of the gather.
+    constexpr int OOB = (int)0x80000000;  // >= num_records (tensors are < 2 GiB, checked on the host)
+    const __amdgpu_buffer_rsrc_t xrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, p.w_bytes, 0x00020000);
+    const int wbase_row = (int)g * p.cout_g + m0;       // filter row of tile row 0
+
+    // Per-k lookup table, one chunk ahead: {element offset cin*HW + a*dh*W + b*dw,
+    // (a*dh) | (b*dw) << 16}.  k >= kend gets a row delta that fails every range test.
+    auto write_lut = [&](int chunk) {
+        if (tid < C::BK) {
+            const int k = kbeg + chunk * C::BK + tid;
+            unsigned cin, r, a, b;
+            p.divKhw.divmod((unsigned)k, cin, r);
+            p.divKw.divmod(r, a, b);
+            int2 e;
+            e.x = (int)cin * p.HW + (int)a * p.dh * p.W + (int)b * p.dw;
+            e.y = k < kend ? ((int)a * p.dh) | (((int)b * p.dw) << 16) : 0x7fff;
+            Lut[(chunk & 1) * C::BK + tid] = e;
+        }
+    };
 
     float breg[C::B_PER_THREAD];
     float4 areg[C::A_PER_THREAD];
 
-    auto load_chunk = [&](int k0) {
-        // B: im2col gather, zero fill for padding / K tail / column tail
+    auto load_chunk = [&](int chunk) {
+        const int k0 = kbeg + chunk * C::BK;
+        const int2 *lut = Lut + (chunk & 1) * C::BK;
+        // B: im2col gather.  Table entries first (wave-uniform addresses: LDS
+        // broadcast reads), pinned so hipcc cannot make them lazy/conditional.
+        int2 e[C::B_PER_THREAD];
+#pragma unroll
+        for (int i = 0; i < C::B_PER_THREAD; ++i) e[i] = lut[krow0 + i * C::ROWS_PER_PASS];
+#pragma unroll
+        for (int i = 0; i < C::B_PER_THREAD; ++i) asm volatile("" : "+v"(e[i].x), "+v"(e[i].y));
 #pragma unroll
         for (int i = 0; i < C::B_PER_THREAD; ++i) {
-            const int k = k0 + krow0 + i * C::ROWS_PER_PASS;
-            unsigned cin, r, a, b;
-            p.divKhw.divmod((unsigned)k, cin, r);
-            p.divKw.divmod(r, a, b);
-            const int hi = hbase + (int)a * p.dh, wi = wbase + (int)b * p.dw;
-            const bool ok = jok && k < kend && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            breg[i] = ok ? xcol[(size_t)cin * p.HW + hi * p.W + wi] : 0.f;
+            const int hi = hbase + (e[i].y & 0xffff), wi = wbase + (e[i].y >> 16);
+            const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const int off = ok ? (cbase + e[i].x) << 2 : OOB;
+            breg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, off, 0, 0));
         }
         // A: weights, row-major [cout][K]
 #pragma unroll
         for (int i = 0; i < C::A_PER_THREAD; ++i) {
             const int v = tid + i * C::THREADS;
             const int row = v / C::KQ, kq = v % C::KQ;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (v < C::A_VEC && m0 + row < p.cout_g) {
-                const int k = k0 + kq * 4;
-                const float *src = wg + (size_t)(m0 + row) * p.K + k;
-                if (AVEC) {
-                    if (k + 3 < kend) val = *reinterpret_cast<const float4 *>(src);
-                    else {
-                        if (k < kend) val.x = src[0];
-                        if (k + 1 < kend) val.y = src[1];
-                        if (k + 2 < kend) val.z = src[2];
-                    }
-                } else {
-                    if (k < kend) val.x = src[0];
-                    if (k + 1 < kend) val.y = src[1];
-                    if (k + 2 < kend) val.z = src[2];
-                    if (k + 3 < kend) val.w = src[3];
+            const int k = k0 + kq * 4;
+            const bool rok = (C::A_VEC % C::THREADS == 0 || v < C::A_VEC) && m0 + row < p.cout_g;
+            const int eoff = (wbase_row + row) * p.K + k;                       // elements
+            if (AVEC) {
+                // K % 4 == 0 and kend % 4 == 0: a float4 is entirely inside or outside
+                const int off = (rok && k < kend) ? eoff << 2 : OOB;
+                areg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off, 0, 0));
+            } else {
+                float tv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int off = (rok && k + e < kend) ? (eoff + e) << 2 : OOB;
+                    tv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrsrc, off, 0, 0));
                 }
+                areg[i] = make_float4(tv[0], tv[1], tv[2], tv[3]);
             }
-            areg[i] = val;
         }
     };
 
@@ -176,7 +204,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
         for (int i = 0; i < C::A_PER_THREAD; ++i) {
             const int v = tid + i * C::THREADS;
-            if (v < C::A_VEC) {
+            if (C::A_VEC % C::THREADS == 0 || v < C::A_VEC) {
                 const int row = v / C::KQ, kq = v % C::KQ;
                 float *dst = Ab + (kq * 4) * C::LDA + row;
                 dst[0] = areg[i].x;
@@ -199,34 +227,47 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
     const int a_off = lhi * C::LDA + wm * C::WTM + l31;
     const int b_off = lhi * C::LDB + wn * C::WTN + l31;
 
-    const int nchunks = (kend - kbeg + C::BK - 1) / C::BK;
-    if (nchunks > 0) {
-        load_chunk(kbeg);
-        store_chunk(0);
-    }
-    __syncthreads();
-
-    for (int c = 0; c < nchunks; ++c) {
-        const int buf = c & 1;
-        if (c + 1 < nchunks) load_chunk(kbeg + (c + 1) * C::BK);  // in flight during the MFMAs
+    auto compute = [&](int buf) {
         const float *Ab = As + buf * C::A_ELEMS + a_off;
         const float *Bb = Bs + buf * C::B_ELEMS + b_off;
+        // all fragments of the chunk first (one LDS round trip), then the MFMAs
+        float af[C::BK / 2][C::TM], bf[C::BK / 2][C::TN];
 #pragma unroll
         for (int kk = 0; kk < C::BK; kk += 2) {
-            float af[C::TM], bf[C::TN];
 #pragma unroll
-            for (int a = 0; a < C::TM; ++a) af[a] = Ab[kk * C::LDA + a * 32];
+            for (int a = 0; a < C::TM; ++a) af[kk / 2][a] = Ab[kk * C::LDA + a * 32];
 #pragma unroll
-            for (int b = 0; b < C::TN; ++b) bf[b] = Bb[kk * C::LDB + b * 32];
+            for (int b = 0; b < C::TN; ++b) bf[kk / 2][b] = Bb[kk * C::LDB + b * 32];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < C::BK / 2; ++kk)
 #pragma unroll
             for (int a = 0; a < C::TM; ++a)
 #pragma unroll
                 for (int b = 0; b < C::TN; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
-        }
-        if (c + 1 < nchunks) store_chunk(buf ^ 1);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][a], bf[kk][b], acc[a][b], 0, 0, 0);
+        // keep the staging stores (and their vmcnt waits) BEHIND the MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- prologue ------------------------------------------------------------
+    write_lut(0);
+    __syncthreads();
+    load_chunk(0);
+    write_lut(1);
+    store_chunk(0);
+    __syncthreads();
+
+    // ---- main loop: straight-line body (loads for c+1 fly over the MFMAs of c) --
+    for (int c = 0; c + 1 < nchunks; ++c) {
+        load_chunk(c + 1);
+        write_lut(c + 2);
+        compute(c & 1);
+        store_chunk((c + 1) & 1);
         __syncthreads();
     }
+    if (nchunks > 0) compute((nchunks - 1) & 1);
 
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31,
     //      row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -330,10 +371,13 @@ int conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const
     const int Ho = (H + pt + pb - (kh - 1) * dh - 1 + sh) / sh;  // util.py:25
     const int Wo = (W + pl + pr - (kw - 1) * dw - 1 + sw) / sw;  // util.py:26
     PL_REQUIRE(Ho > 0 && Wo > 0, PL_EINVAL, "conv2d: empty output (%d x %d)", Ho, Wo);
+    PL_REQUIRE(H + 2 * pt < 16384 && W + 2 * pl < 16384 && kh * dh < 16384 && kw * dw < 16384, PL_EUNSUPPORTED,
+               "conv2d: spatial extent above 16383");
     if (N == 0) return PL_OK;
     const size_t out_elems = (size_t)N * Cout * Ho * Wo, in_elems = (size_t)N * Cin * H * W;
-    PL_REQUIRE(out_elems < (1ull << 31) && in_elems < (1ull << 31) && (size_t)N * Ho * Wo < (1ull << 31),
-               PL_EUNSUPPORTED, "conv2d: tensor exceeds 2^31 elements");
+    const size_t w_elems = (size_t)Cout * (Cin / group) * kh * kw;
+    PL_REQUIRE(out_elems < (1ull << 31) && in_elems <= (1ull << 29) && w_elems <= (1ull << 29),
+               PL_EUNSUPPORTED, "conv2d: input/filter above 2 GiB or output above 2^31 elements");
     CtxGuard guard(ctx);
 
     ConvArgs a;
@@ -345,6 +389,7 @@ int conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const
     a.cols = N * Ho * Wo;
     a.HoWo = Ho * Wo; a.HW = H * W;
     a.slab = out_elems;
+    a.x_bytes = (int)(in_elems * 4); a.w_bytes = (int)(w_elems * 4);
     a.divKhw = FastDiv(kh * kw); a.divKw = FastDiv(kw);
     a.divHoWo = FastDiv(a.HoWo); a.divWo = FastDiv(Wo);
     a.ep = Epilogue{bias, scale, shift, res, act, (float)alpha, (float)(1.0 - alpha)};
