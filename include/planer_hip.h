@@ -101,11 +101,25 @@ int pl_conv2d_fused_f32(pl_ctx *ctx, const float *x, int N, int Cin, int H,
                         const float *bias, float *y, int sh, int sw, int dh,
                         int dw, int pt, int pl, int pb, int pr, int group,
                         const float *scale, const float *shift,
-                        const float *res, int act, double alpha);
+                        const float *res, int act, double alpha, int w_layout);
 
+/* w_layout 0: filters exactly as the reference holds them, OIHW (layer.py:22).
+ * w_layout 1: "tap-major" filters [Cout][kh*kw][Cin/g] produced once per model
+ * by pl_conv2d_prepare_weights_f32 (needs Cin/g % 16 == 0); lets the kernel
+ * compute padding validity once per K-chunk instead of once per element.
+ * 1x1 filters are identical in both layouts. */
+int pl_conv2d_prepare_weights_f32(pl_ctx *ctx, const float *w, int Cout, int Cin_g,
+                                  int kh, int kw, float *out);
+/* First call for a new conv shape times every applicable tile configuration
+ * and remembers the fastest (on by default; PLANER_HIP_AUTOTUNE=0 or 0 here
+ * selects the static heuristic). Never runs during graph capture. */
+int pl_set_autotune(pl_ctx *ctx, int enabled);
 /* Force one tile configuration for the conv kernel (tuning / tests).
  * cfg < 0 restores the built-in heuristic. split_k <= 0 means automatic. */
 int pl_conv2d_set_config(pl_ctx *ctx, int cfg, int split_k);
+/* Full launch plan: tiles [0,dp_tiles) run data-parallel with the fused epilogue,
+ * the rest as split_k slices + tile reduce; occupancy>0 pins workgroups per CU. */
+int pl_conv2d_set_plan(pl_ctx *ctx, int cfg, int dp_tiles, int split_k, int occupancy);
 int pl_conv2d_num_configs(void);
 int pl_conv2d_config_name(int cfg, char *buf, size_t len);
 

@@ -47,8 +47,11 @@ SIGNATURES = {
     "pl_graph_destroy": [_P],
     "pl_conv2d_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P] + [_I] * 9,
     "pl_conv2d_fused_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P] + [_I] * 9
-                           + [_P, _P, _P, _I, c_double],
+                           + [_P, _P, _P, _I, c_double, _I],
+    "pl_conv2d_prepare_weights_f32": [_P, _P, _I, _I, _I, _I, _P],
+    "pl_set_autotune": [_P, _I],
     "pl_conv2d_set_config": [_P, _I, _I],
+    "pl_conv2d_set_plan": [_P, _I, _I, _I, _I],
     "pl_conv2d_num_configs": [],
     "pl_conv2d_config_name": [_I, c_char_p, _Z],
     "pl_gemm_f32": [_P, _P, _I, _I, _P, _I, _I, _P, _P],

@@ -70,6 +70,8 @@ struct pl_ctx {
     // conv tuning overrides
     int conv_cfg = -1;
     int conv_split_k = 0;
+    bool autotune = true;
+    int conv_t1 = 0, conv_occ = 0;
 
     // RCCL (dlopen'ed on first use)
     void *comm = nullptr;

@@ -29,7 +29,10 @@
 //  - small-spatial layers (ResNet layer3/4 at batch 32 have 6272 / 1568 GEMM
 //    columns) use split-K over gridDim.y with a second pass that sums the
 //    slabs and applies the fused tail.
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 
 #include "common.h"
 #include "device_utils.h"
@@ -40,7 +43,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct ConvArgs {
     const float *x, *w;
-    float *y;  // output, or split-K workspace [splits][N*Cout*HoWo]
+    float *y;         // NCHW output (fused pass) or compact split-K slabs [split][tile][BM*BN]
     int N, Cin, H, W, Cout, Ho, Wo;
     int kh, kw, sh, sw, dh, dw, pt, pl;
     int cin_g, cout_g, groups;
@@ -48,12 +51,108 @@ struct ConvArgs {
     int cols;         // N*Ho*Wo
     int HoWo, HW;
     int mtiles, ntiles, tiles;  // per group
-    int splits, k_per_split;
-    size_t slab;      // N*Cout*HoWo
+    int tile_offset;  // first (group-major) tile index this launch covers
+    int tile_count;   // tiles this launch covers (slab stride of the split pass)
+    int splits, k_per_split;    // k_per_split: K elements (generic) or BK-chunks (tap-major)
     int x_bytes, w_bytes;
-    FastDiv divKhw, divKw, divHoWo, divWo, divMt;
+    FastDiv divKhw, divKw, divHoWo, divWo, divMt, divCpt;
     Epilogue ep;
 };
+
+// blockIdx.x -> (group, m-tile, n-tile).  XCD-aware: the 8 XCDs (private L2s)
+// each walk a contiguous range of tiles, M-tiles fastest, so workgroups that
+// are co-resident on an XCD share input pixels and filter panels in its L2.
+struct TileCoord {
+    unsigned g, local;  // group, index of the tile inside this launch
+    int m0, col0;
+};
+
+template <int BM, int BN>
+__device__ __forceinline__ TileCoord tile_coord(const ConvArgs &p) {
+    const unsigned nblk = gridDim.x;
+    unsigned bid = blockIdx.x;
+    const unsigned q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;   // bijective for any grid
+    TileCoord tc;
+    tc.local = bid;
+    const unsigned gt = bid + (unsigned)p.tile_offset;
+    tc.g = gt / (unsigned)p.tiles;
+    const unsigned t = gt - tc.g * (unsigned)p.tiles;
+    const unsigned nt = p.divMt.div(t);
+    tc.m0 = (int)(t - nt * (unsigned)p.mtiles) * BM;
+    tc.col0 = (int)nt * BN;
+    return tc;
+}
+
+// Write one wave's accumulators.  C/D layout of the 32x32 MFMA: col = lane&31,
+// row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Fused pass: NCHW + epilogue.  Split
+// pass: raw partial sums into this (split, tile)'s compact slab.
+template <int BM, int BN, int TM, int TN, int WTM, int WTN>
+__device__ __forceinline__ void store_tile(const ConvArgs &p, const TileCoord &tc, f32x16 (&acc)[TM][TN], int wm,
+                                           int wn, int lane) {
+    const int l31 = lane & 31, lhi = lane >> 5;
+    if (p.splits > 1) {
+        float *slab = p.y + ((size_t)blockIdx.y * p.tile_count + tc.local) * (BM * BN);
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * WTM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    slab[row * BN + wn * WTN + b * 32 + l31] = acc[a][b][r];
+                }
+        return;
+    }
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int jc = tc.col0 + wn * WTN + b * 32 + l31;
+        if (jc >= p.cols) continue;
+        unsigned n, pix;
+        p.divHoWo.divmod((unsigned)jc, n, pix);
+        const size_t obase = ((size_t)n * p.Cout + (size_t)tc.g * p.cout_g) * p.HoWo + pix;
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = tc.m0 + wm * WTM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (row < p.cout_g) {
+                    const size_t idx = obase + (size_t)row * p.HoWo;
+                    p.y[idx] = apply_epilogue(p.ep, acc[a][b][r], (int)tc.g * p.cout_g + row, idx);
+                }
+            }
+        }
+    }
+}
+
+// Combine the split-K slabs of the tiles [tile_offset, tile_offset+tile_count)
+// and apply the fused tail.  One workgroup per tile; thread = one column.
+template <int BM, int BN>
+__global__ void __launch_bounds__(256) reduce_tiles_kernel(const ConvArgs p, const float *slabs, float *y) {
+    const unsigned local = blockIdx.x;
+    const unsigned gt = local + (unsigned)p.tile_offset;
+    const unsigned g = gt / (unsigned)p.tiles;
+    const unsigned t = gt - g * (unsigned)p.tiles;
+    const unsigned nt = p.divMt.div(t);
+    const int m0 = (int)(t - nt * (unsigned)p.mtiles) * BM, col0 = (int)nt * BN;
+    constexpr int RPP = 256 / BN;
+    const int cl = threadIdx.x % BN, r0 = threadIdx.x / BN;
+    const int jc = col0 + cl;
+    if (jc >= p.cols) return;
+    unsigned n, pix;
+    p.divHoWo.divmod((unsigned)jc, n, pix);
+    const size_t obase = ((size_t)n * p.Cout + (size_t)g * p.cout_g) * p.HoWo + pix;
+    const size_t sstride = (size_t)p.tile_count * (BM * BN);
+    const float *sp = slabs + (size_t)local * (BM * BN) + cl;
+    for (int rl = r0; rl < BM; rl += RPP) {
+        const int row = m0 + rl;
+        if (row >= p.cout_g) break;
+        float v = sp[rl * BN];
+        for (int z = 1; z < p.splits; ++z) v += sp[z * sstride + rl * BN];
+        const size_t idx = obase + (size_t)row * p.HoWo;
+        y[idx] = apply_epilogue(p.ep, v, (int)g * p.cout_g + row, idx);
+    }
+}
 
 template <int BM_, int BN_, int BK_, int WM_, int WN_>
 struct Cfg {
@@ -89,20 +188,9 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / C::WN, wn = wave % C::WN;
 
-    // ---- XCD-aware tile mapping (bijective for any grid size) -------------
-    const unsigned nblk = gridDim.x;
-    unsigned bid = blockIdx.x;
-    {
-        const unsigned q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    // bid -> (group, ntile, mtile); mtile fastest
-    const unsigned g = bid / (unsigned)p.tiles;
-    const unsigned t = bid - g * (unsigned)p.tiles;
-    const unsigned nt = p.divMt.div(t);
-    const unsigned mt = t - nt * (unsigned)p.mtiles;
-    const int m0 = mt * C::BM;          // row offset inside the group
-    const int col0 = nt * C::BN;
+    const TileCoord tc = tile_coord<C::BM, C::BN>(p);
+    const unsigned g = tc.g;
+    const int m0 = tc.m0, col0 = tc.col0;
     const int split = blockIdx.y;
     const int kbeg = split * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
@@ -269,30 +357,201 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
     }
     if (nchunks > 0) compute((nchunks - 1) & 1);
 
-    // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31,
-    //      row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    float *yout = p.y + (size_t)split * p.slab;
-    const bool fuse = p.splits == 1;
+    store_tile<C::BM, C::BN, C::TM, C::TN, C::WTM, C::WTN>(p, tc, acc, wm, wn, lane);
+}
+
+// =============================================================================
+// Tap-major kernel: the fast path for convs whose weights were re-ordered once
+// (pl_conv2d_prepare_weights_f32) from OIHW [co][cin][tap] to [co][tap][cin].
+// The GEMM K axis then runs (kh, kw, cin), so a whole BK-chunk shares one filter
+// tap: padding validity and the spatial offset are computed ONCE per chunk per
+// thread, and the per-element part of the im2col address (cin * H*W) is wave
+// uniform and rides in the buffer load's scalar offset -- zero VALU per
+// gathered element.  LDS tiles are [row][k] (k contiguous, +4 pad), filled with
+// ds_write_b128 and read as ds_read_b128 fragments: lane (i, hi) takes k =
+// 8u+4hi .. 8u+4hi+3 and feeds MFMA step s with its s-th value, i.e. step s pairs
+// k = 8u+s (lanes 0-31) with k = 8u+4+s (lanes 32-63) for A and B alike.
+// Requires cin_g % BK == 0 (ResNet/YOLO bodies); everything else takes the
+// generic kernel above.
+// =============================================================================
+template <int BM_, int BN_, int BK_, int WM_, int WN_>
+struct TapCfg {
+    static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_;
+    static constexpr int THREADS = 256;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static constexpr int WTM = BM / WM, WTN = BN / WN;
+    static constexpr int TM = WTM / 32, TN = WTN / 32;
+    static_assert(WTM % 32 == 0 && WTN % 32 == 0 && BK % 8 == 0, "tile alignment");
+    static constexpr int LDK = BK + 4;                        // floats; LDK/4 odd -> conflict-free b128
+    static_assert((LDK / 4) % 2 == 1, "LDK/4 must be odd");
+    static constexpr int A_ELEMS = BM * LDK, B_ELEMS = BN * LDK;
+    static constexpr int LDS_BYTES = 2 * (A_ELEMS + B_ELEMS) * 4;
+    static constexpr int KG = BK / 4;                         // float4 groups along k
+    static constexpr int KG_PER_PASS = THREADS / BN;          // k-groups covered by one pass of all threads
+    static constexpr int B_PASSES = (KG + KG_PER_PASS - 1) / KG_PER_PASS;
+    static constexpr bool B_ALL_ACTIVE = (KG % KG_PER_PASS == 0);
+    static constexpr int A_VEC = BM * KG;
+    static constexpr int A_PER_THREAD = (A_VEC + THREADS - 1) / THREADS;
+};
+
+template <class C>
+__global__ void __launch_bounds__(256) conv_tap_kernel(const ConvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *As = smem;                         // [2][BM][LDK]
+    float *Bs = smem + 2 * C::A_ELEMS;        // [2][BN][LDK]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / C::WN, wn = wave % C::WN;
+
+    const TileCoord tc = tile_coord<C::BM, C::BN>(p);
+    const unsigned g = tc.g;
+    const int m0 = tc.m0, col0 = tc.col0;
+    const int split = blockIdx.y;
+    // K range of this split, in BK-chunks of the tap-major axis
+    const int cpt = p.cin_g / C::BK;                           // chunks per tap
+    const int total_chunks = p.kh * p.kw * cpt;
+    const int cbeg = split * p.k_per_split;                    // k_per_split counts chunks here
+    const int nchunks = min(total_chunks, cbeg + p.k_per_split) - cbeg;
+
+    // ---- per-thread gather column ------------------------------------------
+    const int jl = tid % C::BN;
+    const int kg0 = tid / C::BN;
+    const int j = col0 + jl;
+    const bool jok = j < p.cols && (C::B_ALL_ACTIVE || kg0 < C::KG);
+    int hbase = -(1 << 20), wbase = 0, cbase = 0;
+    if (jok) {
+        unsigned n, pix, ho, wo;
+        p.divHoWo.divmod((unsigned)j, n, pix);
+        p.divWo.divmod(pix, ho, wo);
+        hbase = (int)ho * p.sh - p.pt;
+        wbase = (int)wo * p.sw - p.pl;
+        cbase = (int)n * p.Cin * p.HW + (int)g * p.cin_g * p.HW + hbase * p.W + wbase + kg0 * 4 * p.HW;
+    }
+    constexpr int OOB = (int)0x80000000;
+    const __amdgpu_buffer_rsrc_t xrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, p.w_bytes, 0x00020000);
+    // A: per-thread constant part of the weight offset (elements), OOB for rows past Cout
+    int aoff[C::A_PER_THREAD];
 #pragma unroll
-    for (int b = 0; b < C::TN; ++b) {
-        const int jc = col0 + wn * C::WTN + b * 32 + l31;
-        if (jc >= p.cols) continue;
-        unsigned n, pix;
-        p.divHoWo.divmod((unsigned)jc, n, pix);
-        const size_t obase = ((size_t)n * p.Cout + (size_t)g * p.cout_g) * p.HoWo + pix;
+    for (int i = 0; i < C::A_PER_THREAD; ++i) {
+        const int v = tid + i * C::THREADS;
+        const int row = v / C::KG, kq = v % C::KG;
+        const bool rok = (C::A_VEC % C::THREADS == 0 || v < C::A_VEC) && m0 + row < p.cout_g;
+        aoff[i] = rok ? (((int)g * p.cout_g + m0 + row) * p.K + kq * 4) << 2 : OOB;
+    }
+
+    float4 breg[C::B_PASSES];
+    float4 areg[C::A_PER_THREAD];
+
+    auto load_chunk = [&](int c) {
+        const int ci = cbeg + c;                                // wave-uniform
+        const unsigned tap = p.divCpt.div((unsigned)ci);
+        const int cin0 = (ci - (int)tap * cpt) * C::BK;
+        unsigned a, b;
+        p.divKw.divmod(tap, a, b);
+        const int dy = (int)a * p.dh, dx = (int)b * p.dw;
+        const bool ok = (unsigned)(hbase + dy) < (unsigned)p.H && (unsigned)(wbase + dx) < (unsigned)p.W;
+        const int voff = ok ? (cbase + dy * p.W + dx) << 2 : OOB;
 #pragma unroll
-        for (int a = 0; a < C::TM; ++a) {
+        for (int ps = 0; ps < C::B_PASSES; ++ps) {
+            float tv[4];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * C::WTM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                if (row < p.cout_g) {
-                    const size_t idx = obase + (size_t)row * p.HoWo;
-                    float v = acc[a][b][r];
-                    if (fuse) v = apply_epilogue(p.ep, v, (int)g * p.cout_g + row, idx);
-                    yout[idx] = v;
-                }
+            for (int e = 0; e < 4; ++e) {
+                const int soff = ((cin0 + ps * C::KG_PER_PASS * 4 + e) * p.HW) << 2;   // scalar
+                tv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, voff, soff, 0));
             }
+            breg[ps] = make_float4(tv[0], tv[1], tv[2], tv[3]);
         }
+        const int ksoff = (ci * C::BK) << 2;                    // scalar: chunk start along K
+#pragma unroll
+        for (int i = 0; i < C::A_PER_THREAD; ++i)
+            areg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, aoff[i], ksoff, 0));
+    };
+
+    auto store_chunk = [&](int buf) {
+        float *Ab = As + buf * C::A_ELEMS;
+        float *Bb = Bs + buf * C::B_ELEMS;
+#pragma unroll
+        for (int ps = 0; ps < C::B_PASSES; ++ps) {
+            const int kg = kg0 + ps * C::KG_PER_PASS;
+            if (C::B_ALL_ACTIVE || kg < C::KG)
+                *reinterpret_cast<float4 *>(Bb + jl * C::LDK + kg * 4) = breg[ps];
+        }
+#pragma unroll
+        for (int i = 0; i < C::A_PER_THREAD; ++i) {
+            const int v = tid + i * C::THREADS;
+            if (C::A_VEC % C::THREADS == 0 || v < C::A_VEC)
+                *reinterpret_cast<float4 *>(Ab + (v / C::KG) * C::LDK + (v % C::KG) * 4) = areg[i];
+        }
+    };
+
+    f32x16 acc[C::TM][C::TN];
+#pragma unroll
+    for (int a = 0; a < C::TM; ++a)
+#pragma unroll
+        for (int b = 0; b < C::TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int a_off = (wm * C::WTM + l31) * C::LDK + 4 * lhi;
+    const int b_off = (wn * C::WTN + l31) * C::LDK + 4 * lhi;
+
+    auto compute = [&](int buf) {
+        const float *Ab = As + buf * C::A_ELEMS + a_off;
+        const float *Bb = Bs + buf * C::B_ELEMS + b_off;
+        float4 af[C::BK / 8][C::TM], bf[C::BK / 8][C::TN];
+#pragma unroll
+        for (int u = 0; u < C::BK / 8; ++u) {
+#pragma unroll
+            for (int a = 0; a < C::TM; ++a) af[u][a] = *reinterpret_cast<const float4 *>(Ab + a * 32 * C::LDK + 8 * u);
+#pragma unroll
+            for (int b = 0; b < C::TN; ++b) bf[u][b] = *reinterpret_cast<const float4 *>(Bb + b * 32 * C::LDK + 8 * u);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < C::BK / 8; ++u)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int a = 0; a < C::TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < C::TN; ++b) {
+                        const float av = s4 == 0 ? af[u][a].x : s4 == 1 ? af[u][a].y : s4 == 2 ? af[u][a].z : af[u][a].w;
+                        const float bv = s4 == 0 ? bf[u][b].x : s4 == 1 ? bf[u][b].y : s4 == 2 ? bf[u][b].z : bf[u][b].w;
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a][b], 0, 0, 0);
+                    }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    if (nchunks > 0) {
+        load_chunk(0);
+        store_chunk(0);
+    }
+    __syncthreads();
+    for (int c = 0; c + 1 < nchunks; ++c) {
+        load_chunk(c + 1);
+        compute(c & 1);
+        store_chunk((c + 1) & 1);
+        __syncthreads();
+    }
+    if (nchunks > 0) compute((nchunks - 1) & 1);
+    store_tile<C::BM, C::BN, C::TM, C::TN, C::WTM, C::WTN>(p, tc, acc, wm, wn, lane);
+}
+
+// OIHW [co][cin][tap] -> [co][tap][cin]
+__global__ void __launch_bounds__(256) permute_weights_kernel(const float *w, float *out, unsigned total, int cin,
+                                                              int khw, FastDiv divCin, FastDiv divKhw) {
+    unsigned stride = gridDim.x * 256;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        unsigned r, ci, co, tap;          // i indexes the OUTPUT: ((co*khw)+tap)*cin + ci
+        divCin.divmod(i, r, ci);
+        divKhw.divmod(r, co, tap);
+        out[i] = w[((size_t)co * cin + ci) * khw + tap];
     }
 }
 
@@ -306,61 +565,307 @@ typedef Cfg<32, 256, 16, 1, 4> C32x256;
 typedef Cfg<64, 256, 16, 2, 2> C64x256;
 typedef Cfg<128, 32, 16, 4, 1> C128x32;
 
+typedef TapCfg<128, 128, 16, 2, 2> T128x128x16;
+typedef TapCfg<128, 128, 32, 2, 2> T128x128x32;
+typedef TapCfg<64, 128, 16, 2, 2> T64x128x16;
+typedef TapCfg<64, 128, 32, 2, 2> T64x128x32;
+typedef TapCfg<128, 64, 16, 2, 2> T128x64x16;
+typedef TapCfg<128, 64, 32, 2, 2> T128x64x32;
+typedef TapCfg<64, 64, 16, 2, 2> T64x64x16;
+typedef TapCfg<64, 64, 32, 2, 2> T64x64x32;
+typedef TapCfg<128, 32, 32, 4, 1> T128x32x32;
+typedef TapCfg<32, 128, 32, 1, 4> T32x128x32;
+typedef TapCfg<256, 64, 16, 4, 1> T256x64x16;
+typedef TapCfg<64, 256, 16, 1, 4> T64x256x16;
+
 struct CfgInfo {
     const char *name;
+    int tap;  // 0: generic (OIHW weights, any shape)   1: tap-major (prepared weights, cin_g % bk == 0)
     int bm, bn, bk, lds;
     void (*vec)(const ConvArgs);
     void (*scl)(const ConvArgs);
+    void (*reduce)(const ConvArgs, const float *, float *);
 };
 
-#define CFG_ENTRY(T, nm) \
-    { nm, T::BM, T::BN, T::BK, T::LDS_BYTES, conv_igemm_kernel<T, true>, conv_igemm_kernel<T, false> }
+#define CFG_ENTRY(T, nm)                                                                                 \
+    {                                                                                                    \
+        nm, 0, T::BM, T::BN, T::BK, T::LDS_BYTES, conv_igemm_kernel<T, true>, conv_igemm_kernel<T, false>, \
+            reduce_tiles_kernel<T::BM, T::BN>                                                            \
+    }
+#define TAP_ENTRY(T, nm) \
+    { nm, 1, T::BM, T::BN, T::BK, T::LDS_BYTES, conv_tap_kernel<T>, conv_tap_kernel<T>, reduce_tiles_kernel<T::BM, T::BN> }
 
 const CfgInfo kCfgs[] = {
     CFG_ENTRY(C128x128, "128x128"), CFG_ENTRY(C64x128, "64x128"), CFG_ENTRY(C128x64, "128x64"),
     CFG_ENTRY(C64x64, "64x64"),     CFG_ENTRY(C32x128, "32x128"), CFG_ENTRY(C32x256, "32x256"),
     CFG_ENTRY(C64x256, "64x256"),   CFG_ENTRY(C128x32, "128x32"),
+    TAP_ENTRY(T128x128x16, "t128x128x16"), TAP_ENTRY(T128x128x32, "t128x128x32"),
+    TAP_ENTRY(T64x128x16, "t64x128x16"),   TAP_ENTRY(T64x128x32, "t64x128x32"),
+    TAP_ENTRY(T128x64x16, "t128x64x16"),   TAP_ENTRY(T128x64x32, "t128x64x32"),
+    TAP_ENTRY(T64x64x16, "t64x64x16"),     TAP_ENTRY(T64x64x32, "t64x64x32"),
+    TAP_ENTRY(T128x32x32, "t128x32x32"),   TAP_ENTRY(T32x128x32, "t32x128x32"),
+    TAP_ENTRY(T256x64x16, "t256x64x16"),   TAP_ENTRY(T64x256x16, "t64x256x16"),
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+constexpr int kLdsPerCu = 160 * 1024;
 
-// Pick tile + split-K so the grid covers the 256 CUs a few times over while
-// wasting as little padded work as possible.
-void choose_config(pl_ctx *ctx, int cout_g, int cols, int K, int groups, int &cfg, int &splits) {
+bool cfg_applies(const CfgInfo &ci, int layout, int cin_g) {
+    if (ci.tap != (layout ? 1 : 0)) return false;
+    return !ci.tap || cin_g % ci.bk == 0;
+}
+
+// How one conv is run.  Tiles [0, t1) take the data-parallel pass with the
+// fused epilogue; tiles [t1, T) take a split-K pass (s2 slices of K, compact
+// per-tile slabs) followed by the tile reduce.  `occ` > 0 pins the number of
+// co-resident workgroups per CU (by padding the LDS request) so a pass of
+// exactly occ*CUs tiles lands as occ tiles on EVERY CU -- at batch 32 the
+// ResNet layers have only 200-800 tiles, and an uneven 3-vs-4 tiles per CU
+// split costs more than anything inside the kernel.
+struct Plan {
+    int cfg, t1, s2, occ;
+};
+
+void (*kernel_of(const CfgInfo &ci, bool avec))(const ConvArgs) { return (ci.tap || avec) ? ci.vec : ci.scl; }
+
+int ensure_lds_attr(const void *kern, int bytes) {
+    static std::mutex mu;
+    static std::map<const void *, int> done;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = done.find(kern);
+    if (it != done.end() && it->second >= bytes) return PL_OK;
+    PL_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done[kern] = bytes;
+    return PL_OK;
+}
+
+// K slices a request for `splits` really yields (slices are whole BK-chunks)
+int effective_splits(const CfgInfo &ci, int K, int splits) {
+    if (splits <= 1) return 1;
+    const int chunks = (K + ci.bk - 1) / ci.bk;
+    const int cps = (chunks + splits - 1) / splits;
+    return (chunks + cps - 1) / cps;
+}
+
+int launch_pass(pl_ctx *ctx, ConvArgs a, const CfgInfo &ci, bool avec, int tile_offset, int tile_count, int splits,
+                int occ, float *out, int *used_splits) {
+    *used_splits = 0;
+    if (tile_count <= 0) return PL_OK;
+    if (ci.tap) {
+        const int total_chunks = a.K / ci.bk;
+        const int cps = (total_chunks + splits - 1) / splits;
+        splits = (total_chunks + cps - 1) / cps;
+        a.k_per_split = cps;
+        a.divCpt = FastDiv(a.cin_g / ci.bk);
+    } else {
+        const int kps = ((a.K + splits - 1) / splits + ci.bk - 1) / ci.bk * ci.bk;
+        splits = (a.K + kps - 1) / kps;
+        a.k_per_split = kps;
+    }
+    a.splits = splits;
+    a.tile_offset = tile_offset;
+    a.tile_count = tile_count;
+    a.y = out;
+    int lds = ci.lds;
+    if (occ > 0) {
+        const int want = (kLdsPerCu / occ) & ~255;          // occ blocks fit, occ+1 do not
+        if (want > lds && kLdsPerCu / (occ + 1) < want) lds = want;
+    }
+    auto kern = kernel_of(ci, avec);
+    if (lds > 48 * 1024) {
+        int rc = ensure_lds_attr((const void *)kern, lds);
+        if (rc != PL_OK) return rc;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)tile_count, (unsigned)splits), dim3(256), lds, ctx->stream, a);
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) {
+        pl_set_error("conv launch (%s): %s", ci.name, hipGetErrorString(le));
+        return PL_EHIP;
+    }
+    *used_splits = splits;  // K slices actually used (K may be too short for the request)
+    return PL_OK;
+}
+
+int run_plan(pl_ctx *ctx, const ConvArgs &a0, const Plan &pl, bool avec, float *y) {
+    const CfgInfo &ci = kCfgs[pl.cfg];
+    ConvArgs a = a0;
+    a.mtiles = (a.cout_g + ci.bm - 1) / ci.bm;
+    a.ntiles = (a.cols + ci.bn - 1) / ci.bn;
+    a.tiles = a.mtiles * a.ntiles;
+    a.divMt = FastDiv(a.mtiles);
+    const int T = a.tiles * a.groups;
+    const int s2 = effective_splits(ci, a.K, pl.s2);
+    const int t1 = s2 <= 1 ? T : (pl.t1 < 0 ? 0 : (pl.t1 > T ? T : pl.t1));
+    int used = 0;
+    int rc = launch_pass(ctx, a, ci, avec, 0, t1, 1, pl.occ, y, &used);
+    if (rc != PL_OK) return rc;
+    const int tail = T - t1;
+    if (tail <= 0) return PL_OK;
+    float *ws = nullptr;
+    const size_t slab_elems = (size_t)tail * ci.bm * ci.bn;
+    rc = pl_alloc(ctx, (size_t)s2 * slab_elems * sizeof(float), (void **)&ws);
+    if (rc != PL_OK) return rc;
+    rc = launch_pass(ctx, a, ci, avec, t1, tail, s2, 0, ws, &used);
+    if (rc == PL_OK && used != s2) {
+        pl_set_error("conv: split bookkeeping mismatch (%d vs %d)", used, s2);
+        rc = PL_EINVAL;
+    } else if (rc == PL_OK) {
+        ConvArgs r = a;
+        r.splits = used;
+        r.tile_offset = t1;
+        r.tile_count = tail;
+        hipLaunchKernelGGL(ci.reduce, dim3((unsigned)tail), dim3(256), 0, ctx->stream, r, (const float *)ws, y);
+        hipError_t le = hipGetLastError();
+        if (le != hipSuccess) {
+            pl_set_error("conv tile reduce: %s", hipGetErrorString(le));
+            rc = PL_EHIP;
+        }
+    }
+    pl_free(ctx, ws);  // stream-ordered: safe to recycle after the enqueue
+    return rc;
+}
+
+// Static choice (while capturing, or with autotune off).
+Plan choose_plan(pl_ctx *ctx, int layout, const ConvArgs &a) {
     const double cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
     double best = 1e300;
-    cfg = 0;
-    splits = 1;
+    Plan pl{-1, 0, 1, 0};
     for (int c = 0; c < kNumCfgs; ++c) {
         const CfgInfo &ci = kCfgs[c];
-        const double mt = (cout_g + ci.bm - 1) / ci.bm, nt = (cols + ci.bn - 1) / ci.bn;
-        const double tiles = mt * nt * groups;
-        for (int s = 1; s <= 16; s *= 2) {
-            if (s > 1 && K / s < 8 * ci.bk) break;  // keep >= 8 chunks per split
+        if (!cfg_applies(ci, layout, a.cin_g)) continue;
+        const double mt = (a.cout_g + ci.bm - 1) / ci.bm, nt = (a.cols + ci.bn - 1) / ci.bn;
+        const double tiles = mt * nt * a.groups;
+        const double kch = std::ceil((double)a.K / ci.bk);
+        const double per_chunk = (ci.bk / 2) * (ci.bm / 32) * (ci.bn / 32) / 4.0 + 2.0;   // MFMA slots per wave
+        const int maxocc = std::min(8, kLdsPerCu / ci.lds);
+        for (int s = 1; s <= 8; ++s) {
+            if (s > 1 && kch / s < 6) break;
             const double blocks = tiles * s;
-            // padded MFMA work per block, in units of 32x32x2 MFMA issue slots (64 cycles)
-            const double kchunks = (double)((K + s - 1) / s + ci.bk - 1) / ci.bk;
-            const double mfma_per_wave = kchunks * (ci.bk / 2) * (ci.bm / 32) * (ci.bn / 32) / 4.0;
-            // fixed per-chunk overhead (barrier + staging not hidden) and per-block prologue/epilogue
-            const double block_cost = mfma_per_wave + kchunks * 3.0 + 40.0 + (ci.bm / 32) * (ci.bn / 32) * 2.0;
-            // co-resident workgroups per CU (LDS/regs allow at least 2; big tiles: 2, small: 4)
-            const double per_cu = (ci.bm * ci.bn >= 128 * 128) ? 2.0 : (ci.bm * ci.bn >= 64 * 128 ? 3.0 : 4.0);
-            const double slots = cus * per_cu;
-            const double rounds = std::ceil(blocks / slots);
-            // each SIMD hosts per_cu waves; throughput-limited by MFMA pipe
-            double cost = rounds * per_cu * block_cost;
-            if (s > 1) cost += 60.0 + (double)cout_g * cols * groups * (s + 1) / (cus * 4 * 64.0) ;  // reduce pass
+            const double per_cu = std::ceil(blocks / cus);
+            const double rounds = std::ceil(per_cu / maxocc);
+            double cost = per_cu * (std::ceil(kch / s) * per_chunk + 40.0) + rounds * 20.0;
+            if (s > 1) cost += 50.0 + tiles * ci.bm * ci.bn * (s + 1) / (cus * 256.0);
             if (cost < best) {
                 best = cost;
-                cfg = c;
-                splits = s;
+                pl = Plan{c, s > 1 ? 0 : (int)tiles, s, 0};
             }
         }
     }
+    return pl;
+}
+
+struct TuneKey {
+    int v[18];
+    bool operator<(const TuneKey &o) const { return memcmp(v, o.v, sizeof v) < 0; }
+};
+std::mutex g_tune_mu;
+std::map<std::pair<pl_ctx *, TuneKey>, Plan> g_tune;
+
+float time_plan(pl_ctx *ctx, const ConvArgs &a, const Plan &pl, bool avec, float *y, hipEvent_t e0, hipEvent_t e1,
+                int reps) {
+    float best = 1e30f;
+    for (int rep = 0; rep <= reps; ++rep) {
+        (void)hipEventRecord(e0, ctx->stream);
+        if (run_plan(ctx, a, pl, avec, y) != PL_OK) return 1e30f;
+        (void)hipEventRecord(e1, ctx->stream);
+        if (hipEventSynchronize(e1) != hipSuccess) return 1e30f;
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (rep > 0 && ms < best) best = ms;   // first run warms caches / clocks
+    }
+    return best;
+}
+
+// First sight of a conv shape: measure candidate plans (MIOpen-find style) and
+// remember the winner for this context.
+Plan tune_plan(pl_ctx *ctx, int layout, const ConvArgs &a, bool avec, float *y, Plan fallback) {
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess) return fallback;
+    if (hipEventCreate(&e1) != hipSuccess) {
+        (void)hipEventDestroy(e0);
+        return fallback;
+    }
+    const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
+    const double work = (double)a.cout_g * a.cols * a.groups;
+    struct Cand {
+        float ms;
+        Plan pl;
+    };
+    std::vector<Cand> stage1;
+    const int splits[] = {2, 3, 4, 6, 8, 12, 16};
+    for (int c = 0; c < kNumCfgs; ++c) {
+        const CfgInfo &ci = kCfgs[c];
+        if (!cfg_applies(ci, layout, a.cin_g)) continue;
+        const int T = ((a.cout_g + ci.bm - 1) / ci.bm) * ((a.cols + ci.bn - 1) / ci.bn) * a.groups;
+        if ((double)T * ci.bm * ci.bn > 2.5 * work + 1e5) continue;               // mostly padding
+        Plan dp{c, T, 1, 0};
+        stage1.push_back({time_plan(ctx, a, dp, avec, y, e0, e1, 2), dp});
+        const int chunks = (a.K + ci.bk - 1) / ci.bk;
+        for (int s : splits) {
+            if (chunks / s < 3 || (double)T * s > 8.0 * cus * 4 || T > 6 * cus) break;
+            Plan sk{c, 0, s, 0};
+            stage1.push_back({time_plan(ctx, a, sk, avec, y, e0, e1, 2), sk});
+        }
+    }
+    if (stage1.empty()) {
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        return fallback;
+    }
+    std::sort(stage1.begin(), stage1.end(), [](const Cand &x, const Cand &y2) { return x.ms < y2.ms; });
+    Cand best = stage1[0];
+    // stage 2: for the most promising tile shapes, an exactly balanced
+    // data-parallel prefix (occ tiles on every CU) plus a split-K tail
+    std::vector<int> tried;
+    for (size_t i = 0; i < stage1.size() && tried.size() < 4; ++i) {
+        const int c = stage1[i].pl.cfg;
+        if (std::find(tried.begin(), tried.end(), c) != tried.end()) continue;
+        tried.push_back(c);
+        const CfgInfo &ci = kCfgs[c];
+        const int T = ((a.cout_g + ci.bm - 1) / ci.bm) * ((a.cols + ci.bn - 1) / ci.bn) * a.groups;
+        const int chunks = (a.K + ci.bk - 1) / ci.bk;
+        const int maxocc = std::min(8, kLdsPerCu / ci.lds);
+        for (int occ = 1; occ <= maxocc; ++occ) {
+            const int wave = occ * cus;
+            if (wave > T) break;
+            const int t1 = T / wave * wave;
+            if (T / wave > 1 && occ < maxocc / 2) continue;   // several rounds: prefer fuller CUs
+            const int tail = T - t1;
+            if (tail == 0) {
+                Plan pl{c, T, 1, occ};
+                float ms = time_plan(ctx, a, pl, avec, y, e0, e1, 2);
+                if (ms < best.ms) best = {ms, pl};
+                continue;
+            }
+            for (int s : splits) {
+                if (chunks / s < 2) break;
+                if ((double)tail * s < 0.4 * cus && s < 16) continue;          // tail would leave CUs idle
+                if ((double)tail * s > 6.0 * cus) break;
+                Plan pl{c, t1, s, occ};
+                float ms = time_plan(ctx, a, pl, avec, y, e0, e1, 2);
+                if (ms < best.ms) best = {ms, pl};
+            }
+        }
+    }
+    // confirm the winner against the runner-up with more repetitions (noise)
+    if (stage1.size() > 1) {
+        float m0 = time_plan(ctx, a, best.pl, avec, y, e0, e1, 5);
+        float m1 = time_plan(ctx, a, stage1[0].pl, avec, y, e0, e1, 5);
+        if (m1 < m0) best = {m1, stage1[0].pl};
+        else best.ms = m0;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (getenv("PLANER_CONV_TUNE_LOG"))
+        fprintf(stderr, "[planer_hip] conv N%d C%d %dx%d -> %d k%dx%d s%d g%d layout %d: %s t1 %d split %d occ %d (%.3f ms, %.1f TFLOP/s)\n",
+                a.N, a.Cin, a.H, a.W, a.Cout, a.kh, a.kw, a.sh, a.groups, layout, kCfgs[best.pl.cfg].name, best.pl.t1,
+                best.pl.s2, best.pl.occ, best.ms, 2.0 * a.cout_g * a.groups * (double)a.cols * a.K / best.ms / 1e9);
+    return best.pl;
 }
 
 int conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const float *w, int Cout, int kh, int kw,
                 const float *bias, float *y, int sh, int sw, int dh, int dw, int pt, int pl, int pb, int pr,
-                int group, const float *scale, const float *shift, const float *res, int act, double alpha) {
+                int group, const float *scale, const float *shift, const float *res, int act, double alpha,
+                int layout) {
     PL_REQUIRE(ctx && x && w && y, PL_EINVAL, "conv2d: null pointer");
     PL_REQUIRE(N >= 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0 && kh > 0 && kw > 0, PL_EINVAL, "conv2d: bad shape");
     PL_REQUIRE(sh > 0 && sw > 0 && dh > 0 && dw > 0 && pt >= 0 && pl >= 0 && group > 0, PL_EINVAL, "conv2d: bad parameter");
@@ -368,6 +873,7 @@ int conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const
     PL_REQUIRE(pt == pb && pl == pr, PL_EUNSUPPORTED, "asymmetric pads are undefined in the reference (util.py:8)");
     PL_REQUIRE(Cin % group == 0 && Cout % group == 0, PL_EUNSUPPORTED, "group must divide Cin and Cout");
     PL_REQUIRE(act >= 0 && act <= 2, PL_EINVAL, "conv2d: bad activation code");
+    PL_REQUIRE(layout == 0 || layout == 1, PL_EINVAL, "conv2d: bad weight layout");
     const int Ho = (H + pt + pb - (kh - 1) * dh - 1 + sh) / sh;  // util.py:25
     const int Wo = (W + pl + pr - (kw - 1) * dw - 1 + sw) / sw;  // util.py:26
     PL_REQUIRE(Ho > 0 && Wo > 0, PL_EINVAL, "conv2d: empty output (%d x %d)", Ho, Wo);
@@ -378,9 +884,11 @@ int conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const
     const size_t w_elems = (size_t)Cout * (Cin / group) * kh * kw;
     PL_REQUIRE(out_elems < (1ull << 31) && in_elems <= (1ull << 29) && w_elems <= (1ull << 29),
                PL_EUNSUPPORTED, "conv2d: input/filter above 2 GiB or output above 2^31 elements");
+    PL_REQUIRE(layout == 0 || (Cin / group) % 16 == 0, PL_EINVAL, "conv2d: tap-major weights need Cin/group %% 16 == 0");
     CtxGuard guard(ctx);
 
     ConvArgs a;
+    memset(&a, 0, sizeof a);
     a.x = x; a.w = w; a.y = y;
     a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.Ho = Ho; a.Wo = Wo;
     a.kh = kh; a.kw = kw; a.sh = sh; a.sw = sw; a.dh = dh; a.dw = dw; a.pt = pt; a.pl = pl;
@@ -388,48 +896,42 @@ int conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const
     a.K = a.cin_g * kh * kw;
     a.cols = N * Ho * Wo;
     a.HoWo = Ho * Wo; a.HW = H * W;
-    a.slab = out_elems;
     a.x_bytes = (int)(in_elems * 4); a.w_bytes = (int)(w_elems * 4);
     a.divKhw = FastDiv(kh * kw); a.divKw = FastDiv(kw);
     a.divHoWo = FastDiv(a.HoWo); a.divWo = FastDiv(Wo);
+    a.divMt = FastDiv(1); a.divCpt = FastDiv(1);
     a.ep = Epilogue{bias, scale, shift, res, act, (float)alpha, (float)(1.0 - alpha)};
-
-    int cfg, splits;
-    choose_config(ctx, a.cout_g, a.cols, a.K, group, cfg, splits);
-    if (ctx->conv_cfg >= 0 && ctx->conv_cfg < kNumCfgs) cfg = ctx->conv_cfg;
-    if (ctx->conv_split_k > 0) splits = ctx->conv_split_k;
-    const CfgInfo &ci = kCfgs[cfg];
-    // split boundaries on BK multiples so every chunk start keeps float4 alignment
-    int kps = ((a.K + splits - 1) / splits + ci.bk - 1) / ci.bk * ci.bk;
-    splits = (a.K + kps - 1) / kps;
-    a.splits = splits; a.k_per_split = kps;
-    a.mtiles = (a.cout_g + ci.bm - 1) / ci.bm;
-    a.ntiles = (a.cols + ci.bn - 1) / ci.bn;
-    a.tiles = a.mtiles * a.ntiles;
-    a.divMt = FastDiv(a.mtiles);
-
-    float *ws = nullptr;
-    if (splits > 1) {
-        int rc = pl_alloc(ctx, (size_t)splits * out_elems * sizeof(float), (void **)&ws);
-        if (rc != PL_OK) return rc;
-        a.y = ws;
-    }
     const bool avec = (a.K % 4 == 0) && ((reinterpret_cast<uintptr_t>(w) & 15u) == 0);
-    dim3 grid((unsigned)(a.tiles * group), (unsigned)splits);
-    auto kern = avec ? ci.vec : ci.scl;
-    hipLaunchKernelGGL(kern, grid, dim3(256), ci.lds, ctx->stream, a);
-    hipError_t le = hipGetLastError();
-    int rc = PL_OK;
-    if (le != hipSuccess) {
-        pl_set_error("conv_igemm launch (%s): %s", ci.name, hipGetErrorString(le));
-        rc = PL_EHIP;
+
+    // forced configuration (tests / tuning tools): split > 1 means split-K over all tiles
+    if (ctx->conv_cfg >= 0 && ctx->conv_cfg < kNumCfgs && cfg_applies(kCfgs[ctx->conv_cfg], layout, a.cin_g)) {
+        const int s = ctx->conv_split_k > 0 ? ctx->conv_split_k : 1;
+        Plan pl{ctx->conv_cfg, s > 1 ? ctx->conv_t1 : (1 << 30), s, ctx->conv_occ};
+        return run_plan(ctx, a, pl, avec, y);
     }
-    if (splits > 1) {
-        if (rc == PL_OK)
-            rc = pl_splitk_reduce_f32(ctx, ws, splits, y, N, Cout, a.HoWo, bias, scale, shift, res, act, alpha);
-        pl_free(ctx, ws);  // stream-ordered: safe to recycle after the enqueue
+    TuneKey key = {{layout, N, Cin, H, W, Cout, kh, kw, sh, sw, dh, dw, pt, pl, group, res != nullptr,
+                    (scale != nullptr) * 2 + (bias != nullptr), act}};
+    Plan plan{-1, 0, 1, 0};
+    bool have = false;
+    {
+        std::lock_guard<std::mutex> lk(g_tune_mu);
+        auto it = g_tune.find({ctx, key});
+        if (it != g_tune.end()) {
+            plan = it->second;
+            have = true;
+        }
     }
-    return rc;
+    if (!have) {
+        plan = choose_plan(ctx, layout, a);
+        PL_REQUIRE(plan.cfg >= 0, PL_EUNSUPPORTED, "conv2d: no kernel configuration applies");
+        const bool tune = ctx->autotune && !ctx->capturing && res != y && x != y;
+        if (tune) plan = tune_plan(ctx, layout, a, avec, y, plan);
+        if (tune || !ctx->autotune) {
+            std::lock_guard<std::mutex> lk(g_tune_mu);
+            g_tune[{ctx, key}] = plan;
+        }
+    }
+    return run_plan(ctx, a, plan, avec, y);
 }
 
 }  // namespace
@@ -440,15 +942,35 @@ int pl_conv2d_f32(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, con
                   int kw, const float *bias, float *y, int sh, int sw, int dh, int dw, int pt, int pl, int pb,
                   int pr, int group) {
     return conv_launch(ctx, x, N, Cin, H, W, w, Cout, kh, kw, bias, y, sh, sw, dh, dw, pt, pl, pb, pr, group,
-                       nullptr, nullptr, nullptr, PL_ACT_NONE, 0.0);
+                       nullptr, nullptr, nullptr, PL_ACT_NONE, 0.0, 0);
 }
 
 int pl_conv2d_fused_f32(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const float *w, int Cout, int kh,
                         int kw, const float *bias, float *y, int sh, int sw, int dh, int dw, int pt, int pl, int pb,
                         int pr, int group, const float *scale, const float *shift, const float *res, int act,
-                        double alpha) {
+                        double alpha, int w_layout) {
     return conv_launch(ctx, x, N, Cin, H, W, w, Cout, kh, kw, bias, y, sh, sw, dh, dw, pt, pl, pb, pr, group, scale,
-                       shift, res, act, alpha);
+                       shift, res, act, alpha, w_layout);
+}
+
+int pl_conv2d_prepare_weights_f32(pl_ctx *ctx, const float *w, int Cout, int Cin_g, int kh, int kw, float *out) {
+    PL_REQUIRE(ctx && w && out, PL_EINVAL, "pl_conv2d_prepare_weights_f32: null pointer");
+    PL_REQUIRE(Cout > 0 && Cin_g > 0 && kh > 0 && kw > 0, PL_EINVAL, "pl_conv2d_prepare_weights_f32: bad shape");
+    const size_t total = (size_t)Cout * Cin_g * kh * kw;
+    PL_REQUIRE(total < (1ull << 31), PL_EUNSUPPORTED, "filter too large");
+    CtxGuard g(ctx);
+    unsigned blocks = (unsigned)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    permute_weights_kernel<<<blocks, 256, 0, ctx->stream>>>(w, out, (unsigned)total, Cin_g, kh * kw, FastDiv(Cin_g),
+                                                           FastDiv(kh * kw));
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
+
+int pl_set_autotune(pl_ctx *ctx, int enabled) {
+    PL_REQUIRE(ctx, PL_EINVAL, "null ctx");
+    ctx->autotune = enabled != 0;
+    return PL_OK;
 }
 
 int pl_conv2d_set_config(pl_ctx *ctx, int cfg, int split_k) {
@@ -456,6 +978,18 @@ int pl_conv2d_set_config(pl_ctx *ctx, int cfg, int split_k) {
     PL_REQUIRE(cfg < kNumCfgs, PL_EINVAL, "config %d out of range (%d)", cfg, kNumCfgs);
     ctx->conv_cfg = cfg;
     ctx->conv_split_k = split_k;
+    ctx->conv_t1 = 0;
+    ctx->conv_occ = 0;
+    return PL_OK;
+}
+
+int pl_conv2d_set_plan(pl_ctx *ctx, int cfg, int dp_tiles, int split_k, int occupancy) {
+    PL_REQUIRE(ctx, PL_EINVAL, "null ctx");
+    PL_REQUIRE(cfg < kNumCfgs, PL_EINVAL, "config %d out of range (%d)", cfg, kNumCfgs);
+    ctx->conv_cfg = cfg;
+    ctx->conv_split_k = split_k;
+    ctx->conv_t1 = dp_tiles;
+    ctx->conv_occ = occupancy;
     return PL_OK;
 }
 
@@ -480,10 +1014,10 @@ int pl_gemm_f32(pl_ctx *ctx, const float *a, int M, int K, const float *b, int N
     if (M == 0 || N == 0) return PL_OK;
     if (trans_b)
         return conv_launch(ctx, a, M, K, 1, 1, b, N, 1, 1, bias, y, 1, 1, 1, 1, 0, 0, 0, 0, 1, nullptr, nullptr,
-                           nullptr, PL_ACT_NONE, 0.0);
+                           nullptr, PL_ACT_NONE, 0.0, 0);
     PL_REQUIRE(!bias, PL_EUNSUPPORTED, "pl_gemm_f32: bias needs trans_b=1");
     return conv_launch(ctx, b, 1, K, 1, N, a, M, 1, 1, nullptr, y, 1, 1, 1, 1, 0, 0, 0, 0, 1, nullptr, nullptr,
-                       nullptr, PL_ACT_NONE, 0.0);
+                       nullptr, PL_ACT_NONE, 0.0, 0);
 }
 
 }  // extern "C"

@@ -6,6 +6,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "common.h"
@@ -46,6 +47,7 @@ int pl_ctx_create(int device, pl_ctx **out) {
     c->cu_count = prop.multiProcessorCount;
     c->hbm_bytes = prop.totalGlobalMem;
     c->arch = prop.gcnArchName;
+    { const char *at = getenv("PLANER_HIP_AUTOTUNE"); c->autotune = !(at && at[0] == '0'); }
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete c;

@@ -73,11 +73,27 @@ def Conv2d(x, K, B=None, group=1, strides=(1, 1), dilations=(1, 1), pads=(0, 0, 
     return ConvFused(x, K, B, group=group, strides=strides, dilations=dilations, pads=pads)
 
 
+def prepare_conv_weights(K):
+    """OIHW filters -> the tap-major layout [Cout][kh*kw][Cin/g] the fast conv
+    kernel reads (done once per model by Net's plan compiler).  The returned
+    array keeps the logical OIHW shape; only the bytes are permuted."""
+    _f32(K)
+    cout, cin_g, kh, kw = K.shape
+    if cin_g % 16:
+        raise ValueError("tap-major filters need Cin/group % 16 == 0")
+    if kh * kw == 1:
+        return K                                   # identical in both layouts
+    out = empty(K.shape, ctx=K.ctx)
+    _lib.call("pl_conv2d_prepare_weights_f32", K.ctx.handle, K.ptr, cout, cin_g, kh, kw, out.ptr)
+    return out
+
+
 def ConvFused(x, K, B=None, scale=None, shift=None, res=None, group=1, strides=(1, 1),
-              dilations=(1, 1), pads=(0, 0, 0, 0), act=ACT_NONE, alpha=0.0):
+              dilations=(1, 1), pads=(0, 0, 0, 0), act=ACT_NONE, alpha=0.0, w_layout=0):
     """Conv2d with BatchNorm / Add / (Leaky)ReLU folded into its epilogue:
     act((conv(x,K)+B)*scale + shift + res).  Emitted by Net's plan compiler for
-    the chains conv->batchnorm->[add]->[relu|leakyrelu]; not a reference op."""
+    the chains conv->batchnorm->[add]->[relu|leakyrelu]; not a reference op.
+    w_layout=1: K holds tap-major bytes from prepare_conv_weights()."""
     _f32(x, K, B, scale, shift, res)
     n, cin, h, w = x.shape
     cout, cin_g, kh, kw = K.shape
@@ -93,7 +109,7 @@ def ConvFused(x, K, B=None, scale=None, shift=None, res=None, group=1, strides=(
     _lib.call("pl_conv2d_fused_f32", x.ctx.handle, x.ptr, n, cin, h, w, K.ptr, cout, kh, kw,
               _ptr(B), y.ptr, strides[0], strides[1], dilations[0], dilations[1],
               pads[0], pads[1], pads[2], pads[3], int(group),
-              _ptr(scale), _ptr(shift), _ptr(res), int(act), float(alpha))
+              _ptr(scale), _ptr(shift), _ptr(res), int(act), float(alpha), int(w_layout))
     return y
 
 

@@ -86,6 +86,7 @@ class Net:
         self._slots = []             # (offset, nbytes) per weight inside the blob
         self._program = None
         self._plans = {}
+        self._extra = {}             # derived constant tensors (tap-major filters)
 
     # ---- loading ----------------------------------------------------------------
     def load_json(self, inputs, inits, body, flow, debug=False):
@@ -124,7 +125,7 @@ class Net:
             self._host[o:o + n] = raw[pos:pos + n]
             pos += n
         self._blob.set(self._host)
-        self._plans = {}
+        self._plans, self._extra = {}, {}
 
     def weight_blob(self):
         """The single device allocation holding all weights (RCCL broadcast unit)."""
@@ -133,6 +134,7 @@ class Net:
     def refresh_host_mirror(self):
         """Re-read the host mirror after the device blob was written by a broadcast."""
         self._host[:] = self._blob.get()
+        self._plans, self._extra = {}, {}
 
     def half(self):
         raise NotImplementedError("planer_amd computes the hot path in float32 only (BASELINE metric)")
@@ -150,6 +152,7 @@ class Net:
         """net.py:37-72: one kernel launch (or view) per layer, in flow order."""
         env = {"None": None}
         env.update(zip(self.inits, self.weights))
+        env.update(self._extra)
         env.update(zip(self.input, xs))
         events, out_key = [], None
         for i, (src, names, dst) in enumerate(prog.flow):
@@ -209,9 +212,41 @@ class Net:
         return rst if isinstance(rst, tuple) else (rst,)
 
     # ---- plan compiler -----------------------------------------------------------------
-    def _fuse(self, shapes):
-        body, flow, nfused = fuse_flow(self.layer, self.flow, self.inits, shapes)
+    def _fuse(self, shapes, fuse=True):
+        """Plan program: fused epilogues + tap-major filter copies for the fast conv kernel."""
+        if fuse:
+            body, flow, nfused = fuse_flow(self.layer, self.flow, self.inits, shapes)
+        else:
+            body, flow, nfused = [list(b) for b in self.layer], [list(f) for f in self.flow], 0
+        if os.environ.get("PLANER_HIP_TAPMAJOR", "1") != "0":
+            body, flow = self._prepare_filters(body, flow)
         return _Program(body, flow), nfused
+
+    def _prepare_filters(self, body, flow):
+        """Give every eligible conv a tap-major copy of its (constant) filter."""
+        from .layer import prepare_conv_weights
+        wmap = dict(zip(self.inits, self.weights))
+        kinds = {b[0]: b for b in body}
+        out_body = {b[0]: list(b) for b in body}
+        out_flow = []
+        for src, names, dst in flow:
+            name = names[0] if isinstance(names, list) else names
+            entry = kinds[name]
+            srcs = list(src) if isinstance(src, list) else [src]
+            if entry[1] in ("conv", "conv_fused") and len(srcs) >= 2 and srcs[1] in wmap:
+                K = wmap[srcs[1]]
+                if K.ndim == 4 and K.dtype == numpy.float32 and K.shape[1] % 16 == 0:
+                    key = srcs[1] + "@tap"
+                    if key not in self._extra:
+                        self._extra[key] = prepare_conv_weights(K)
+                    srcs[1] = key
+                    if entry[1] == "conv":            # plain conv: route through the fused entry point
+                        srcs = (srcs + ["None"] * 6)[:6] if len(srcs) < 6 else srcs
+                        out_body[name] = [name, "conv_fused", dict(entry[2], w_layout=1)]
+                    else:
+                        out_body[name] = [name, "conv_fused", dict(entry[2], w_layout=1)]
+            out_flow.append([srcs, [name], dst])
+        return [out_body[b[0]] for b in body], out_flow
 
     def compile(self, *xs):
         """Build (or fetch) the captured plan for these device inputs."""
@@ -227,7 +262,7 @@ class Net:
         #    ReLU works in place, so feed it copies, not the static inputs.
         timer = dict(self.timer)
         self._interpret(self._program, [s.copy() for s in statics], shapes=shapes)
-        prog, nfused = (self._fuse(shapes) if self.use_fusion else (self._program, 0))
+        prog, nfused = self._fuse(shapes, self.use_fusion)
         # 2) fused eager pass warms the pool with exactly the blocks the capture will ask for
         self._interpret(prog, [s.copy() for s in statics])
         ctx.synchronize()

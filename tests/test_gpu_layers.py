@@ -54,27 +54,63 @@ def test_copy_and_compare_ops_are_bit_exact(pa, name, golden_layers):
     np.testing.assert_array_equal(outs[0].get(), z["%s/out0" % name])
 
 
-def test_conv_every_tile_config_and_split_k(pa):
-    """All tile shapes of the implicit-GEMM kernel and the split-K path agree with the oracle."""
+def _cfg_names(pa):
+    import ctypes
     lib = pa._lib.load()
+    names = []
+    for c in range(lib.pl_conv2d_num_configs()):
+        buf = ctypes.create_string_buffer(32)
+        lib.pl_conv2d_config_name(c, buf, 32)
+        names.append(buf.value.decode())
+    return names
+
+
+def test_conv_every_tile_config_and_split_k(pa):
+    """All tile shapes of both implicit-GEMM kernels (generic OIHW and tap-major) and the
+    split-K path agree with the oracle."""
     ctx = pa.hip.context()
+    names = _cfg_names(pa)
+    assert any(n.startswith("t") for n in names) and any(not n.startswith("t") for n in names)
     rng = np.random.default_rng(7)
-    shapes = [((3, 24, 14, 14), (40, 24, 3, 3), dict(strides=[1, 1], pads=[1, 1, 1, 1])),
+    shapes = [((3, 32, 14, 14), (40, 32, 3, 3), dict(strides=[1, 1], pads=[1, 1, 1, 1])),
               ((2, 3, 33, 35), (20, 3, 7, 7), dict(strides=[2, 2], pads=[3, 3, 3, 3])),
-              ((2, 64, 7, 7), (130, 64, 1, 1), dict(strides=[1, 1], pads=[0, 0, 0, 0]))]
+              ((2, 64, 7, 7), (130, 64, 1, 1), dict(strides=[1, 1], pads=[0, 0, 0, 0])),
+              ((2, 64, 13, 11), (70, 64, 3, 3), dict(strides=[2, 2], pads=[1, 1, 1, 1])),
+              ((2, 64, 9, 9), (48, 32, 3, 3), dict(strides=[1, 1], pads=[2, 2, 2, 2], dilations=[2, 2], group=2))]
     try:
         for xs, ks, p in shapes:
             x = rng.standard_normal(xs).astype(np.float32)
             k = (rng.standard_normal(ks) * 0.1).astype(np.float32)
             b = rng.standard_normal(ks[0]).astype(np.float32)
             ref = np.ascontiguousarray(onp.conv2d(x, k, b, **p))
-            for cfg in range(lib.pl_conv2d_num_configs()):
+            dx, dk, db = pa.asarray(x), pa.asarray(k), pa.asarray(b)
+            dkt = pa.prepare_conv_weights(dk) if ks[1] % 16 == 0 else None
+            for cfg, name in enumerate(names):
+                tap = name.startswith("t")
+                if tap and (dkt is None or ks[1] % int(name.split("x")[-1])):
+                    continue
                 for split in (1, 2, 3):
                     ctx.set_conv_config(cfg, split)
-                    y = pa.Conv2d(pa.asarray(x), pa.asarray(k), pa.asarray(b), **p).get()
-                    assert_close(y, ref, RTOL, "cfg %d split %d %s" % (cfg, split, xs))
+                    y = pa.ConvFused(dx, dkt if tap else dk, db, w_layout=int(tap), **p).get()
+                    assert_close(y, ref, RTOL, "cfg %s split %d %s" % (name, split, xs))
     finally:
         ctx.set_conv_config(-1, 0)
+
+
+def test_autotune_and_heuristic_agree(pa):
+    ctx = pa.hip.context()
+    lib = pa._lib.load()
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((4, 64, 20, 20)).astype(np.float32)
+    k = (rng.standard_normal((96, 64, 3, 3)) * 0.1).astype(np.float32)
+    ref = np.ascontiguousarray(onp.conv2d(x, k, pads=[1, 1, 1, 1]))
+    dx, dk = pa.asarray(x), pa.asarray(k)
+    dkt = pa.prepare_conv_weights(dk)
+    for tune in (1, 0, 1):
+        lib.pl_set_autotune(ctx.handle, tune)
+        assert_close(pa.Conv2d(dx, dk, pads=[1, 1, 1, 1]).get(), ref, RTOL)
+        assert_close(pa.ConvFused(dx, dkt, pads=[1, 1, 1, 1], w_layout=1).get(), ref, RTOL)
+    lib.pl_set_autotune(ctx.handle, 1)
 
 
 def test_conv_fused_epilogue_matches_layer_by_layer(pa):
