@@ -109,7 +109,8 @@ def main():
     xs_host = [np.random.default_rng(1 + 1000 * i + rank).standard_normal((hi - lo, 3, 224, 224)).astype(np.float32)
                for i in range(2)]
     xs = [planer_amd.asarray(a, ctx=ctx) for a in xs_host]
-    plan = net.compile(xs[0])                   # fuse + warm the pool + capture the hipGraph
+    plan = net.compile(xs[0])                   # fuse + tune + warm the pool + capture the hipGraph
+    ctx.save_tune_cache()                       # no-op unless PLANER_HIP_TUNE_CACHE is set
     state = {"i": 0}
 
     def step():
@@ -160,7 +161,8 @@ def main():
     c3 = classes["conv3x3"]
     achieved = c3["flops"] / (c3["ms"] * 1e-3) / 1e12
     total_flops = sum(f for f, _ in flops.values()) + 2.0 * n * 512 * 1000
-    roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel (16 conv3x3 launches per forward)",
+    roofline = {"bound": "mfma", "kernel": "conv_tap_kernel / conv_igemm_kernel: the 16 conv3x3 launches of one forward "
+                                          "(incl. their split-K tile-reduce launches)",
                 "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
                 "avg_launch_ms": round(c3["ms"] / c3["launches"], 4),

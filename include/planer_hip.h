@@ -114,6 +114,9 @@ int pl_conv2d_prepare_weights_f32(pl_ctx *ctx, const float *w, int Cout, int Cin
  * and remembers the fastest (on by default; PLANER_HIP_AUTOTUNE=0 or 0 here
  * selects the static heuristic). Never runs during graph capture. */
 int pl_set_autotune(pl_ctx *ctx, int enabled);
+/* Persist / restore the tuned plans of a context (text file). */
+int pl_tune_cache_save(pl_ctx *ctx, const char *path);
+int pl_tune_cache_load(pl_ctx *ctx, const char *path, int *entries);
 /* Force one tile configuration for the conv kernel (tuning / tests).
  * cfg < 0 restores the built-in heuristic. split_k <= 0 means automatic. */
 int pl_conv2d_set_config(pl_ctx *ctx, int cfg, int split_k);

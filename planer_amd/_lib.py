@@ -50,6 +50,8 @@ SIGNATURES = {
                            + [_P, _P, _P, _I, c_double, _I],
     "pl_conv2d_prepare_weights_f32": [_P, _P, _I, _I, _I, _I, _P],
     "pl_set_autotune": [_P, _I],
+    "pl_tune_cache_save": [_P, c_char_p],
+    "pl_tune_cache_load": [_P, c_char_p, POINTER(c_int)],
     "pl_conv2d_set_config": [_P, _I, _I],
     "pl_conv2d_set_plan": [_P, _I, _I, _I, _I],
     "pl_conv2d_num_configs": [],

@@ -126,7 +126,9 @@ __device__ __forceinline__ void store_tile(const ConvArgs &p, const TileCoord &t
 }
 
 // Combine the split-K slabs of the tiles [tile_offset, tile_offset+tile_count)
-// and apply the fused tail.  One workgroup per tile; thread = one column.
+// and apply the fused tail.  blockIdx.x = tile, blockIdx.y = band of
+// REDUCE_ROWS rows; thread = one column, so slab reads and NCHW writes coalesce.
+constexpr int REDUCE_ROWS = 16;
 template <int BM, int BN>
 __global__ void __launch_bounds__(256) reduce_tiles_kernel(const ConvArgs p, const float *slabs, float *y) {
     const unsigned local = blockIdx.x;
@@ -136,7 +138,7 @@ __global__ void __launch_bounds__(256) reduce_tiles_kernel(const ConvArgs p, con
     const unsigned nt = p.divMt.div(t);
     const int m0 = (int)(t - nt * (unsigned)p.mtiles) * BM, col0 = (int)nt * BN;
     constexpr int RPP = 256 / BN;
-    const int cl = threadIdx.x % BN, r0 = threadIdx.x / BN;
+    const int cl = threadIdx.x % BN, r0 = blockIdx.y * REDUCE_ROWS + threadIdx.x / BN;
     const int jc = col0 + cl;
     if (jc >= p.cols) return;
     unsigned n, pix;
@@ -144,13 +146,16 @@ __global__ void __launch_bounds__(256) reduce_tiles_kernel(const ConvArgs p, con
     const size_t obase = ((size_t)n * p.Cout + (size_t)g * p.cout_g) * p.HoWo + pix;
     const size_t sstride = (size_t)p.tile_count * (BM * BN);
     const float *sp = slabs + (size_t)local * (BM * BN) + cl;
-    for (int rl = r0; rl < BM; rl += RPP) {
+#pragma unroll
+    for (int i = 0; i < REDUCE_ROWS / RPP; ++i) {
+        const int rl = r0 + i * RPP;
         const int row = m0 + rl;
-        if (row >= p.cout_g) break;
-        float v = sp[rl * BN];
-        for (int z = 1; z < p.splits; ++z) v += sp[z * sstride + rl * BN];
-        const size_t idx = obase + (size_t)row * p.HoWo;
-        y[idx] = apply_epilogue(p.ep, v, (int)g * p.cout_g + row, idx);
+        if (row < p.cout_g) {
+            float v = sp[rl * BN];
+            for (int z = 1; z < p.splits; ++z) v += sp[z * sstride + rl * BN];
+            const size_t idx = obase + (size_t)row * p.HoWo;
+            y[idx] = apply_epilogue(p.ep, v, (int)g * p.cout_g + row, idx);
+        }
     }
 }
 
@@ -444,10 +449,13 @@ __global__ void __launch_bounds__(256) conv_tap_kernel(const ConvArgs p) {
         aoff[i] = rok ? (((int)g * p.cout_g + m0 + row) * p.K + kq * 4) << 2 : OOB;
     }
 
-    float4 breg[C::B_PASSES];
-    float4 areg[C::A_PER_THREAD];
+    // two staging register sets: loads run TWO chunks ahead of the MFMAs, so a
+    // lone wave per SIMD (the batch-32 regime: 1-3 workgroups per CU) still
+    // covers the ~1000-cycle L2 latency with its own matrix work
+    float4 breg0[C::B_PASSES], breg1[C::B_PASSES];
+    float4 areg0[C::A_PER_THREAD], areg1[C::A_PER_THREAD];
 
-    auto load_chunk = [&](int c) {
+    auto load_chunk = [&](int c, float4 (&breg)[C::B_PASSES], float4 (&areg)[C::A_PER_THREAD]) {
         const int ci = cbeg + c;                                // wave-uniform
         const unsigned tap = p.divCpt.div((unsigned)ci);
         const int cin0 = (ci - (int)tap * cpt) * C::BK;
@@ -472,7 +480,7 @@ __global__ void __launch_bounds__(256) conv_tap_kernel(const ConvArgs p) {
             areg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, aoff[i], ksoff, 0));
     };
 
-    auto store_chunk = [&](int buf) {
+    auto store_chunk = [&](int buf, const float4 (&breg)[C::B_PASSES], const float4 (&areg)[C::A_PER_THREAD]) {
         float *Ab = As + buf * C::A_ELEMS;
         float *Bb = Bs + buf * C::B_ELEMS;
 #pragma unroll
@@ -529,17 +537,32 @@ __global__ void __launch_bounds__(256) conv_tap_kernel(const ConvArgs p) {
     };
 
     if (nchunks > 0) {
-        load_chunk(0);
-        store_chunk(0);
-    }
-    __syncthreads();
-    for (int c = 0; c + 1 < nchunks; ++c) {
-        load_chunk(c + 1);
-        compute(c & 1);
-        store_chunk((c + 1) & 1);
+        const int last = nchunks - 1;
+        load_chunk(0, breg0, areg0);
+        load_chunk(min(1, last), breg1, areg1);
+        store_chunk(0, breg0, areg0);
         __syncthreads();
+        // invariant at the loop head: LDS buffer 0 holds chunk c, set 1 holds (or is
+        // still receiving) chunk c+1.  The body is branch-free; past-the-end loads are
+        // clamped to the last chunk instead of predicated.
+        int c = 0;
+        for (; c + 2 <= last; c += 2) {
+            load_chunk(c + 2, breg0, areg0);
+            compute(0);
+            store_chunk(1, breg1, areg1);
+            __syncthreads();
+            load_chunk(min(c + 3, last), breg1, areg1);
+            compute(1);
+            store_chunk(0, breg0, areg0);
+            __syncthreads();
+        }
+        compute(0);
+        if (c + 1 <= last) {
+            store_chunk(1, breg1, areg1);
+            __syncthreads();
+            compute(1);
+        }
     }
-    if (nchunks > 0) compute((nchunks - 1) & 1);
     store_tile<C::BM, C::BN, C::TM, C::TN, C::WTM, C::WTN>(p, tc, acc, wm, wn, lane);
 }
 
@@ -713,7 +736,8 @@ int run_plan(pl_ctx *ctx, const ConvArgs &a0, const Plan &pl, bool avec, float *
         r.splits = used;
         r.tile_offset = t1;
         r.tile_count = tail;
-        hipLaunchKernelGGL(ci.reduce, dim3((unsigned)tail), dim3(256), 0, ctx->stream, r, (const float *)ws, y);
+        hipLaunchKernelGGL(ci.reduce, dim3((unsigned)tail, (unsigned)(ci.bm / REDUCE_ROWS)), dim3(256), 0, ctx->stream, r,
+                           (const float *)ws, y);
         hipError_t le = hipGetLastError();
         if (le != hipSuccess) {
             pl_set_error("conv tile reduce: %s", hipGetErrorString(le));
@@ -964,6 +988,44 @@ int pl_conv2d_prepare_weights_f32(pl_ctx *ctx, const float *w, int Cout, int Cin
     permute_weights_kernel<<<blocks, 256, 0, ctx->stream>>>(w, out, (unsigned)total, Cin_g, kh * kw, FastDiv(Cin_g),
                                                            FastDiv(kh * kw));
     PL_LAUNCH_CHECK();
+    return PL_OK;
+}
+
+// Plans are stored by configuration NAME so a cache survives re-ordering of the table.
+int pl_tune_cache_save(pl_ctx *ctx, const char *path) {
+    PL_REQUIRE(ctx && path, PL_EINVAL, "pl_tune_cache_save: null argument");
+    FILE *f = fopen(path, "w");
+    PL_REQUIRE(f, PL_EINVAL, "pl_tune_cache_save: cannot open %s", path);
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    for (auto &kv : g_tune) {
+        if (kv.first.first != ctx) continue;
+        for (int v : kv.first.second.v) fprintf(f, "%d ", v);
+        fprintf(f, "%s %d %d %d\n", kCfgs[kv.second.cfg].name, kv.second.t1, kv.second.s2, kv.second.occ);
+    }
+    fclose(f);
+    return PL_OK;
+}
+
+int pl_tune_cache_load(pl_ctx *ctx, const char *path, int *entries) {
+    PL_REQUIRE(ctx && path, PL_EINVAL, "pl_tune_cache_load: null argument");
+    if (entries) *entries = 0;
+    FILE *f = fopen(path, "r");
+    if (!f) return PL_OK;   // no cache yet
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    for (;;) {
+        TuneKey key;
+        bool ok = true;
+        for (int &v : key.v) ok = ok && fscanf(f, "%d", &v) == 1;
+        char name[64];
+        Plan pl{-1, 0, 1, 0};
+        if (!ok || fscanf(f, "%63s %d %d %d", name, &pl.t1, &pl.s2, &pl.occ) != 4) break;
+        for (int c = 0; c < kNumCfgs; ++c)
+            if (!strcmp(kCfgs[c].name, name)) pl.cfg = c;
+        if (pl.cfg < 0 || !cfg_applies(kCfgs[pl.cfg], key.v[0], key.v[2] / (key.v[14] > 0 ? key.v[14] : 1))) continue;
+        g_tune[{ctx, key}] = pl;
+        if (entries) ++*entries;
+    }
+    fclose(f);
     return PL_OK;
 }
 

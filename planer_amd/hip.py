@@ -33,6 +33,20 @@ class Context:
         _lib.check(lib.pl_ctx_info(h, byref(dev), byref(cus), byref(hbm), name, 64))
         self.cu_count, self.hbm_bytes, self.arch = cus.value, hbm.value, name.value.decode()
         self.comm = None
+        # PLANER_HIP_TUNE_CACHE=<file>: reuse conv launch plans found by earlier runs
+        self.tune_cache = os.environ.get("PLANER_HIP_TUNE_CACHE")
+        if self.tune_cache:
+            self.load_tune_cache(self.tune_cache)
+
+    def load_tune_cache(self, path):
+        n = c_int()
+        _lib.call("pl_tune_cache_load", self.handle, path.encode(), byref(n))
+        return n.value
+
+    def save_tune_cache(self, path=None):
+        path = path or self.tune_cache
+        if path:
+            _lib.call("pl_tune_cache_save", self.handle, path.encode())
 
     def synchronize(self):
         _lib.call("pl_sync", self.handle)
