@@ -62,6 +62,10 @@ class Context:
     def set_conv_config(self, cfg=-1, split_k=0):
         _lib.call("pl_conv2d_set_config", self.handle, int(cfg), int(split_k))
 
+    def set_conv_plan(self, cfg, dp_tiles, split_k, occupancy=0):
+        """Force a full launch plan: `dp_tiles` data-parallel tiles + the rest split `split_k` ways."""
+        _lib.call("pl_conv2d_set_plan", self.handle, int(cfg), int(dp_tiles), int(split_k), int(occupancy))
+
     def close(self):
         if self.handle is not None:
             _lib.load().pl_ctx_destroy(self.handle)

@@ -97,6 +97,37 @@ def test_conv_every_tile_config_and_split_k(pa):
         ctx.set_conv_config(-1, 0)
 
 
+def test_hybrid_split_k_plans_are_deterministic(pa):
+    """Hybrid launch plans (data-parallel prefix + split-K tail with compact slabs and the tile
+    reduce): many tiles, many slices, occupancy pins, repeated launches; every run must be
+    bit-identical and match the oracle."""
+    ctx = pa.hip.context()
+    names = _cfg_names(pa)
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal((8, 64, 28, 28)).astype(np.float32)
+    k = (rng.standard_normal((128, 64, 3, 3)) * 0.05).astype(np.float32)
+    res = rng.standard_normal((8, 128, 28, 28)).astype(np.float32)
+    ref = onp.relu(np.ascontiguousarray(onp.conv2d(x, k, pads=[1, 1, 1, 1])) + res)
+    dx, dk, dres = pa.asarray(x), pa.asarray(k), pa.asarray(res)
+    dkt = pa.prepare_conv_weights(dk)
+    try:
+        for name, dp, split, occ in [("t64x64x16", 0, 4, 0), ("t64x64x16", 64, 6, 0), ("t128x64x16", 0, 9, 0),
+                                     ("64x64", 0, 3, 0), ("t64x64x32", 128, 2, 4), ("128x32", 8, 5, 2)]:
+            tap = name.startswith("t")
+            ctx.set_conv_plan(names.index(name), dp, split, occ)
+            first = None
+            for it in range(12):
+                y = pa.ConvFused(dx, dkt if tap else dk, None, None, None, dres, pads=[1, 1, 1, 1], act=1,
+                                 w_layout=int(tap)).get()
+                if first is None:
+                    first = y
+                    assert_close(y, ref, RTOL, "%s dp%d s%d" % (name, dp, split))
+                else:
+                    np.testing.assert_array_equal(y, first)
+    finally:
+        ctx.set_conv_config(-1, 0)
+
+
 def test_autotune_and_heuristic_agree(pa):
     ctx = pa.hip.context()
     lib = pa._lib.load()
