@@ -31,11 +31,19 @@
 //    slabs and applies the fused tail.
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 #include <cstdlib>
 #include <cstring>
 
 #include "common.h"
 #include "device_utils.h"
+
+#ifndef PL_SCHED
+#define PL_SCHED 0
+#endif
+#ifndef PL_ABL
+#define PL_ABL 0   // debug builds only: 1 no B gather, 2 no A loads, 3 neither, 4 no output stores, 8 no LDS stores
+#endif
 
 namespace {
 
@@ -118,6 +126,9 @@ __device__ __forceinline__ void store_tile(const ConvArgs &p, const TileCoord &t
                 const int row = tc.m0 + wm * WTM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                 if (row < p.cout_g) {
                     const size_t idx = obase + (size_t)row * p.HoWo;
+#if PL_ABL & 4
+                    if (acc[a][b][r] == 12345.678f)
+#endif
                     p.y[idx] = apply_epilogue(p.ep, acc[a][b][r], (int)tc.g * p.cout_g + row, idx);
                 }
             }
@@ -470,14 +481,22 @@ __global__ void __launch_bounds__(256) conv_tap_kernel(const ConvArgs p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int soff = ((cin0 + ps * C::KG_PER_PASS * 4 + e) * p.HW) << 2;   // scalar
+#if (PL_ABL & 3) == 1 || (PL_ABL & 3) == 3
+                tv[e] = (float)(voff + soff);
+#else
                 tv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, voff, soff, 0));
+#endif
             }
             breg[ps] = make_float4(tv[0], tv[1], tv[2], tv[3]);
         }
         const int ksoff = (ci * C::BK) << 2;                    // scalar: chunk start along K
 #pragma unroll
         for (int i = 0; i < C::A_PER_THREAD; ++i)
+#if (PL_ABL & 3) >= 2
+            areg[i] = make_float4((float)(aoff[i] + ksoff), 1.f, 2.f, 3.f);
+#else
             areg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, aoff[i], ksoff, 0));
+#endif
     };
 
     auto store_chunk = [&](int buf, const float4 (&breg)[C::B_PASSES], const float4 (&areg)[C::A_PER_THREAD]) {
@@ -509,20 +528,34 @@ __global__ void __launch_bounds__(256) conv_tap_kernel(const ConvArgs p) {
     const int a_off = (wm * C::WTM + l31) * C::LDK + 4 * lhi;
     const int b_off = (wn * C::WTN + l31) * C::LDK + 4 * lhi;
 
-    auto compute = [&](int buf) {
+    // ---- rotated software pipeline -------------------------------------------
+    // A chunk's MFMAs are split into a HEAD (k-groups 0..U-2) and a TAIL (group
+    // U-1).  Step k, right after the barrier that publishes chunk k in LDS:
+    //   1. issue ALL fragment reads of chunk k          (ds_read_b128, into set k&1)
+    //   2. run the TAIL of chunk k-1 from the other set  -> covers the LDS latency
+    //   3. ds_write chunk k+1 (its loads were issued a whole step ago) so the
+    //      writes complete under the head MFMAs, long before the barrier
+    //   4. issue the global loads of chunk k+2 (two chunks ahead), run the HEAD of chunk k
+    //   5. barrier
+    // so the matrix pipe only idles for the barrier itself.
+    constexpr int U = C::BK / 8;
+    float4 fa0[U][C::TM], fb0[U][C::TN], fa1[U][C::TM], fb1[U][C::TN];
+
+    auto read_frags = [&](int buf, float4 (&af)[U][C::TM], float4 (&bf)[U][C::TN]) {
         const float *Ab = As + buf * C::A_ELEMS + a_off;
         const float *Bb = Bs + buf * C::B_ELEMS + b_off;
-        float4 af[C::BK / 8][C::TM], bf[C::BK / 8][C::TN];
 #pragma unroll
-        for (int u = 0; u < C::BK / 8; ++u) {
+        for (int u = 0; u < U; ++u) {
 #pragma unroll
             for (int a = 0; a < C::TM; ++a) af[u][a] = *reinterpret_cast<const float4 *>(Ab + a * 32 * C::LDK + 8 * u);
 #pragma unroll
             for (int b = 0; b < C::TN; ++b) bf[u][b] = *reinterpret_cast<const float4 *>(Bb + b * 32 * C::LDK + 8 * u);
         }
-        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mma = [&](const float4 (&af)[U][C::TM], const float4 (&bf)[U][C::TN], int u0, int u1) {
 #pragma unroll
-        for (int u = 0; u < C::BK / 8; ++u)
+        for (int u = 0; u < U; ++u) {
+            if (u < u0 || u >= u1) continue;
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
@@ -533,34 +566,51 @@ __global__ void __launch_bounds__(256) conv_tap_kernel(const ConvArgs p) {
                         const float bv = s4 == 0 ? bf[u][b].x : s4 == 1 ? bf[u][b].y : s4 == 2 ? bf[u][b].z : bf[u][b].w;
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a][b], 0, 0, 0);
                     }
-        __builtin_amdgcn_sched_barrier(0);
+        }
     };
 
     if (nchunks > 0) {
         const int last = nchunks - 1;
+        // One step, parity known at compile time so every register set is statically named.
+        // Past-the-end loads/stores are clamped duplicates of the last chunk (branch-free body).
+        auto step = [&](auto parity, int k, bool with_tail) {
+            constexpr int P = decltype(parity)::value;
+            if constexpr (P == 0) {
+                read_frags(0, fa0, fb0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (with_tail) mma(fa1, fb1, U - 1, U);
+                store_chunk(1, breg1, areg1);          // early: completes under the head MFMAs
+                __builtin_amdgcn_sched_barrier(0);
+                load_chunk(min(k + 2, last), breg0, areg0);
+                mma(fa0, fb0, 0, U - 1);
+            } else {
+                read_frags(1, fa1, fb1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (with_tail) mma(fa0, fb0, U - 1, U);
+                store_chunk(0, breg0, areg0);
+                __builtin_amdgcn_sched_barrier(0);
+                load_chunk(min(k + 2, last), breg1, areg1);
+                mma(fa1, fb1, 0, U - 1);
+            }
+            __syncthreads();
+        };
+        using P0 = std::integral_constant<int, 0>;
+        using P1 = std::integral_constant<int, 1>;
         load_chunk(0, breg0, areg0);
         load_chunk(min(1, last), breg1, areg1);
         store_chunk(0, breg0, areg0);
         __syncthreads();
-        // invariant at the loop head: LDS buffer 0 holds chunk c, set 1 holds (or is
-        // still receiving) chunk c+1.  The body is branch-free; past-the-end loads are
-        // clamped to the last chunk instead of predicated.
-        int c = 0;
-        for (; c + 2 <= last; c += 2) {
-            load_chunk(c + 2, breg0, areg0);
-            compute(0);
-            store_chunk(1, breg1, areg1);
-            __syncthreads();
-            load_chunk(min(c + 3, last), breg1, areg1);
-            compute(1);
-            store_chunk(0, breg0, areg0);
-            __syncthreads();
+        step(P0{}, 0, false);
+        int k = 1;
+        for (; k + 1 <= last; k += 2) {
+            step(P1{}, k, true);
+            step(P0{}, k + 1, true);
         }
-        compute(0);
-        if (c + 1 <= last) {
-            store_chunk(1, breg1, areg1);
-            __syncthreads();
-            compute(1);
+        if (k <= last) {
+            step(P1{}, k, true);
+            mma(fa1, fb1, U - 1, U);
+        } else {
+            mma(fa0, fb0, U - 1, U);
         }
     }
     store_tile<C::BM, C::BN, C::TM, C::TN, C::WTM, C::WTN>(p, tc, acc, wm, wn, lane);
@@ -815,7 +865,7 @@ Plan tune_plan(pl_ctx *ctx, int layout, const ConvArgs &a, bool avec, float *y, 
         Plan pl;
     };
     std::vector<Cand> stage1;
-    const int splits[] = {2, 3, 4, 6, 8, 12, 16};
+    const int splits[] = {2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14, 16};
     for (int c = 0; c < kNumCfgs; ++c) {
         const CfgInfo &ci = kCfgs[c];
         if (!cfg_applies(ci, layout, a.cin_g)) continue;

@@ -184,6 +184,19 @@ def test_conv_linearity_at_resnet_layer_size(pa):
     assert_close(f(2.5 * x1 + x2), 2.5 * f(x1) + f(x2), RTOL)
 
 
+def test_maxpool_fast_path_is_bit_exact(pa):
+    """The vectorised 3x3/s2/p1 kernel (even maps, Wo % 4 == 0) vs the oracle, negatives included so
+    the zero-padding / -1e4 rule shows at the borders."""
+    rng = np.random.default_rng(4)
+    for shape in [(2, 5, 16, 16), (3, 4, 24, 8), (1, 2, 112, 112)]:
+        x = (rng.standard_normal(shape) * 3 - 1).astype(np.float32)
+        y = pa.Maxpool(pa.asarray(x), w=[3, 3], pads=[1, 1, 1, 1], strides=[2, 2]).get()
+        np.testing.assert_array_equal(y, onp.maxpool(x, (3, 3), (1, 1, 1, 1), (2, 2)))
+    x = np.full((1, 1, 8, 8), -2e4, np.float32)
+    y = pa.Maxpool(pa.asarray(x), w=[3, 3], pads=[1, 1, 1, 1], strides=[2, 2]).get()
+    np.testing.assert_array_equal(y, onp.maxpool(x, (3, 3), (1, 1, 1, 1), (2, 2)))
+
+
 def test_unsupported_inputs_fail_loudly(pa):
     x = pa.asarray(np.zeros((1, 4, 8, 8), np.float32))
     k = pa.asarray(np.zeros((4, 4, 3, 3), np.float32))
