@@ -137,10 +137,11 @@ __device__ __forceinline__ void store_tile(const ConvArgs &p, const TileCoord &t
 }
 
 // Combine the split-K slabs of the tiles [tile_offset, tile_offset+tile_count)
-// and apply the fused tail.  blockIdx.x = tile, blockIdx.y = band of
-// REDUCE_ROWS rows; thread = one column, so slab reads and NCHW writes coalesce.
+// and apply the fused tail.  blockIdx.x = tile, blockIdx.y = band of rows.
+// VEC4: a thread owns 4 neighbouring columns (float4 slab reads, float4 NCHW
+// stores; needs Ho*Wo % 4 == 0 so the 4 pixels share an image and stay aligned).
 constexpr int REDUCE_ROWS = 16;
-template <int BM, int BN>
+template <int BM, int BN, bool VEC4>
 __global__ void __launch_bounds__(256) reduce_tiles_kernel(const ConvArgs p, const float *slabs, float *y) {
     const unsigned local = blockIdx.x;
     const unsigned gt = local + (unsigned)p.tile_offset;
@@ -148,24 +149,41 @@ __global__ void __launch_bounds__(256) reduce_tiles_kernel(const ConvArgs p, con
     const unsigned t = gt - g * (unsigned)p.tiles;
     const unsigned nt = p.divMt.div(t);
     const int m0 = (int)(t - nt * (unsigned)p.mtiles) * BM, col0 = (int)nt * BN;
-    constexpr int RPP = 256 / BN;
-    const int cl = threadIdx.x % BN, r0 = blockIdx.y * REDUCE_ROWS + threadIdx.x / BN;
+    constexpr int CW = VEC4 ? 4 : 1;                 // columns per thread
+    constexpr int TPR = BN / CW;                     // threads per row
+    constexpr int RPP = 256 / TPR;                   // rows per pass
+    constexpr int ROWS = VEC4 ? (REDUCE_ROWS * 4 > BM ? BM : REDUCE_ROWS * 4) : REDUCE_ROWS;   // rows per block
+    const int cl = (threadIdx.x % TPR) * CW, r0 = blockIdx.y * ROWS + threadIdx.x / TPR;
     const int jc = col0 + cl;
-    if (jc >= p.cols) return;
+    if (jc >= p.cols) return;                        // cols % 4 == 0 in VEC4 mode: all or nothing
     unsigned n, pix;
     p.divHoWo.divmod((unsigned)jc, n, pix);
     const size_t obase = ((size_t)n * p.Cout + (size_t)g * p.cout_g) * p.HoWo + pix;
     const size_t sstride = (size_t)p.tile_count * (BM * BN);
     const float *sp = slabs + (size_t)local * (BM * BN) + cl;
 #pragma unroll
-    for (int i = 0; i < REDUCE_ROWS / RPP; ++i) {
+    for (int i = 0; i < ROWS / RPP; ++i) {
         const int rl = r0 + i * RPP;
         const int row = m0 + rl;
-        if (row < p.cout_g) {
-            float v = sp[rl * BN];
-            for (int z = 1; z < p.splits; ++z) v += sp[z * sstride + rl * BN];
+        if (rl < BM && row < p.cout_g) {
             const size_t idx = obase + (size_t)row * p.HoWo;
-            y[idx] = apply_epilogue(p.ep, v, (int)g * p.cout_g + row, idx);
+            const int c = (int)g * p.cout_g + row;
+            if (VEC4) {
+                float4 v = *reinterpret_cast<const float4 *>(sp + rl * BN);
+                for (int z = 1; z < p.splits; ++z) {
+                    const float4 w = *reinterpret_cast<const float4 *>(sp + z * sstride + rl * BN);
+                    v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+                }
+                v.x = apply_epilogue(p.ep, v.x, c, idx);
+                v.y = apply_epilogue(p.ep, v.y, c, idx + 1);
+                v.z = apply_epilogue(p.ep, v.z, c, idx + 2);
+                v.w = apply_epilogue(p.ep, v.w, c, idx + 3);
+                *reinterpret_cast<float4 *>(y + idx) = v;
+            } else {
+                float v = sp[rl * BN];
+                for (int z = 1; z < p.splits; ++z) v += sp[z * sstride + rl * BN];
+                y[idx] = apply_epilogue(p.ep, v, c, idx);
+            }
         }
     }
 }
@@ -658,15 +676,17 @@ struct CfgInfo {
     void (*vec)(const ConvArgs);
     void (*scl)(const ConvArgs);
     void (*reduce)(const ConvArgs, const float *, float *);
+    void (*reduce4)(const ConvArgs, const float *, float *);
 };
 
 #define CFG_ENTRY(T, nm)                                                                                 \
     {                                                                                                    \
         nm, 0, T::BM, T::BN, T::BK, T::LDS_BYTES, conv_igemm_kernel<T, true>, conv_igemm_kernel<T, false>, \
-            reduce_tiles_kernel<T::BM, T::BN>                                                            \
+            reduce_tiles_kernel<T::BM, T::BN, false>, reduce_tiles_kernel<T::BM, T::BN, true>            \
     }
 #define TAP_ENTRY(T, nm) \
-    { nm, 1, T::BM, T::BN, T::BK, T::LDS_BYTES, conv_tap_kernel<T>, conv_tap_kernel<T>, reduce_tiles_kernel<T::BM, T::BN> }
+    { nm, 1, T::BM, T::BN, T::BK, T::LDS_BYTES, conv_tap_kernel<T>, conv_tap_kernel<T>, \
+      reduce_tiles_kernel<T::BM, T::BN, false>, reduce_tiles_kernel<T::BM, T::BN, true> }
 
 const CfgInfo kCfgs[] = {
     CFG_ENTRY(C128x128, "128x128"), CFG_ENTRY(C64x128, "64x128"), CFG_ENTRY(C128x64, "128x64"),
@@ -786,8 +806,11 @@ int run_plan(pl_ctx *ctx, const ConvArgs &a0, const Plan &pl, bool avec, float *
         r.splits = used;
         r.tile_offset = t1;
         r.tile_count = tail;
-        hipLaunchKernelGGL(ci.reduce, dim3((unsigned)tail, (unsigned)(ci.bm / REDUCE_ROWS)), dim3(256), 0, ctx->stream, r,
-                           (const float *)ws, y);
+        const bool vec4 = a.HoWo % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15u) == 0 &&
+                          (!a.ep.res || (reinterpret_cast<uintptr_t>(a.ep.res) & 15u) == 0);
+        const int rows = vec4 ? std::min(ci.bm, REDUCE_ROWS * 4) : REDUCE_ROWS;
+        hipLaunchKernelGGL(vec4 ? ci.reduce4 : ci.reduce, dim3((unsigned)tail, (unsigned)((ci.bm + rows - 1) / rows)),
+                           dim3(256), 0, ctx->stream, r, (const float *)ws, y);
         hipError_t le = hipGetLastError();
         if (le != hipSuccess) {
             pl_set_error("conv tile reduce: %s", hipGetErrorString(le));
