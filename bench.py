@@ -79,11 +79,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=5)
     ap.add_argument("--detail", action="store_true", help="also print the per-layer table to stderr")
+    ap.add_argument("--workload", default="resnet18", choices=["resnet18", "yolov3", "conv2"],
+                    help="resnet18 = the headline (BASELINE configs[2]); yolov3 = config 5 at batch 1; "
+                         "conv2 = config 2's single Conv2d 3->64 on (8,3,224,224)")
+    ap.add_argument("--e2e", action="store_true", help="also time net(x_host): H2D + forward + D2H (PCIe-inclusive)")
     args = ap.parse_args()
 
     import planer_amd
     from planer_amd import dist
-    from planer_amd.irgen import resnet18
+    from planer_amd.irgen import resnet18, yolov3
+    from planer_amd.irgen.builder import GraphBuilder
 
     rank, world, _ = dist.env_world()
     if world != args.gpus:
@@ -94,7 +99,20 @@ def main():
     comm = dist.init(ctx)
 
     # ---- model: graph on every rank, weights from rank 0 by RCCL broadcast -------
-    g, blob = resnet18.build() if rank == 0 else (resnet18.build()[0], None)
+    if args.workload == "yolov3":
+        build, in_shape, args.batch = yolov3.build, (3, 416, 416), (args.batch if args.batch != PER_GPU_BATCH else 1)
+    elif args.workload == "conv2":
+        def build():
+            rng = np.random.default_rng(0)
+            gb = GraphBuilder(["x"])
+            gb.init("K", (rng.standard_normal((64, 3, 3, 3)) * 0.1).astype(np.float32))
+            gb.init("B", rng.standard_normal(64).astype(np.float32))
+            gb.op("conv", ["x", "K", "B"], "y", name="conv", group=1, strides=[1, 1], dilations=[1, 1], pads=[1, 1, 1, 1])
+            return gb.finish(["y"])
+        in_shape, args.batch = (3, 224, 224), (args.batch if args.batch != PER_GPU_BATCH else 8)
+    else:
+        build, in_shape = resnet18.build, (3, 224, 224)
+    g, blob = build() if rank == 0 else (build()[0], None)
     net = planer_amd.Net(ctx)
     net.load_json(g["input"], g["inits"], g["layers"], g["flow"])
     t0 = time.perf_counter()
@@ -106,23 +124,30 @@ def main():
     n = args.batch
     global_batch = n * world
     lo, hi = dist.shard_range(global_batch, world, rank)
-    xs_host = [np.random.default_rng(1 + 1000 * i + rank).standard_normal((hi - lo, 3, 224, 224)).astype(np.float32)
+    xs_host = [np.random.default_rng(1 + 1000 * i + rank).standard_normal((hi - lo,) + in_shape).astype(np.float32)
                for i in range(2)]
     xs = [planer_amd.asarray(a, ctx=ctx) for a in xs_host]
-    plan = net.compile(xs[0])                   # fuse + tune + warm the pool + capture the hipGraph
+    # fuse + tune + warm the pool + capture the hipGraph(s); "throughput": sub-batch streams free-run
+    plan = net.compile(xs[0], mode="throughput")
     ctx.save_tune_cache()                       # no-op unless PLANER_HIP_TUNE_CACHE is set
     state = {"i": 0}
 
     def step():
-        plan.inputs[0].copy_from(xs[state["i"] & 1])   # rotate two distinct resident batches
-        plan.launch()
+        if not os.environ.get("PLANER_BENCH_NOFEED"):
+            plan.feed([xs[state["i"] & 1]])        # rotate two distinct resident batches
+        plan.launch(join=False)
         state["i"] += 1
 
-    elapsed = dist.timed_steps(comm, step, ctx.synchronize, args.steps, args.warmup)
+    def sync():
+        plan.join()                            # side streams -> main stream
+        ctx.synchronize()
+
+    elapsed = dist.timed_steps(comm, step, sync, args.steps, args.warmup)
     ms_per_step = elapsed / args.steps * 1e3
     value = global_batch * args.steps / elapsed
 
     # ---- correctness guard on what was just timed (cheap: logits of 2 images) ----
+    sync()
     logits = plan.outputs[0].get() if isinstance(plan.outputs, tuple) else plan.outputs.get()
     assert np.isfinite(logits).all()
 
@@ -132,7 +157,7 @@ def main():
     # ---- roofline of the dominant kernel: HIP events around every layer of the
     #      same fused program, launched eagerly on the same stream, K steps ----------
     shapes = {k: a.shape for k, a in zip(net.inits, net.weights)}
-    shapes["x"] = xs[0].shape
+    shapes[g["input"][0]] = xs[0].shape
     net._interpret(net._program, [xs[0].copy()], shapes=shapes)
     flops = conv_flops(g, shapes)
     prog, _ = net._fuse(shapes)
@@ -158,9 +183,27 @@ def main():
         c["launches"] += 1
         if args.detail:
             print("%-14s %-10s %8.3f ms %8.2f TFLOP/s" % (name, cls, ms, f / ms / 1e9 if ms else 0), file=sys.stderr)
+    e2e = None
+    if args.e2e:
+        net(xs_host[0])
+        t0 = time.perf_counter()
+        for i in range(10):
+            net(xs_host[i & 1])
+        e2e = n * 10 / (time.perf_counter() - t0)
+    if args.workload != "resnet18":
+        tot = sum(f for f, _ in flops.values())
+        print(json.dumps({"metric": "images/sec %s fp32 forward" % args.workload, "value": round(value, 1),
+                          "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "dtype": "f32",
+                          "config": {"workload": args.workload, "per_gpu_batch": n, "fused_steps": plan.fused_steps,
+                                     "sub_batch_streams": plan.streams},
+                          "conv_tflops_whole_step": round(tot / (ms_per_step * 1e-3) / 1e12, 2),
+                          "by_class_ms": {k: round(v["ms"], 4) for k, v in sorted(classes.items())},
+                          "pcie_inclusive_images_per_sec": e2e}))
+        return
     c3 = classes["conv3x3"]
     achieved = c3["flops"] / (c3["ms"] * 1e-3) / 1e12
-    total_flops = sum(f for f, _ in flops.values()) + 2.0 * n * 512 * 1000
+    total_flops = sum(f for f, _ in flops.values()) + 2.0 * n * 512 * 1000   # + the 512->1000 dense layer
     roofline = {"bound": "mfma", "kernel": "conv_tap_kernel / conv_igemm_kernel: the 16 conv3x3 launches of one forward "
                                           "(incl. their split-K tile-reduce launches)",
                 "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -178,6 +221,8 @@ def main():
                                   "fused conv epilogues + hipGraph replay" % n,
                       "global_batch": global_batch, "per_gpu_batch": n, "parallelism": "batch-shard x%d" % world,
                       "weight_bcast_ms": round(bcast_ms, 2), "fused_steps": plan.fused_steps,
+                      "sub_batch_streams": plan.streams,
+                      "pcie_inclusive_images_per_sec": None if e2e is None else round(e2e, 1),
                       "device": ctx.arch, "cu_count": ctx.cu_count},
            "roofline": roofline}
     if world == 1 and not args.no_cpu_baseline:

@@ -73,6 +73,9 @@ int pl_event_record(pl_ctx *ctx, pl_event *ev);
 int pl_event_elapsed_ms(pl_event *start, pl_event *stop, float *ms); /* syncs on stop */
 int pl_event_destroy(pl_event *ev);
 
+/* fork/join between two contexts (streams) of one device */
+int pl_stream_wait(pl_ctx *waiter, pl_ctx *signal);
+
 /* whole-forward capture: the HIP-native replacement for interpreting the flow
  * in Python on every call (net.py:37-72).  Between begin/end every launch and
  * pool allocation on the context is recorded instead of executed. */

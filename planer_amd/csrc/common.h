@@ -72,6 +72,7 @@ struct pl_ctx {
     int conv_split_k = 0;
     bool autotune = true;
     int conv_t1 = 0, conv_occ = 0;
+    void *sync_event = nullptr;      // hipEvent_t used by pl_stream_wait
 
     // RCCL (dlopen'ed on first use)
     void *comm = nullptr;

@@ -855,7 +855,8 @@ struct TuneKey {
     bool operator<(const TuneKey &o) const { return memcmp(v, o.v, sizeof v) < 0; }
 };
 std::mutex g_tune_mu;
-std::map<std::pair<pl_ctx *, TuneKey>, Plan> g_tune;
+// keyed by DEVICE (not context): side-stream contexts of one GPU share what was tuned
+std::map<std::pair<int, TuneKey>, Plan> g_tune;
 
 float time_plan(pl_ctx *ctx, const ConvArgs &a, const Plan &pl, bool avec, float *y, hipEvent_t e0, hipEvent_t e1,
                 int reps) {
@@ -1012,7 +1013,7 @@ int conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const
     bool have = false;
     {
         std::lock_guard<std::mutex> lk(g_tune_mu);
-        auto it = g_tune.find({ctx, key});
+        auto it = g_tune.find({ctx->device, key});
         if (it != g_tune.end()) {
             plan = it->second;
             have = true;
@@ -1025,7 +1026,7 @@ int conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const
         if (tune) plan = tune_plan(ctx, layout, a, avec, y, plan);
         if (tune || !ctx->autotune) {
             std::lock_guard<std::mutex> lk(g_tune_mu);
-            g_tune[{ctx, key}] = plan;
+            g_tune[{ctx->device, key}] = plan;
         }
     }
     return run_plan(ctx, a, plan, avec, y);
@@ -1071,7 +1072,7 @@ int pl_tune_cache_save(pl_ctx *ctx, const char *path) {
     PL_REQUIRE(f, PL_EINVAL, "pl_tune_cache_save: cannot open %s", path);
     std::lock_guard<std::mutex> lk(g_tune_mu);
     for (auto &kv : g_tune) {
-        if (kv.first.first != ctx) continue;
+        if (kv.first.first != ctx->device) continue;
         for (int v : kv.first.second.v) fprintf(f, "%d ", v);
         fprintf(f, "%s %d %d %d\n", kCfgs[kv.second.cfg].name, kv.second.t1, kv.second.s2, kv.second.occ);
     }
@@ -1095,7 +1096,7 @@ int pl_tune_cache_load(pl_ctx *ctx, const char *path, int *entries) {
         for (int c = 0; c < kNumCfgs; ++c)
             if (!strcmp(kCfgs[c].name, name)) pl.cfg = c;
         if (pl.cfg < 0 || !cfg_applies(kCfgs[pl.cfg], key.v[0], key.v[2] / (key.v[14] > 0 ? key.v[14] : 1))) continue;
-        g_tune[{ctx, key}] = pl;
+        g_tune[{ctx->device, key}] = pl;
         if (entries) ++*entries;
     }
     fclose(f);

@@ -79,6 +79,7 @@ int pl_ctx_destroy(pl_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     pl_comm_destroy(ctx);
     for (auto &kv : ctx->block_size) (void)hipFree(kv.first);
+    if (ctx->sync_event) (void)hipEventDestroy((hipEvent_t)ctx->sync_event);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return PL_OK;
@@ -244,6 +245,25 @@ int pl_event_destroy(pl_event *ev) {
     if (!ev) return PL_OK;
     (void)hipEventDestroy(ev->ev);
     delete ev;
+    return PL_OK;
+}
+
+// Fork/join between the streams of two contexts on one device: everything
+// enqueued on `waiter` after this call runs after everything enqueued on
+// `signal` before it.  Lets a forward pass fan sub-batches out over side
+// streams (concurrent kernels fill CUs a lone small grid leaves idle).
+int pl_stream_wait(pl_ctx *waiter, pl_ctx *signal) {
+    PL_REQUIRE(waiter && signal, PL_EINVAL, "pl_stream_wait: null ctx");
+    if (waiter == signal) return PL_OK;
+    PL_REQUIRE(waiter->device == signal->device, PL_EINVAL, "pl_stream_wait: contexts on different devices");
+    CtxGuard g(signal);
+    if (!signal->sync_event) {
+        hipEvent_t ev;
+        PL_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        signal->sync_event = ev;
+    }
+    PL_HIP(hipEventRecord((hipEvent_t)signal->sync_event, signal->stream));
+    PL_HIP(hipStreamWaitEvent(waiter->stream, (hipEvent_t)signal->sync_event, 0));
     return PL_OK;
 }
 

@@ -51,6 +51,10 @@ class Context:
     def synchronize(self):
         _lib.call("pl_sync", self.handle)
 
+    def wait_for(self, other):
+        """Order this context's stream after everything already enqueued on `other`'s."""
+        _lib.call("pl_stream_wait", self.handle, other.handle)
+
     def pool_stats(self):
         r, u = c_size_t(), c_size_t()
         _lib.call("pl_pool_stats", self.handle, byref(r), byref(u))
@@ -189,6 +193,14 @@ class DeviceArray:
         if self.host is not None:
             v.host = self.host.reshape(shape)
         return v
+
+    def rows(self, lo, hi):
+        """a[lo:hi] along axis 0 as a view (contiguous)."""
+        n = self.shape[0]
+        if not 0 <= lo <= hi <= n:
+            raise IndexError((lo, hi))
+        step = self.nbytes // n if n else 0
+        return self._view((hi - lo,) + self.shape[1:], lo * step)
 
     def __getitem__(self, i):
         """a[i] for an integer i: the i-th slab along axis 0 (net.py:101)."""

@@ -57,10 +57,19 @@ class _Plan:
 
     def __init__(self, inputs, outputs, graph, ctx, fused_steps):
         self.inputs, self.outputs, self.graph, self.ctx = inputs, outputs, graph, ctx
-        self.fused_steps = fused_steps
+        self.fused_steps, self.ms, self.streams = fused_steps, None, "1x1"
 
-    def launch(self):
+    def feed(self, xs):
+        """Copy new inputs into the plan's static input buffers (on the plan's stream)."""
+        for s, a in zip(self.inputs, xs):
+            if a is not s:
+                s.copy_from(a)
+
+    def launch(self, join=True):
         _lib.call("pl_graph_launch", self.graph)
+
+    def join(self):
+        pass
 
     def __del__(self):
         try:
@@ -69,6 +78,51 @@ class _Plan:
                 _lib.load().pl_graph_destroy(self.graph)
         except Exception:
             pass
+
+
+class _NotSplittable(Exception):
+    """An output does not carry the batch on axis 0, so sub-batch streams cannot be used."""
+
+
+class _MultiPlan:
+    """A forward pass fanned out over several streams: sub-batch i is its own captured graph on
+    side stream i (kernels of different streams run concurrently and fill CUs that one small
+    grid leaves idle); the net's own stream forks before and joins after."""
+
+    def __init__(self, inputs, outputs, subs, ctx, fused_steps):
+        self.inputs, self.outputs, self.subs, self.ctx = inputs, outputs, subs, ctx
+        self.fused_steps, self.ms = fused_steps, None
+        self.streams = "%dx%d" % (len(subs), len(subs))
+
+    def feed(self, xs):
+        """Per-stream input copy: stream i copies ITS rows, ordered behind its own previous
+        sub-graph, so consecutive forward passes may overlap across streams without a join."""
+        n = self.inputs[0].shape[0] // len(self.subs)
+        for i, sp in enumerate(self.subs):
+            for dst, a in zip(sp.inputs, xs):
+                _lib.call("pl_d2d", sp.ctx.handle, dst.ptr, a.rows(i * n, (i + 1) * n).ptr, dst.nbytes)
+
+    def launch(self, join=True):
+        """join=True: fork from / join into the net's own stream (what Net.__call__ needs: inputs
+        written and outputs read on the main stream).  join=False: throughput mode -- the streams
+        free-run and pipeline across passes; call join() before reading outputs."""
+        if join:
+            for c in {id(sp.ctx): sp.ctx for sp in self.subs}.values():
+                c.wait_for(self.ctx)           # fork FIRST: inputs were written on the main stream
+        for sp in sorted(self.subs, key=lambda q: q.ctx is self.ctx):   # main-stream graphs last
+            sp.launch()
+        if join:
+            self.join()
+
+    def join(self):
+        """Gather every sub-batch's outputs into the full output (on its own stream, outside the
+        graphs: memcpy nodes inside the sub-graphs serialised the streams), then join."""
+        for sp, rows in zip(self.subs, self.out_rows):
+            outs = sp.outputs if isinstance(sp.outputs, tuple) else (sp.outputs,)
+            for o, d in zip(outs, rows):
+                _lib.call("pl_d2d", sp.ctx.handle, d.ptr, o.ptr, o.nbytes)
+        for c in {id(sp.ctx): sp.ctx for sp in self.subs}.values():
+            self.ctx.wait_for(c)
 
 
 class Net:
@@ -80,6 +134,9 @@ class Net:
         self.use_graph = os.environ.get("PLANER_HIP_GRAPH", "1") != "0"
         self.use_fusion = os.environ.get("PLANER_HIP_FUSE", "1") != "0"
         self.profile = os.environ.get("PLANER_HIP_PROFILE", "0") == "1"
+        # streams: how many sub-batch graphs a forward pass is fanned out to ("auto" measures 1/2/4)
+        self.streams = os.environ.get("PLANER_HIP_STREAMS", "auto")
+        self._side = []
         self.device_timer = {}       # kind -> ms of device time (profile mode)
         self.last_events = []        # [(layer name, kind, ms)] of the last profiled forward
         self._blob = None
@@ -248,26 +305,118 @@ class Net:
             out_flow.append([srcs, [name], dst])
         return [out_body[b[0]] for b in body], out_flow
 
-    def compile(self, *xs):
-        """Build (or fetch) the captured plan for these device inputs."""
-        key = tuple((a.shape, str(a.dtype)) for a in xs)
+    def compile(self, *xs, mode="latency"):
+        """Build (or fetch) the captured plan for these device inputs.  `mode` only affects how
+        the number of sub-batch streams is chosen: "latency" measures fork/join passes (what
+        __call__ does), "throughput" measures free-running back-to-back passes."""
+        key = (mode,) + tuple((a.shape, str(a.dtype)) for a in xs)
         plan = self._plans.get(key)
         if plan is not None:
             return plan
         ctx = self.ctx
-        statics = [DeviceArray(a.shape, a.dtype, ctx).copy_from(a) for a in xs]
         shapes = {k: a.shape for k, a in zip(self.input, xs)}
         shapes.update({k: w.shape for k, w in zip(self.inits, self.weights)})
-        # 1) unfused eager pass: validates the graph and records every shape.
-        #    ReLU works in place, so feed it copies, not the static inputs.
+        # unfused eager pass: validates the graph and records every shape.
+        # ReLU works in place, so feed it copies, never the caller's arrays.
         timer = dict(self.timer)
-        self._interpret(self._program, [s.copy() for s in statics], shapes=shapes)
+        self._interpret(self._program, [a.copy() for a in xs], shapes=shapes)
         prog, nfused = self._fuse(shapes, self.use_fusion)
-        # 2) fused eager pass warms the pool with exactly the blocks the capture will ask for
-        self._interpret(prog, [s.copy() for s in statics])
+        batch = xs[0].shape[0] if xs and xs[0].ndim else 0
+        # A plan is (Q, P): the batch is cut into P sub-batches, each its own captured graph,
+        # dealt round-robin onto Q streams.  Q > 1 lets two kernels overlap (one's tail and ramp
+        # under the other's body); P > Q keeps per-kernel grids small enough to interleave well.
+        splittable = batch > 0 and all(a.ndim and a.shape[0] == batch for a in xs)
+        want = str(self.streams)
+        if want == "auto":
+            cands = [(1, 1)] + [(q, p_) for q, p_ in ((2, 2), (2, 4), (3, 3), (4, 4))
+                                if splittable and batch % p_ == 0 and batch // p_ >= 4]
+        else:
+            q, _, p_ = want.partition("x")
+            q, p_ = int(q), int(p_ or q)
+            cands = [(q, p_) if splittable and p_ >= q >= 1 and batch % p_ == 0 else (1, 1)]
+        best = None
+        for Q, P in cands:
+            try:
+                cand = self._build_plan(prog, xs, Q, P, nfused)
+            except _NotSplittable:
+                continue
+            if len(cands) == 1:
+                best = cand
+                break
+            def burst(k):
+                for _ in range(k):
+                    if mode == "throughput":
+                        cand.feed(xs)
+                    cand.launch(join=mode != "throughput")
+                cand.join()
+                ctx.synchronize()
+            burst(3)
+            t0 = time.perf_counter()
+            burst(10)
+            cand.ms = (time.perf_counter() - t0) / 10 * 1e3
+            if best is None or cand.ms < best.ms:
+                best = cand
+        self.timer = timer
+        self._plans[key] = best
+        return best
+
+    def _side_context(self, i):
+        """Extra stream (context) number i of this net's device; 0 is the net's own."""
+        while len(self._side) < i:
+            self._side.append(hip.Context(self.ctx.device))
+        return self.ctx if i == 0 else self._side[i - 1]
+
+    def _build_plan(self, prog, xs, Q, S, nfused):
+        """Q streams, S sub-batch graphs (S >= Q)."""
+        if S == 1:
+            return self._capture(prog, [DeviceArray(a.shape, a.dtype, self.ctx).copy_from(a) for a in xs],
+                                 self.ctx, nfused)
+        # S sub-batches on S streams: full-size static inputs/outputs live on the net's own
+        # context; every sub-graph copies its input rows in and its output rows out itself.
+        ctx0 = self.ctx
+        full_in = [DeviceArray(a.shape, a.dtype, ctx0).copy_from(a) for a in xs]
+        ctx0.synchronize()
+        n = xs[0].shape[0] // S
+        state = {"full_out": None}
+
+        def dst_views(i, warm):
+            outs = warm if isinstance(warm, tuple) else (warm,)
+            if any(not isinstance(o, DeviceArray) or not o.ndim or o.shape[0] != n for o in outs):
+                raise _NotSplittable()
+            if state["full_out"] is None:
+                state["full_out"] = [DeviceArray((n * S,) + o.shape[1:], o.dtype, ctx0) for o in outs]
+            return [f.rows(i * n, (i + 1) * n) for f in state["full_out"]]
+
+        subs = []
+        for i in range(S):
+            c = self._side_context(i % Q)
+            # the sub-plan reads its rows of the full input in place: an alias view that belongs
+            # to the side context, so every op that consumes it runs on the side stream
+            statics = []
+            for f in full_in:
+                v = f.rows(i * n, (i + 1) * n)
+                statics.append(DeviceArray(v.shape, v.dtype, c, v.ptr, f))
+            subs.append(self._capture(prog, statics, c, nfused))
+            dst_views(i, subs[-1].outputs)
+        outs = state["full_out"]
+        was_tuple = isinstance(subs[0].outputs, tuple)
+        plan = _MultiPlan(full_in, tuple(outs) if was_tuple else outs[0], subs, ctx0, nfused)
+        plan.streams = "%dx%d" % (Q, S)
+        plan.out_rows = [[f.rows(i * n, (i + 1) * n) for f in outs] for i in range(S)]
+        return plan
+
+    def _capture(self, prog, statics, ctx, nfused, srcs=None, make_dsts=None):
+        """Warm the pool / tuner with one eager pass of `prog` on `ctx`, then capture it."""
+        def fill():
+            if srcs is not None:
+                for s_, v in zip(statics, srcs):
+                    _lib.call("pl_d2d", ctx.handle, s_.ptr, v.ptr, s_.nbytes)
+        fill()
+        warm = self._interpret(prog, [s_.copy() for s_ in statics])
+        dsts = make_dsts(warm) if make_dsts else None
+        del warm
         ctx.synchronize()
-        # 3) capture
-        #    A static input is only copied first if a step could overwrite it in place.
+        # A static input is only copied first if a step could overwrite it in place.
         kinds = {b[0]: b[1] for b in prog_body(prog)}
         inplace = set()
         for src, names, dst in prog.flow:
@@ -275,13 +424,17 @@ class Net:
                 inplace.update(_as_list(src))
         _lib.call("pl_capture_begin", ctx.handle)
         try:
+            fill()
             work = []
-            for k, s in zip(self.input, statics):
+            for k, s_ in zip(self.input, statics):
                 if k in inplace:
-                    s = DeviceArray(s.shape, s.dtype, ctx).copy_from(s)
-                work.append(s)
+                    s_ = DeviceArray(s_.shape, s_.dtype, ctx).copy_from(s_)
+                work.append(s_)
             out = self._interpret(prog, work)
             del work
+            if dsts is not None:
+                for o, d in zip(out if isinstance(out, tuple) else (out,), dsts):
+                    _lib.call("pl_d2d", ctx.handle, d.ptr, o.ptr, o.nbytes)
         except Exception:
             g = _lib.c_void_p()
             _lib.load().pl_capture_end(ctx.handle, _lib.byref(g))
@@ -290,14 +443,11 @@ class Net:
             raise
         g = _lib.c_void_p()
         _lib.call("pl_capture_end", ctx.handle, _lib.byref(g))
-        self.timer = timer
-        plan = _Plan(statics, out, g, ctx, nfused)
-        self._plans[key] = plan
-        return plan
+        return _Plan(statics, out, g, ctx, nfused)
 
     def _replay(self, xs):
         plan = self.compile(*xs)
-        for s, a in zip(plan.inputs, xs):
+        for s, a in zip(plan.inputs, xs):          # on the main stream; launch() forks behind it
             if a is not s:
                 s.copy_from(a)
         plan.launch()

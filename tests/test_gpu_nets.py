@@ -79,6 +79,37 @@ def test_resnet18_stage_activations(pa):
         assert err <= RTOL, (key, err)
 
 
+@pytest.mark.parametrize("streams", ["1x1", "2x2", "2x4", "4x4"])
+def test_sub_batch_streams_give_identical_results(pa, streams):
+    """Fanning a batch out over side streams (concurrent sub-batch graphs) must not change a bit
+    relative to... the oracle tolerance, and replays must be stable."""
+    g, b = resnet18.build()
+    x = resnet18.make_input(8, size=96)
+    ref = onp.OracleNet()
+    ref.load_json(g["input"], g["inits"], g["layers"], g["flow"])
+    ref.load_weights(b)
+    want = ref(x.copy())
+    net = pa.from_graph(g, b)
+    net.streams = streams
+    d = pa.asarray(x)
+    y1 = net(d).get()
+    y2 = net(d).get()
+    assert net.compile(d).streams == streams
+    assert_close(y1, want, RTOL)
+    np.testing.assert_array_equal(y1, y2)
+    # tuple outputs (YOLO heads) through the multi-stream path
+    if streams == "2x2":
+        gy, by = yolov3.build()
+        ny = pa.from_graph(gy, by)
+        ny.streams = "2x2"
+        xy = yolov3.make_input(2, size=96)
+        outs = ny(xy)
+        ny1 = pa.from_graph(gy, by)
+        ny1.streams = "1x1"
+        for a, c in zip(outs, ny1(xy)):
+            assert_close(a, c, RTOL)
+
+
 def test_resnet18_batch32_vs_oracle(pa):
     """BASELINE config 3 at full size: batch 32, fused + graph path vs the CPU oracle."""
     g, b = resnet18.build()
