@@ -113,6 +113,10 @@ int pl_conv2d_fused_f32(pl_ctx *ctx, const float *x, int N, int Cin, int H,
  * 1x1 filters are identical in both layouts. */
 int pl_conv2d_prepare_weights_f32(pl_ctx *ctx, const float *w, int Cout, int Cin_g,
                                   int kh, int kw, float *out);
+/* w_layout 3: Winograd F(2x2,3x3) filters U[16][Cout][Cin] (16*Cout*Cin floats) for 3x3 /
+ * stride 1 / pad 1 / group 1 convs with Cin % 16 == 0: input transform + 16 GEMMs (one grouped
+ * 1x1 conv on the MFMA kernel) + output transform with the fused tail. */
+int pl_conv2d_prepare_winograd_f32(pl_ctx *ctx, const float *w, int Cout, int Cin, float *out);
 /* First call for a new conv shape times every applicable tile configuration
  * and remembers the fastest (on by default; PLANER_HIP_AUTOTUNE=0 or 0 here
  * selects the static heuristic). Never runs during graph capture. */

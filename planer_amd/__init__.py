@@ -14,7 +14,7 @@ from . import hip
 from .hip import DeviceArray
 from .io import from_graph, read_net
 from .layer import *  # noqa: F401,F403  (Conv2d, Dense, ..., layer_map, wrap)
-from .layer import layer_map, prepare_conv_weights, wrap
+from .layer import layer_map, prepare_conv_weights, prepare_winograd_weights, wrap
 from .net import Net
 
 # compatible with onnxruntime, as in the reference (__init__.py:7)

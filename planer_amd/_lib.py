@@ -50,6 +50,7 @@ SIGNATURES = {
     "pl_conv2d_fused_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P] + [_I] * 9
                            + [_P, _P, _P, _I, c_double, _I],
     "pl_conv2d_prepare_weights_f32": [_P, _P, _I, _I, _I, _I, _P],
+    "pl_conv2d_prepare_winograd_f32": [_P, _P, _I, _I, _P],
     "pl_set_autotune": [_P, _I],
     "pl_tune_cache_save": [_P, c_char_p],
     "pl_tune_cache_load": [_P, c_char_p, POINTER(c_int)],

@@ -858,6 +858,11 @@ std::mutex g_tune_mu;
 // keyed by DEVICE (not context): side-stream contexts of one GPU share what was tuned
 std::map<std::pair<int, TuneKey>, Plan> g_tune;
 
+int max_split_env() {
+    const char *ms_env = getenv("PLANER_CONV_MAX_SPLIT");
+    return ms_env ? atoi(ms_env) : 1 << 20;
+}
+
 float time_plan(pl_ctx *ctx, const ConvArgs &a, const Plan &pl, bool avec, float *y, hipEvent_t e0, hipEvent_t e1,
                 int reps) {
     float best = 1e30f;
@@ -898,7 +903,10 @@ Plan tune_plan(pl_ctx *ctx, int layout, const ConvArgs &a, bool avec, float *y, 
         Plan dp{c, T, 1, 0};
         stage1.push_back({time_plan(ctx, a, dp, avec, y, e0, e1, 2), dp});
         const int chunks = (a.K + ci.bk - 1) / ci.bk;
+        const char *ms_env = getenv("PLANER_CONV_MAX_SPLIT");     // experiments: cap split-K
+        const int max_split = ms_env ? atoi(ms_env) : 1 << 20;
         for (int s : splits) {
+            if (s > max_split) break;
             if (chunks / s < 3 || (double)T * s > 8.0 * cus * 4 || T > 6 * cus) break;
             Plan sk{c, 0, s, 0};
             stage1.push_back({time_plan(ctx, a, sk, avec, y, e0, e1, 2), sk});
@@ -935,6 +943,7 @@ Plan tune_plan(pl_ctx *ctx, int layout, const ConvArgs &a, bool avec, float *y, 
                 continue;
             }
             for (int s : splits) {
+                if (s > max_split_env()) break;
                 if (chunks / s < 2) break;
                 if ((double)tail * s < 0.4 * cus && s < 16) continue;          // tail would leave CUs idle
                 if ((double)tail * s > 6.0 * cus) break;
@@ -960,6 +969,10 @@ Plan tune_plan(pl_ctx *ctx, int layout, const ConvArgs &a, bool avec, float *y, 
     return best.pl;
 }
 
+int winograd_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const float *U, int Cout,
+                    const float *bias, float *y, const float *scale, const float *shift, const float *res, int act,
+                    double alpha);
+
 int conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const float *w, int Cout, int kh, int kw,
                 const float *bias, float *y, int sh, int sw, int dh, int dw, int pt, int pl, int pb, int pr,
                 int group, const float *scale, const float *shift, const float *res, int act, double alpha,
@@ -971,7 +984,14 @@ int conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const
     PL_REQUIRE(pt == pb && pl == pr, PL_EUNSUPPORTED, "asymmetric pads are undefined in the reference (util.py:8)");
     PL_REQUIRE(Cin % group == 0 && Cout % group == 0, PL_EUNSUPPORTED, "group must divide Cin and Cout");
     PL_REQUIRE(act >= 0 && act <= 2, PL_EINVAL, "conv2d: bad activation code");
-    PL_REQUIRE(layout == 0 || layout == 1, PL_EINVAL, "conv2d: bad weight layout");
+    PL_REQUIRE(layout == 0 || layout == 1 || layout == 3, PL_EINVAL, "conv2d: bad weight layout");
+    if (layout == 3) {
+        PL_REQUIRE(kh == 3 && kw == 3 && sh == 1 && sw == 1 && dh == 1 && dw == 1 && pt == 1 && pl == 1 && pb == 1 &&
+                       pr == 1 && group == 1, PL_EINVAL, "winograd filters serve 3x3 / stride 1 / pad 1 / group 1 only");
+        if (N == 0) return PL_OK;
+        CtxGuard guard(ctx);
+        return winograd_launch(ctx, x, N, Cin, H, W, w, Cout, bias, y, scale, shift, res, act, alpha);
+    }
     const int Ho = (H + pt + pb - (kh - 1) * dh - 1 + sh) / sh;  // util.py:25
     const int Wo = (W + pl + pr - (kw - 1) * dw - 1 + sw) / sw;  // util.py:26
     PL_REQUIRE(Ho > 0 && Wo > 0, PL_EINVAL, "conv2d: empty output (%d x %d)", Ho, Wo);
@@ -1032,6 +1052,170 @@ int conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const
     return run_plan(ctx, a, plan, avec, y);
 }
 
+// =============================================================================
+// Winograd F(2x2,3x3) for 3x3 / stride 1 / pad 1 / group 1 convolutions.
+// Y = A^T [ (G g G^T) .* (B^T d B) ] A  turns each 2x2 output tile into 16
+// element-wise products instead of 36 MACs (2.25x fewer multiplies); summed
+// over input channels the 16 "frequencies" are 16 independent GEMMs
+//   M[f] (Cout x T) = U[f] (Cout x Cin) . V[f] (Cin x T),   T = N*ceil(Ho/2)*ceil(Wo/2)
+// which run as ONE grouped 1x1 convolution (group = 16) on the MFMA kernel above.
+// The filter transform U is made once per model; the input transform writes
+// V[f][cin][tile] and the output transform reads M[f][cout][tile], applies the
+// fused tail and writes NCHW.  The transforms move 4x the activation bytes, so
+// this wins where activations are small next to the arithmetic (14x14, 7x7
+// maps); the plan compiler times it against the direct kernel per conv.
+// fp32 error of F(2,3) is a few 1e-7 relative (no large transform constants).
+// =============================================================================
+struct WinoArgs {
+    int N, C, H, W, Cout, Ho, Wo, th, tw, T;  // th,tw = tiles per image; T = N*th*tw
+    FastDiv divT, divTw, divTh;
+    Epilogue ep;
+};
+
+// U[f][co][c] = (G g G^T)[f],  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+__global__ void __launch_bounds__(256) wino_filter_kernel(const float *w, float *U, unsigned total) {
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;   // (co, c) pair
+    if (i >= total) return;
+    const float *g = w + (size_t)i * 9;
+    float t[4][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float g0 = g[j], g1 = g[3 + j], g2 = g[6 + j];
+        t[0][j] = g0;
+        t[1][j] = 0.5f * (g0 + g1 + g2);
+        t[2][j] = 0.5f * (g0 - g1 + g2);
+        t[3][j] = g2;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float a = t[r][0], b = t[r][1], c = t[r][2];
+        U[(size_t)(r * 4 + 0) * total + i] = a;
+        U[(size_t)(r * 4 + 1) * total + i] = 0.5f * (a + b + c);
+        U[(size_t)(r * 4 + 2) * total + i] = 0.5f * (a - b + c);
+        U[(size_t)(r * 4 + 3) * total + i] = c;
+    }
+}
+
+// V[f][c][t] = (B^T d B)[f],  B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]
+__global__ void __launch_bounds__(256) wino_input_kernel(const float *x, float *V, const WinoArgs p, unsigned total) {
+    const unsigned stride = gridDim.x * 256;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        unsigned c, t, n, r, ty, tx;
+        p.divT.divmod(i, c, t);               // i = c*T + t : consecutive lanes = consecutive tiles
+        p.divTw.divmod(t, r, tx);
+        p.divTh.divmod(r, n, ty);
+        const int h0 = (int)ty * 2 - 1, w0 = (int)tx * 2 - 1;
+        const float *xp = x + ((size_t)n * p.C + c) * p.H * p.W;
+        float d[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int hi = h0 + a;
+            const bool hok = (unsigned)hi < (unsigned)p.H;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int wi = w0 + b;
+                d[a][b] = (hok && (unsigned)wi < (unsigned)p.W) ? xp[(size_t)hi * p.W + wi] : 0.f;
+            }
+        }
+        float m[4][4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            m[0][b] = d[0][b] - d[2][b];
+            m[1][b] = d[1][b] + d[2][b];
+            m[2][b] = d[2][b] - d[1][b];
+            m[3][b] = d[1][b] - d[3][b];
+        }
+        const size_t plane = (size_t)p.C * p.T;
+        float *vp = V + (size_t)c * p.T + t;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            vp[(size_t)(a * 4 + 0) * plane] = m[a][0] - m[a][2];
+            vp[(size_t)(a * 4 + 1) * plane] = m[a][1] + m[a][2];
+            vp[(size_t)(a * 4 + 2) * plane] = m[a][2] - m[a][1];
+            vp[(size_t)(a * 4 + 3) * plane] = m[a][1] - m[a][3];
+        }
+    }
+}
+
+// y = epilogue(A^T m A),  A^T = [[1,1,1,0],[0,1,-1,-1]]
+__global__ void __launch_bounds__(256) wino_output_kernel(const float *M, float *y, const WinoArgs p, unsigned total) {
+    const unsigned stride = gridDim.x * 256;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        unsigned co, t, n, r, ty, tx;
+        p.divT.divmod(i, co, t);              // i = co*T + t
+        p.divTw.divmod(t, r, tx);
+        p.divTh.divmod(r, n, ty);
+        const size_t plane = (size_t)p.Cout * p.T;
+        const float *mp = M + (size_t)co * p.T + t;
+        float m[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) m[a][b] = mp[(size_t)(a * 4 + b) * plane];
+        float s[2][4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            s[0][b] = m[0][b] + m[1][b] + m[2][b];
+            s[1][b] = m[1][b] - m[2][b] - m[3][b];
+        }
+        const int ho = (int)ty * 2, wo = (int)tx * 2;
+        const size_t obase = (((size_t)n * p.Cout + co) * p.Ho + ho) * p.Wo + wo;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            if (ho + a >= p.Ho) continue;
+            const float y0 = s[a][0] + s[a][1] + s[a][2];
+            const float y1 = s[a][1] - s[a][2] - s[a][3];
+            const size_t idx = obase + (size_t)a * p.Wo;
+            y[idx] = apply_epilogue(p.ep, y0, (int)co, idx);
+            if (wo + 1 < p.Wo) y[idx + 1] = apply_epilogue(p.ep, y1, (int)co, idx + 1);
+        }
+    }
+}
+
+int conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const float *w, int Cout, int kh, int kw,
+                const float *bias, float *y, int sh, int sw, int dh, int dw, int pt, int pl, int pb, int pr,
+                int group, const float *scale, const float *shift, const float *res, int act, double alpha,
+                int layout);
+
+int winograd_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const float *U, int Cout,
+                    const float *bias, float *y, const float *scale, const float *shift, const float *res, int act,
+                    double alpha) {
+    PL_REQUIRE(Cin % 16 == 0, PL_EINVAL, "winograd path needs Cin %% 16 == 0");
+    WinoArgs p;
+    p.N = N; p.C = Cin; p.H = H; p.W = W; p.Cout = Cout; p.Ho = H; p.Wo = W;
+    p.th = (H + 1) / 2; p.tw = (W + 1) / 2; p.T = N * p.th * p.tw;
+    const size_t vin = (size_t)16 * Cin * p.T, vout = (size_t)16 * Cout * p.T;
+    PL_REQUIRE(vin < (1ull << 29) && vout < (1ull << 31) && (size_t)Cin * p.T < (1ull << 32) &&
+                   (size_t)Cout * p.T < (1ull << 32), PL_EUNSUPPORTED, "winograd: tensor too large");
+    p.divT = FastDiv(p.T); p.divTw = FastDiv(p.tw); p.divTh = FastDiv(p.th);
+    p.ep = Epilogue{bias, scale, shift, res, act, (float)alpha, (float)(1.0 - alpha)};
+    float *V = nullptr, *M = nullptr;
+    int rc = pl_alloc(ctx, vin * sizeof(float), (void **)&V);
+    if (rc != PL_OK) return rc;
+    rc = pl_alloc(ctx, vout * sizeof(float), (void **)&M);
+    if (rc != PL_OK) {
+        pl_free(ctx, V);
+        return rc;
+    }
+    const unsigned cap = (unsigned)(ctx->cu_count > 0 ? ctx->cu_count : 256) * 8;
+    const unsigned tin = (unsigned)((size_t)Cin * p.T), tout = (unsigned)((size_t)Cout * p.T);
+    wino_input_kernel<<<std::min(cap, (tin + 255) / 256), 256, 0, ctx->stream>>>(x, V, p, tin);
+    // 16 GEMMs as one grouped 1x1 conv: input (1, 16*Cin, 1, T), filters (16*Cout, Cin, 1, 1), group 16
+    rc = conv_launch(ctx, V, 1, 16 * Cin, 1, p.T, U, 16 * Cout, 1, 1, nullptr, M, 1, 1, 1, 1, 0, 0, 0, 0, 16, nullptr,
+                     nullptr, nullptr, PL_ACT_NONE, 0.0, 1);
+    if (rc == PL_OK) {
+        wino_output_kernel<<<std::min(cap, (tout + 255) / 256), 256, 0, ctx->stream>>>(M, y, p, tout);
+        hipError_t le = hipGetLastError();
+        if (le != hipSuccess) {
+            pl_set_error("winograd transform launch: %s", hipGetErrorString(le));
+            rc = PL_EHIP;
+        }
+    }
+    pl_free(ctx, M);
+    pl_free(ctx, V);
+    return rc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1066,6 +1250,17 @@ int pl_conv2d_prepare_weights_f32(pl_ctx *ctx, const float *w, int Cout, int Cin
 }
 
 // Plans are stored by configuration NAME so a cache survives re-ordering of the table.
+int pl_conv2d_prepare_winograd_f32(pl_ctx *ctx, const float *w, int Cout, int Cin, float *out) {
+    PL_REQUIRE(ctx && w && out, PL_EINVAL, "pl_conv2d_prepare_winograd_f32: null pointer");
+    PL_REQUIRE(Cout > 0 && Cin > 0 && Cin % 16 == 0, PL_EINVAL, "winograd filters need Cin %% 16 == 0");
+    const size_t pairs = (size_t)Cout * Cin;
+    PL_REQUIRE(pairs * 16 < (1ull << 29), PL_EUNSUPPORTED, "filter too large");
+    CtxGuard g(ctx);
+    wino_filter_kernel<<<(unsigned)((pairs + 255) / 256), 256, 0, ctx->stream>>>(w, out, (unsigned)pairs);
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
+
 int pl_tune_cache_save(pl_ctx *ctx, const char *path) {
     PL_REQUIRE(ctx && path, PL_EINVAL, "pl_tune_cache_save: null argument");
     FILE *f = fopen(path, "w");

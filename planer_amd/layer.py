@@ -88,12 +88,33 @@ def prepare_conv_weights(K):
     return out
 
 
+def winograd_eligible(k_shape, group=1, strides=(1, 1), dilations=(1, 1), pads=(0, 0, 0, 0)):
+    """3x3 / stride 1 / pad 1 / no dilation / no groups, Cin % 16 == 0."""
+    cout, cin_g, kh, kw = k_shape
+    return (kh == 3 and kw == 3 and group == 1 and cin_g % 16 == 0 and list(strides) == [1, 1]
+            and list(dilations) == [1, 1] and list(pads) == [1, 1, 1, 1])
+
+
+def prepare_winograd_weights(K):
+    """OIHW 3x3 filters -> Winograd F(2x2,3x3) domain U[16][Cout][Cin] (w_layout=3).  The
+    returned array keeps the logical OIHW shape; its allocation holds 16*Cout*Cin floats."""
+    _f32(K)
+    cout, cin, kh, kw = K.shape
+    if (kh, kw) != (3, 3) or cin % 16:
+        raise ValueError("winograd filters need 3x3 kernels and Cin % 16 == 0")
+    out = empty((16 * cout * cin,), ctx=K.ctx)
+    _lib.call("pl_conv2d_prepare_winograd_f32", K.ctx.handle, K.ptr, cout, cin, out.ptr)
+    out.shape = K.shape
+    return out
+
+
 def ConvFused(x, K, B=None, scale=None, shift=None, res=None, group=1, strides=(1, 1),
               dilations=(1, 1), pads=(0, 0, 0, 0), act=ACT_NONE, alpha=0.0, w_layout=0):
     """Conv2d with BatchNorm / Add / (Leaky)ReLU folded into its epilogue:
     act((conv(x,K)+B)*scale + shift + res).  Emitted by Net's plan compiler for
     the chains conv->batchnorm->[add]->[relu|leakyrelu]; not a reference op.
-    w_layout=1: K holds tap-major bytes from prepare_conv_weights()."""
+    w_layout=1: K holds tap-major bytes from prepare_conv_weights();
+    w_layout=3: K holds Winograd-domain filters from prepare_winograd_weights()."""
     _f32(x, K, B, scale, shift, res)
     n, cin, h, w = x.shape
     cout, cin_g, kh, kw = K.shape

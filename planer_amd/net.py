@@ -143,7 +143,8 @@ class Net:
         self._slots = []             # (offset, nbytes) per weight inside the blob
         self._program = None
         self._plans = {}
-        self._extra = {}             # derived constant tensors (tap-major filters)
+        self._extra = {}             # derived constant tensors (tap-major / Winograd filters)
+        self._algo = {}              # conv shape signature -> chosen w_layout
 
     # ---- loading ----------------------------------------------------------------
     def load_json(self, inputs, inits, body, flow, debug=False):
@@ -276,16 +277,18 @@ class Net:
         else:
             body, flow, nfused = [list(b) for b in self.layer], [list(f) for f in self.flow], 0
         if os.environ.get("PLANER_HIP_TAPMAJOR", "1") != "0":
-            body, flow = self._prepare_filters(body, flow)
+            body, flow = self._prepare_filters(body, flow, shapes)
         return _Program(body, flow), nfused
 
-    def _prepare_filters(self, body, flow):
-        """Give every eligible conv a tap-major copy of its (constant) filter."""
-        from .layer import prepare_conv_weights
+    def _prepare_filters(self, body, flow, shapes):
+        """Give every eligible conv a prepared copy of its (constant) filter: tap-major for the
+        fast implicit-GEMM kernel, or Winograd-domain where that measures faster for this shape."""
+        from .layer import prepare_conv_weights, prepare_winograd_weights, winograd_eligible, ConvFused
         wmap = dict(zip(self.inits, self.weights))
         kinds = {b[0]: b for b in body}
         out_body = {b[0]: list(b) for b in body}
         out_flow = []
+        use_wino = os.environ.get("PLANER_HIP_WINOGRAD", "1") != "0"
         for src, names, dst in flow:
             name = names[0] if isinstance(names, list) else names
             entry = kinds[name]
@@ -293,17 +296,54 @@ class Net:
             if entry[1] in ("conv", "conv_fused") and len(srcs) >= 2 and srcs[1] in wmap:
                 K = wmap[srcs[1]]
                 if K.ndim == 4 and K.dtype == numpy.float32 and K.shape[1] % 16 == 0:
-                    key = srcs[1] + "@tap"
+                    para = {k: v for k, v in entry[2].items() if k in ("group", "strides", "dilations", "pads")}
+                    lay = 1
+                    if use_wino and winograd_eligible(K.shape, **para) and shapes.get(srcs[0]) is not None:
+                        lay = self._pick_conv_algo(ConvFused, K, srcs, entry[2], shapes, wmap)
+                    key = srcs[1] + ("@tap" if lay == 1 else "@wino")
                     if key not in self._extra:
-                        self._extra[key] = prepare_conv_weights(K)
+                        self._extra[key] = prepare_conv_weights(K) if lay == 1 else prepare_winograd_weights(K)
                     srcs[1] = key
-                    if entry[1] == "conv":            # plain conv: route through the fused entry point
-                        srcs = (srcs + ["None"] * 6)[:6] if len(srcs) < 6 else srcs
-                        out_body[name] = [name, "conv_fused", dict(entry[2], w_layout=1)]
-                    else:
-                        out_body[name] = [name, "conv_fused", dict(entry[2], w_layout=1)]
+                    out_body[name] = [name, "conv_fused", dict(entry[2], w_layout=lay)]
             out_flow.append([srcs, [name], dst])
         return [out_body[b[0]] for b in body], out_flow
+
+    def _pick_conv_algo(self, ConvFused, K, srcs, para, shapes, wmap):
+        """Time the direct (tap-major implicit GEMM) and the Winograd pipeline for this conv's
+        real shape and epilogue; -> w_layout 1 or 3.  Cached per shape signature."""
+        from .layer import prepare_conv_weights, prepare_winograd_weights
+        xs = tuple(shapes[srcs[0]])
+        has = [i < len(srcs) and srcs[i] != "None" for i in range(2, 6)]       # B, scale, shift, res
+        sig = (xs, tuple(K.shape), tuple(has), para.get("act", 0))
+        if sig in self._algo:
+            return self._algo[sig]
+        ctx = self.ctx
+        x = hip.zeros(xs, numpy.float32, ctx)
+        cout = K.shape[0]
+        chan = hip.zeros((1, cout, 1, 1), numpy.float32, ctx)
+        out_shape = (xs[0], cout, xs[2], xs[3])
+        res = hip.zeros(out_shape, numpy.float32, ctx) if has[3] else None
+        args = [hip.zeros((cout,), numpy.float32, ctx) if has[0] else None, chan if has[1] else None,
+                chan if has[2] else None, res]
+        kw = {k: v for k, v in para.items() if k != "w_layout"}
+        best, best_ms = 1, None
+        for lay, prep in ((1, prepare_conv_weights), (3, prepare_winograd_weights)):
+            try:
+                Kp = prep(K)
+                run = lambda: ConvFused(x, Kp, *args, w_layout=lay, **kw)
+                for _ in range(3):
+                    run()                              # first call autotunes the MFMA plan(s)
+                e0 = hip.Event(ctx).record()
+                for _ in range(8):
+                    run()
+                e1 = hip.Event(ctx).record()
+                ms = e0.elapsed_ms(e1) / 8
+            except (NotImplementedError, ValueError, MemoryError):
+                continue
+            if best_ms is None or ms < best_ms:
+                best, best_ms = lay, ms
+        self._algo[sig] = best
+        return best
 
     def compile(self, *xs, mode="latency"):
         """Build (or fetch) the captured plan for these device inputs.  `mode` only affects how

@@ -128,6 +128,30 @@ def test_hybrid_split_k_plans_are_deterministic(pa):
         ctx.set_conv_config(-1, 0)
 
 
+def test_winograd_path_matches_direct_conv(pa):
+    """Winograd F(2x2,3x3) pipeline (input transform, 16 grouped GEMMs on the MFMA kernel, output
+    transform + fused tail) vs the oracle, odd and even maps, with and without the epilogue."""
+    rng = np.random.default_rng(17)
+    for (n, cin, h, w, cout) in [(2, 16, 7, 7, 24), (3, 32, 14, 14, 40), (1, 64, 9, 13, 64), (2, 48, 28, 28, 32)]:
+        x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+        k = (rng.standard_normal((cout, cin, 3, 3)) * 0.1).astype(np.float32)
+        b = rng.standard_normal(cout).astype(np.float32)
+        sc = rng.uniform(0.5, 1.5, (1, cout, 1, 1)).astype(np.float32)
+        sh = rng.standard_normal((1, cout, 1, 1)).astype(np.float32)
+        res = rng.standard_normal((n, cout, h, w)).astype(np.float32)
+        dx = pa.asarray(x)
+        U = pa.prepare_winograd_weights(pa.asarray(k))
+        y = pa.ConvFused(dx, U, pa.asarray(b), pads=[1, 1, 1, 1], w_layout=3).get()
+        ref = np.ascontiguousarray(onp.conv2d(x, k, b, pads=[1, 1, 1, 1]))
+        assert_close(y, ref, RTOL, "winograd %s" % ((n, cin, h, w, cout),))
+        y = pa.ConvFused(dx, U, None, pa.asarray(sc), pa.asarray(sh), pa.asarray(res), pads=[1, 1, 1, 1], act=1,
+                         w_layout=3).get()
+        ref = onp.relu(onp.batchnorm(np.ascontiguousarray(onp.conv2d(x, k, pads=[1, 1, 1, 1])), sc, sh) + res)
+        assert_close(y, ref, RTOL, "winograd fused")
+    with pytest.raises(ValueError):
+        pa.ConvFused(dx, U, pads=[0, 0, 0, 0], w_layout=3)
+
+
 def test_autotune_and_heuristic_agree(pa):
     ctx = pa.hip.context()
     lib = pa._lib.load()
