@@ -167,6 +167,22 @@ int pl_copy2d_f32(pl_ctx *ctx, float *dst, size_t dst_pitch, const float *src,
                   size_t src_pitch, size_t width, size_t rows);
 /* layer.GlobalAveragePool (layer.py:77-78): y[r] = mean(x[r, 0:inner]) */
 int pl_gap_f32(pl_ctx *ctx, const float *x, float *y, int rows, int inner);
+/* ---- second-wave operators ---------------------------------- */
+/* Exp/Log/Tanh/Sqrt/Reciprocal/HardSigmoid/Clip (layer.py:53,66-69,174-186,247-251).
+ * op: 0 exp, 1 log, 2 tanh, 3 sqrt, 4 reciprocal, 5 hardsigmoid (p0=alpha,p1=beta),
+ * 6 clip (p0=min,p1=max).  y may alias x (Clip works in place in the reference). */
+int pl_unary_f32(pl_ctx *ctx, const float *x, float *y, size_t n, int op, double p0, double p1);
+/* Add/Sub/Mul/Div/Pow (layer.py:93-111) on a result viewed as (outer,C,inner).
+ * op: 0 add, 1 sub, 2 mul, 3 div, 4 pow.  a_mode/b_mode: 0 full-size operand,
+ * 1 one value per channel (C), 2 a single value. */
+int pl_binary_f32(pl_ctx *ctx, const float *a, const float *b, float *y, int outer, int C,
+                  int inner, int op, int a_mode, int b_mode);
+/* Softmax / LogSoftmax over the last axis (layer.py:141-153) */
+int pl_softmax_f32(pl_ctx *ctx, const float *x, float *y, int rows, int cols, int log_softmax);
+/* ReduceSum/Mean/Max/Min over the trailing `cols` elements (layer.py:113-123): op 0..3 */
+int pl_reduce_f32(pl_ctx *ctx, const float *x, float *y, int rows, int cols, int op);
+/* Transpose (layer.py:194): y = x.transpose(perm), up to 6 axes */
+int pl_transpose_f32(pl_ctx *ctx, const float *x, float *y, int ndim, const int *shape, const int *perm);
 /* split-K combine + epilogue (internal to conv, exported for tests) */
 int pl_splitk_reduce_f32(pl_ctx *ctx, const float *ws, int splits, float *y,
                          int N, int C, int inner, const float *bias,

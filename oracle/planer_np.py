@@ -219,7 +219,100 @@ def ret(*x):
     return x
 
 
-OPS = {"conv": conv2d, "dense": dense, "matmul": matmul,
+# --------------------------------------------------------------------------
+# second-wave operators
+# --------------------------------------------------------------------------
+def sub(a, b):
+    """layer.Sub (layer.py:97-99)"""
+    return a - b
+
+
+def mul(a, b):
+    """layer.Mul (layer.py:101-103)"""
+    return a * b
+
+
+def div(a, b):
+    """layer.Div (layer.py:105-107)"""
+    return a / b
+
+
+def power(x, p):
+    """layer.Pow (layer.py:109-111)"""
+    return np.power(x, p)
+
+
+def hardsigmoid(x, alpha=0.2, beta=0.5):
+    """layer.HardSigmoid (layer.py:66-69)"""
+    y = x * alpha
+    y += beta
+    y = np.minimum(y, 1, out=y)
+    return np.maximum(y, 0, out=y)
+
+
+def clip(x, min=0, max=1):
+    """layer.Clip (layer.py:247-251), numpy branch: in place, returns x."""
+    x = np.minimum(x, max, out=x)
+    return np.maximum(x, min, out=x)
+
+
+def softmax(x, axis=-1):
+    """layer.Softmax (layer.py:141-146)"""
+    y = x - np.max(x, axis=axis, keepdims=True)
+    s = np.sum(np.exp(y), axis=axis, keepdims=True)
+    y -= np.log(s, out=s)
+    return np.exp(y, out=y)
+
+
+def logsoftmax(x, axis=-1):
+    """layer.LogSoftmax (layer.py:148-153)"""
+    y = x - np.max(x, axis=axis, keepdims=True)
+    s = np.sum(np.exp(y), axis=axis, keepdims=True)
+    y -= np.log(s, out=s)
+    return y
+
+
+def _reducer(fn):
+    def op(x, axes=-1, keepdims=True):
+        """layer.Reduce* (layer.py:113-123): axis=tuple(axes)"""
+        return fn(x, axis=tuple(axes), keepdims=keepdims)
+    return op
+
+
+def reshape(x, shp):
+    """layer.Reshape (layer.py:188-192): 0 keeps the input dim."""
+    shp = shp.tolist()
+    for i in range(len(shp)):
+        shp[i] = shp[i] or x.shape[i]
+    return x.reshape(shp)
+
+
+def unsqueeze(x, axes=None):
+    """layer.Unsqueeze (layer.py:129-131)"""
+    return np.expand_dims(x, tuple(np.array(axes).tolist()))
+
+
+def resize(x, roi, k, size=None, mode="nearest", coordinate_transformation_mode="half_pixel",
+           nearest_mode="round_prefer_floor"):
+    """layer.Resize (layer.py:84-88), nearest; for the two mode pairs util.offset()
+    (util.py:155-170) maps to a zero shift this is plain replication like UpSample."""
+    if mode != "nearest" or (coordinate_transformation_mode, nearest_mode) not in (
+            ("half_pixel", "round_prefer_floor"), ("asymmetric", "floor")):
+        raise NotImplementedError("oracle covers the zero-shift nearest modes only")
+    if k.size == 0:
+        k = size[-2:] / np.array(x.shape[-2:])
+    return upsample(x, np.asarray(k)[-2:], "nearest")
+
+
+OPS = {"sub": sub, "mul": mul, "div": div, "pow": power, "exp": lambda x: np.exp(x),
+       "log": lambda x: np.log(x), "tanh": lambda x: np.tanh(x), "sqrt": lambda x: np.sqrt(x),
+       "reciprocal": lambda x: 1 / x, "hardsigmoid": hardsigmoid, "clip": clip,
+       "softmax": softmax, "logsoftmax": logsoftmax, "reducesum": _reducer(np.sum),
+       "reducemean": _reducer(np.mean), "reducemax": _reducer(np.max), "reducemin": _reducer(np.min),
+       "transpose": lambda x, axis: x.transpose(axis), "reshape": reshape,
+       "squeeze": lambda x, axes=[0]: np.squeeze(x, axis=axes[0]), "unsqueeze": unsqueeze,
+       "resize": resize, "identity": lambda x: x,
+       "conv": conv2d, "dense": dense, "matmul": matmul,
        "batchnorm": batchnorm, "relu": relu, "leakyrelu": leakyrelu,
        "sigmoid": sigmoid, "add": add, "maxpool": maxpool,
        "averagepool": avgpool, "gap": gap, "upsample": upsample,

@@ -69,6 +69,11 @@ SIGNATURES = {
     "pl_upsample_nearest_f32": [_P, _P, _P, _I, _I, _I, _I, _I],
     "pl_copy2d_f32": [_P, _P, _Z, _P, _Z, _Z, _Z],
     "pl_gap_f32": [_P, _P, _P, _I, _I],
+    "pl_unary_f32": [_P, _P, _P, _Z, _I, c_double, c_double],
+    "pl_binary_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I],
+    "pl_softmax_f32": [_P, _P, _P, _I, _I, _I],
+    "pl_reduce_f32": [_P, _P, _P, _I, _I, _I],
+    "pl_transpose_f32": [_P, _P, _P, _I, POINTER(c_int), POINTER(c_int)],
     "pl_splitk_reduce_f32": [_P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _I, c_double],
     "pl_comm_unique_id": [_P],
     "pl_comm_init_rank": [_P, _I, _I, _P],

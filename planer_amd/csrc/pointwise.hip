@@ -260,9 +260,177 @@ __global__ void __launch_bounds__(TPB) splitk_reduce_kernel(const float *ws, int
     }
 }
 
+// ---- second-wave operators -----------------------------------
+struct OpMath {
+    int op;       // 0 exp 1 log 2 tanh 3 sqrt 4 reciprocal 5 hardsigmoid 6 clip
+    float p0, p1;
+    __device__ float operator()(float x) const {
+        switch (op) {
+            case 0: return expf(x);
+            case 1: return logf(x);
+            case 2: return tanhf(x);
+            case 3: return sqrtf(x);   // correctly rounded (hipcc default)
+            case 4: return __fdiv_rn(1.f, x);
+            case 5: return fmaxf(fminf(__fadd_rn(__fmul_rn(x, p0), p1), 1.f), 0.f);   // layer.py:66-69
+            default: return fmaxf(fminf(x, p1), p0);                                   // layer.py:250-251
+        }
+    }
+};
+
+__device__ __forceinline__ float bin_op(int op, float a, float b) {
+    switch (op) {
+        case 0: return __fadd_rn(a, b);
+        case 1: return __fsub_rn(a, b);
+        case 2: return __fmul_rn(a, b);
+        case 3: return __fdiv_rn(a, b);
+        default: return powf(a, b);
+    }
+}
+
+// y = a (op) b with each operand either full-size, one value per channel, or a single value
+__global__ void __launch_bounds__(TPB) binary_kernel(const float *a, const float *b, float *y, size_t n, int C, int op,
+                                                     int amode, int bmode, FastDiv divInner, FastDiv divC) {
+    size_t stride = (size_t)gridDim.x * TPB;
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n; i += stride) {
+        unsigned c = 0;
+        if (amode == 1 || bmode == 1) {
+            const unsigned plane = divInner.div((unsigned)i);
+            c = plane - divC.div(plane) * (unsigned)C;
+        }
+        const float av = amode == 0 ? a[i] : amode == 1 ? a[c] : a[0];
+        const float bv = bmode == 0 ? b[i] : bmode == 1 ? b[c] : b[0];
+        y[i] = bin_op(op, av, bv);
+    }
+}
+
+// softmax / logsoftmax over the last axis, one wave64 per row (layer.py:141-153):
+// y = x - max; s = sum(exp(y)); out = exp(y - log s)  (or y - log s)
+__global__ void __launch_bounds__(TPB) softmax_kernel(const float *x, float *y, int rows, int cols, int logmode) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * TPB + threadIdx.x) >> 6, nwaves = (gridDim.x * TPB) >> 6;
+    for (int r = wave; r < rows; r += nwaves) {
+        const float *xp = x + (size_t)r * cols;
+        float *yp = y + (size_t)r * cols;
+        float m = -INFINITY;
+        for (int i = lane; i < cols; i += 64) m = fmaxf(m, xp[i]);
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        float s = 0.f;
+        for (int i = lane; i < cols; i += 64) s += expf(__fsub_rn(xp[i], m));
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        const float ls = logf(s);
+        for (int i = lane; i < cols; i += 64) {
+            const float t = __fsub_rn(__fsub_rn(xp[i], m), ls);
+            yp[i] = logmode ? t : expf(t);
+        }
+    }
+}
+
+// reduce over the trailing `cols` elements of each row: 0 sum, 1 mean, 2 max, 3 min
+__global__ void __launch_bounds__(TPB) reduce_rows_kernel(const float *x, float *y, int rows, int cols, int op) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * TPB + threadIdx.x) >> 6, nwaves = (gridDim.x * TPB) >> 6;
+    for (int r = wave; r < rows; r += nwaves) {
+        const float *xp = x + (size_t)r * cols;
+        float v = op == 2 ? -INFINITY : op == 3 ? INFINITY : 0.f;
+        for (int i = lane; i < cols; i += 64) {
+            const float t = xp[i];
+            v = op == 2 ? fmaxf(v, t) : op == 3 ? fminf(v, t) : v + t;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const float t = __shfl_xor(v, off, 64);
+            v = op == 2 ? fmaxf(v, t) : op == 3 ? fminf(v, t) : v + t;
+        }
+        if (lane == 0) y[r] = op == 1 ? __fdiv_rn(v, (float)cols) : v;
+    }
+}
+
+// general permutation of up to 6 axes: out[idx_out] = in[idx_in]
+struct PermArgs {
+    int ndim;
+    unsigned oshape[6];     // output shape
+    unsigned istride[6];    // input stride (elements) of the axis that feeds output axis d
+};
+__global__ void __launch_bounds__(TPB) transpose_kernel(const float *x, float *y, unsigned total, PermArgs p) {
+    unsigned stride = gridDim.x * TPB;
+    for (unsigned i = blockIdx.x * TPB + threadIdx.x; i < total; i += stride) {
+        unsigned rem = i;
+        size_t src = 0;
+        for (int d = p.ndim - 1; d >= 0; --d) {
+            const unsigned q = rem / p.oshape[d], r = rem - q * p.oshape[d];
+            src += (size_t)r * p.istride[d];
+            rem = q;
+        }
+        y[i] = x[src];
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int pl_unary_f32(pl_ctx *ctx, const float *x, float *y, size_t n, int op, double p0, double p1) {
+    PL_REQUIRE(op >= 0 && op <= 6, PL_EINVAL, "pl_unary_f32: bad op %d", op);
+    return launch_unary(ctx, x, y, n, OpMath{op, (float)p0, (float)p1});
+}
+
+int pl_binary_f32(pl_ctx *ctx, const float *a, const float *b, float *y, int outer, int C, int inner, int op,
+                  int a_mode, int b_mode) {
+    PL_REQUIRE(ctx && a && b && y, PL_EINVAL, "pl_binary_f32: null argument");
+    PL_REQUIRE(op >= 0 && op <= 4 && a_mode >= 0 && a_mode <= 2 && b_mode >= 0 && b_mode <= 2, PL_EINVAL,
+               "pl_binary_f32: bad op / broadcast mode");
+    PL_REQUIRE(outer >= 0 && C > 0 && inner > 0, PL_EINVAL, "pl_binary_f32: bad shape");
+    const size_t n = (size_t)outer * C * inner;
+    if (!n) return PL_OK;
+    PL_REQUIRE(n < (1ull << 32), PL_EUNSUPPORTED, "binary op: tensor too large");
+    CtxGuard g(ctx);
+    binary_kernel<<<stream_grid(ctx, n), TPB, 0, ctx->stream>>>(a, b, y, n, C, op, a_mode, b_mode, FastDiv(inner),
+                                                              FastDiv(C));
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
+
+int pl_softmax_f32(pl_ctx *ctx, const float *x, float *y, int rows, int cols, int log_softmax) {
+    PL_REQUIRE(ctx && x && y, PL_EINVAL, "pl_softmax_f32: null argument");
+    PL_REQUIRE(rows >= 0 && cols > 0, PL_EINVAL, "pl_softmax_f32: bad shape");
+    if (!rows) return PL_OK;
+    CtxGuard g(ctx);
+    softmax_kernel<<<stream_grid(ctx, (size_t)rows * 64), TPB, 0, ctx->stream>>>(x, y, rows, cols, log_softmax);
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
+
+int pl_reduce_f32(pl_ctx *ctx, const float *x, float *y, int rows, int cols, int op) {
+    PL_REQUIRE(ctx && x && y, PL_EINVAL, "pl_reduce_f32: null argument");
+    PL_REQUIRE(rows >= 0 && cols > 0 && op >= 0 && op <= 3, PL_EINVAL, "pl_reduce_f32: bad argument");
+    if (!rows) return PL_OK;
+    CtxGuard g(ctx);
+    reduce_rows_kernel<<<stream_grid(ctx, (size_t)rows * 64), TPB, 0, ctx->stream>>>(x, y, rows, cols, op);
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
+
+int pl_transpose_f32(pl_ctx *ctx, const float *x, float *y, int ndim, const int *shape, const int *perm) {
+    PL_REQUIRE(ctx && x && y && shape && perm, PL_EINVAL, "pl_transpose_f32: null argument");
+    PL_REQUIRE(ndim >= 1 && ndim <= 6, PL_EUNSUPPORTED, "pl_transpose_f32: 1..6 axes");
+    size_t istr[6], total = 1;
+    for (int d = ndim - 1; d >= 0; --d) {
+        PL_REQUIRE(shape[d] >= 0 && perm[d] >= 0 && perm[d] < ndim, PL_EINVAL, "pl_transpose_f32: bad shape/perm");
+        istr[d] = total;
+        total *= (size_t)shape[d];
+    }
+    if (!total) return PL_OK;
+    PL_REQUIRE(total < (1ull << 32), PL_EUNSUPPORTED, "transpose: tensor too large");
+    PermArgs p;
+    p.ndim = ndim;
+    for (int d = 0; d < ndim; ++d) {
+        p.oshape[d] = (unsigned)shape[perm[d]];
+        p.istride[d] = (unsigned)istr[perm[d]];
+    }
+    CtxGuard g(ctx);
+    transpose_kernel<<<stream_grid(ctx, total), TPB, 0, ctx->stream>>>(x, y, (unsigned)total, p);
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
 
 int pl_relu_f32(pl_ctx *ctx, const float *x, float *y, size_t n) { return launch_unary(ctx, x, y, n, OpRelu{}); }
 

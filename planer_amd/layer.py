@@ -208,7 +208,7 @@ def Add(x1, x2):
         _lib.call("pl_add_channel_f32", big.ctx.handle, big.ptr, small.ptr, y.ptr,
                   big.shape[0], c, big.size // (big.shape[0] * c))
         return y
-    raise NotImplementedError("add: broadcast %s + %s is not on the HIP path" % (x1.shape, x2.shape))
+    return _binary(x1, x2, 0)
 
 
 def _pool(x, w, pads, strides, mode):
@@ -297,6 +297,219 @@ def Return(*x):
     return x
 
 
+# ---- second-wave operators -----------------------------------------
+def _broadcast_modes(x1, x2):
+    """-> (out_shape, outer, C, inner, mode1, mode2) for the broadcast forms planer graphs use:
+    equal shapes, a one-element operand, or a (1|-,C,1,...) per-channel operand."""
+    def mode(a, ref):
+        if a.shape == ref.shape:
+            return 0
+        if a.size == 1:
+            return 2
+        nd = ref.ndim
+        shp = (1,) * (nd - a.ndim) + a.shape
+        if nd >= 2 and len(shp) == nd and shp[1] == ref.shape[1] and a.size == ref.shape[1]:
+            return 1
+        raise NotImplementedError("broadcast %s with %s is not on the HIP path" % (a.shape, ref.shape))
+    ref = x1 if x1.size >= x2.size else x2
+    m1, m2 = mode(x1, ref), mode(x2, ref)
+    c = ref.shape[1] if ref.ndim >= 2 else 1
+    outer = ref.shape[0] if ref.ndim >= 2 else 1
+    inner = ref.size // (outer * c) if ref.size else 1
+    return ref.shape, outer, c, max(inner, 1), m1, m2
+
+
+def _binary(x1, x2, op):
+    _f32(x1, x2)
+    shape, outer, c, inner, m1, m2 = _broadcast_modes(x1, x2)
+    y = empty(shape, ctx=x1.ctx)
+    if y.size:
+        _lib.call("pl_binary_f32", x1.ctx.handle, x1.ptr, x2.ptr, y.ptr, outer, c, inner, op, m1, m2)
+    return y
+
+
+def Sub(x1, x2):
+    """layer.Sub (layer.py:97-99)"""
+    return _binary(x1, x2, 1)
+
+
+def Mul(x1, x2):
+    """layer.Mul (layer.py:101-103)"""
+    return _binary(x1, x2, 2)
+
+
+def Div(x1, x2):
+    """layer.Div (layer.py:105-107)"""
+    return _binary(x1, x2, 3)
+
+
+def Pow(x, p):
+    """layer.Pow (layer.py:109-111)"""
+    return _binary(x, p, 4)
+
+
+def _unary(x, op, p0=0.0, p1=0.0, inplace=False):
+    _f32(x)
+    y = x if inplace else empty(x.shape, ctx=x.ctx)
+    _lib.call("pl_unary_f32", x.ctx.handle, x.ptr, y.ptr, x.size, op, float(p0), float(p1))
+    return y
+
+
+def Exp(x):
+    """layer.Exp (layer.py:178-180)"""
+    return _unary(x, 0)
+
+
+def Log(x):
+    """layer.Log (layer.py:182-184)"""
+    return _unary(x, 1)
+
+
+def Tanh(x):
+    """layer.Tanh (layer.py:174-176)"""
+    return _unary(x, 2)
+
+
+def Sqrt(x):
+    """layer.Sqrt (layer.py:53)"""
+    return _unary(x, 3)
+
+
+def Reciprocal(x):
+    """layer.Reciprocal (layer.py:186)"""
+    return _unary(x, 4)
+
+
+def HardSigmoid(x, alpha=0.2, beta=0.5):
+    """layer.HardSigmoid (layer.py:66-69): clip(x*alpha + beta, 0, 1)"""
+    return _unary(x, 5, alpha, beta)
+
+
+def Clip(x, min=0, max=1):
+    """layer.Clip (layer.py:247-251), numpy branch: IN PLACE on x like the reference."""
+    return _unary(x, 6, min, max, inplace=True)
+
+
+def _rows_cols(x, axis):
+    nd = x.ndim
+    axis = axis + nd if axis < 0 else axis
+    if axis != nd - 1:
+        raise NotImplementedError("softmax over axis %d of %d dims is not on the HIP path (last axis only)" % (axis, nd))
+    cols = x.shape[-1]
+    return (x.size // cols if cols else 0), cols
+
+
+def Softmax(x, axis=-1):
+    """layer.Softmax (layer.py:141-146)"""
+    _f32(x)
+    rows, cols = _rows_cols(x, axis)
+    y = empty(x.shape, ctx=x.ctx)
+    _lib.call("pl_softmax_f32", x.ctx.handle, x.ptr, y.ptr, rows, cols, 0)
+    return y
+
+
+def LogSoftmax(x, axis=-1):
+    """layer.LogSoftmax (layer.py:148-153)"""
+    _f32(x)
+    rows, cols = _rows_cols(x, axis)
+    y = empty(x.shape, ctx=x.ctx)
+    _lib.call("pl_softmax_f32", x.ctx.handle, x.ptr, y.ptr, rows, cols, 1)
+    return y
+
+
+def _reduce(x, axes, keepdims, op):
+    """ReduceSum/Mean/Max/Min (layer.py:113-123) over a trailing block of axes."""
+    _f32(x)
+    nd = x.ndim
+    axes = sorted(a + nd if a < 0 else a for a in tuple(axes))      # tuple(axes) as in the reference
+    if axes != list(range(nd - len(axes), nd)):
+        raise NotImplementedError("reduction over axes %s of %d dims is not on the HIP path (trailing axes only)" % (axes, nd))
+    cols = int(numpy.prod(x.shape[nd - len(axes):], dtype=numpy.int64))
+    rows = x.size // cols if cols else 0
+    lead = x.shape[:nd - len(axes)]
+    y = empty(lead + ((1,) * len(axes) if keepdims else ()), ctx=x.ctx)
+    _lib.call("pl_reduce_f32", x.ctx.handle, x.ptr, y.ptr, rows, max(cols, 1), op)
+    return y
+
+
+def ReduceSum(x, axes=-1, keepdims=True):
+    return _reduce(x, axes, keepdims, 0)
+
+
+def ReduceMean(x, axes=-1, keepdims=True):
+    return _reduce(x, axes, keepdims, 1)
+
+
+def ReduceMax(x, axes=-1, keepdims=True):
+    return _reduce(x, axes, keepdims, 2)
+
+
+def ReduceMin(x, axes=-1, keepdims=True):
+    return _reduce(x, axes, keepdims, 3)
+
+
+def Transpose(x, axis):
+    """layer.Transpose (layer.py:194): x.transpose(axis), materialised contiguous."""
+    _f32(x)
+    perm = [int(a) for a in axis]
+    if sorted(perm) != list(range(x.ndim)):
+        raise ValueError("transpose: bad permutation %s" % (perm,))
+    y = empty(tuple(x.shape[a] for a in perm), ctx=x.ctx)
+    n = x.ndim
+    shp = (_lib.c_int * n)(*x.shape)
+    prm = (_lib.c_int * n)(*perm)
+    _lib.call("pl_transpose_f32", x.ctx.handle, x.ptr, y.ptr, n, shp, prm)
+    return y
+
+
+def Reshape(x, shp):
+    """layer.Reshape (layer.py:188-192): a 0 in `shp` keeps that input dim; a view."""
+    shp = [int(v) for v in _host_values(shp).tolist()]
+    for i in range(len(shp)):
+        shp[i] = shp[i] or x.shape[i]
+    return x.reshape(shp)
+
+
+def Squeeze(x, axes=[0]):
+    """layer.Squeeze (layer.py:133-134): np.squeeze(x, axis=axes[0])"""
+    a = axes[0] + x.ndim if axes[0] < 0 else axes[0]
+    if x.shape[a] != 1:
+        raise ValueError("cannot select an axis to squeeze out which has size not equal to one")
+    return x.reshape(x.shape[:a] + x.shape[a + 1:])
+
+
+def Unsqueeze(x, axes=None):
+    """layer.Unsqueeze (layer.py:129-131): np.expand_dims(x, tuple(axes))"""
+    axes = numpy.array(axes).tolist()
+    axes = [axes] if isinstance(axes, int) else list(axes)
+    nd = x.ndim + len(axes)
+    axes = sorted(a + nd if a < 0 else a for a in axes)
+    it, shape = iter(x.shape), []
+    for d in range(nd):
+        shape.append(1 if d in axes else next(it))
+    return x.reshape(shape)
+
+
+def Resize(x, roi, k, size=None, mode="nearest", coordinate_transformation_mode="half_pixel",
+           nearest_mode="round_prefer_floor"):
+    """layer.Resize (layer.py:84-88), nearest with integer scales.  The two mode pairs that
+    util.offset() maps to plain replication are supported; the shifting
+    (asymmetric, ceil) variant and linear modes are not on the HIP path."""
+    if mode != "nearest":
+        raise NotImplementedError("resize mode %r is not on the HIP path" % mode)
+    if (coordinate_transformation_mode, nearest_mode) not in (("half_pixel", "round_prefer_floor"),
+                                                              ("asymmetric", "floor")):
+        raise NotImplementedError("resize %s/%s is not on the HIP path" % (coordinate_transformation_mode, nearest_mode))
+    kv = _host_values(k)
+    if kv.size == 0:
+        sz = _host_values(size)
+        kv = sz[-2:] / numpy.array(x.shape[-2:])
+    fh, fw = [float(v) for v in kv[-2:].tolist()]
+    if fh != int(fh) or fw != int(fw) or fh < 1 or fw < 1:
+        raise NotImplementedError("resize: only integer up-scaling is on the HIP path")
+    return UpSample(x, numpy.array([1, 1, fh, fw], numpy.float32))
+
+
 def _missing(kind):
     def op(*a, **k):
         raise NotImplementedError(
@@ -306,18 +519,22 @@ def _missing(kind):
     return op
 
 
-NOT_ON_DEVICE = ["softmax", "hardsigmoid", "squeeze", "const", "resize", "pad", "convtranspose",
-                 "sub", "reducemean", "exp", "log", "mul", "pow", "tile", "lstm", "reducemax",
-                 "reducemin", "reducesum", "div", "unsqueeze", "shape", "gather", "reshape",
-                 "split", "tanh", "constantofshape", "slice", "expand", "cast", "range", "equal",
-                 "where", "scatternd", "instancenormalization", "clip", "greater", "nonzero",
-                 "greaterorequal", "topk", "sqrt", "erf", "reciprocal", "transpose", "logsoftmax"]
+NOT_ON_DEVICE = ["const", "pad", "convtranspose", "tile", "lstm", "shape", "gather", "split",
+                 "constantofshape", "slice", "expand", "cast", "range", "equal", "where", "scatternd",
+                 "instancenormalization", "greater", "nonzero", "greaterorequal", "topk", "erf"]
 
 layer_map = {"dense": Dense, "conv": Conv2d, "relu": ReLU, "leakyrelu": LeakyReLU,
              "batchnorm": BatchNorm, "flatten": Flatten, "sigmoid": Sigmoid,
              "maxpool": Maxpool, "averagepool": AveragePool, "upsample": UpSample,
              "concat": Concatenate, "add": Add, "gap": GlobalAveragePool, "matmul": MatMul,
              "identity": Identity, "return": Return,
+             # second wave
+             "sub": Sub, "mul": Mul, "div": Div, "pow": Pow, "exp": Exp, "log": Log, "tanh": Tanh,
+             "sqrt": Sqrt, "reciprocal": Reciprocal, "hardsigmoid": HardSigmoid, "clip": Clip,
+             "softmax": Softmax, "logsoftmax": LogSoftmax, "reducesum": ReduceSum,
+             "reducemean": ReduceMean, "reducemax": ReduceMax, "reducemin": ReduceMin,
+             "transpose": Transpose, "reshape": Reshape, "squeeze": Squeeze, "unsqueeze": Unsqueeze,
+             "resize": Resize,
              # plan-compiler internal
              "conv_fused": ConvFused}
 layer_map.update({k: _missing(k) for k in NOT_ON_DEVICE})

@@ -64,6 +64,40 @@ def layer_cases():
     c.append(("gap", "gap", [_r(310, 2, 9, 7, 7)], {}))
     c.append(("gap_big", "gap", [_r(311, 1, 3, 28, 31)], {}))
     c.append(("flatten", "flatten", [_r(320, 2, 4, 3, 5)], {}))
+    # ---- second-wave operators ----
+    pos = np.abs(_r(400, 2, 5, 6, 7)) + 0.1
+    for kind, arr in (("exp", _r(401, 2, 5, 6, 7)), ("log", pos), ("tanh", _r(402, 3, 50, scale=2)),
+                      ("sqrt", pos), ("reciprocal", pos)):
+        c.append((kind, kind, [arr], {}))
+    c.append(("hardsigmoid", "hardsigmoid", [_r(403, 2, 5, 6, 7, scale=3)], {}))
+    c.append(("hardsigmoid_ab", "hardsigmoid", [_r(404, 4, 33, scale=3)], {"alpha": 0.1666, "beta": 0.5}))
+    c.append(("clip", "clip", [_r(405, 2, 5, 6, 7, scale=2)], {"min": -0.5, "max": 1.25}))
+    c.append(("clip_relu6", "clip", [_r(406, 3, 40, scale=5)], {"min": 0, "max": 6}))
+    a4, b4 = _r(410, 2, 6, 5, 7), _r(411, 2, 6, 5, 7)
+    for kind in ("sub", "mul", "div"):
+        c.append((kind, kind, [a4, np.where(np.abs(b4) < 0.1, 0.5, b4).astype(np.float32)], {}))
+        c.append((kind + "_bcast_channel", kind, [a4, (np.abs(_r(412, 1, 6, 1, 1)) + 0.5).astype(np.float32)], {}))
+        c.append((kind + "_scalar_lhs", kind, [np.array([1.5], np.float32), (np.abs(b4) + 0.5).astype(np.float32)], {}))
+    c.append(("pow_scalar", "pow", [pos, np.array([2.0], np.float32)], {}))
+    c.append(("pow_tensor", "pow", [pos, (np.abs(_r(413, 2, 5, 6, 7)) + 0.2).astype(np.float32)], {}))
+    c.append(("add_scalar", "add", [a4, np.array([0.25], np.float32)], {}))
+    c.append(("softmax", "softmax", [_r(420, 6, 1000, scale=3)], {}))
+    c.append(("softmax_3d", "softmax", [_r(421, 2, 7, 33, scale=2)], {"axis": -1}))
+    c.append(("logsoftmax", "logsoftmax", [_r(422, 5, 91, scale=3)], {"axis": 1}))
+    c.append(("reducemean_hw", "reducemean", [_r(430, 2, 9, 7, 5)], {"axes": [2, 3], "keepdims": True}))
+    c.append(("reducesum_last", "reducesum", [_r(431, 4, 77)], {"axes": [-1], "keepdims": False}))
+    c.append(("reducemax_hw", "reducemax", [_r(432, 2, 3, 8, 9)], {"axes": [-2, -1], "keepdims": True}))
+    c.append(("reducemin_last", "reducemin", [_r(433, 3, 5, 40)], {"axes": [2], "keepdims": True}))
+    c.append(("transpose_0231", "transpose", [_r(440, 2, 5, 6, 7)], {"axis": [0, 2, 3, 1]}))
+    c.append(("transpose_10", "transpose", [_r(441, 13, 29)], {"axis": [1, 0]}))
+    c.append(("reshape_keep0", "reshape", [_r(450, 2, 12, 5), np.array([0, 3, -1], np.int64)], {}))
+    c.append(("squeeze", "squeeze", [_r(451, 3, 1, 5)], {"axes": [1]}))
+    c.append(("unsqueeze", "unsqueeze", [_r(452, 3, 5)], {"axes": [0, 3]}))
+    c.append(("resize_nearest_x2", "resize", [_r(460, 2, 3, 5, 6), np.zeros(0, np.float32),
+                                              np.array([1, 1, 2, 2], np.float32)], {"mode": "nearest"}))
+    c.append(("resize_asym_floor", "resize", [_r(461, 1, 2, 4, 4), np.zeros(0, np.float32),
+                                              np.array([1, 1, 3, 2], np.float32)],
+              {"mode": "nearest", "coordinate_transformation_mode": "asymmetric", "nearest_mode": "floor"}))
     return c
 
 

@@ -42,7 +42,11 @@ def test_layer_vs_reference_vectors(pa, case, golden_layers):
 
 EXACT = ["relu", "leakyrelu_0.1", "leakyrelu_default", "add", "batchnorm", "maxpool_k2s2", "maxpool_k3s2p1_neg",
          "maxpool_k3s2p1", "maxpool_clamp_-1e4", "upsample_x2", "upsample_2x3", "concat_axis1", "concat_axis0_3",
-         "flatten", "add_bcast_channel"]
+         "flatten", "add_bcast_channel", "sub", "mul", "div", "sub_bcast_channel", "mul_bcast_channel",
+         "div_bcast_channel", "sub_scalar_lhs", "mul_scalar_lhs", "div_scalar_lhs", "add_scalar", "sqrt",
+         "reciprocal", "hardsigmoid", "hardsigmoid_ab", "clip", "clip_relu6", "reducemax_hw", "reducemin_last",
+         "transpose_0231", "transpose_10", "reshape_keep0", "squeeze", "unsqueeze", "resize_nearest_x2",
+         "resize_asym_floor"]
 
 
 @pytest.mark.parametrize("name", EXACT)
@@ -229,7 +233,9 @@ def test_unsupported_inputs_fail_loudly(pa):
     with pytest.raises(NotImplementedError):
         pa.Maxpool(x, w=[2, 2], pads=[1, 0, 0, 0])
     with pytest.raises(NotImplementedError):
-        pa.layer_map["softmax"](x)
+        pa.layer_map["lstm"](x)
+    with pytest.raises(NotImplementedError):
+        pa.Softmax(x, axis=1)                          # only the last axis is on the HIP path
     with pytest.raises((ValueError, NotImplementedError)):
         pa.Conv2d(x, pa.asarray(np.zeros((4, 3, 3, 3), np.float32)))
 
