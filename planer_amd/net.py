@@ -360,7 +360,6 @@ class Net:
         # ReLU works in place, so feed it copies, never the caller's arrays.
         timer = dict(self.timer)
         self._interpret(self._program, [a.copy() for a in xs], shapes=shapes)
-        prog, nfused = self._fuse(shapes, self.use_fusion)
         batch = xs[0].shape[0] if xs and xs[0].ndim else 0
         # A plan is (Q, P): the batch is cut into P sub-batches, each its own captured graph,
         # dealt round-robin onto Q streams.  Q > 1 lets two kernels overlap (one's tail and ramp
@@ -368,14 +367,28 @@ class Net:
         splittable = batch > 0 and all(a.ndim and a.shape[0] == batch for a in xs)
         want = str(self.streams)
         if want == "auto":
-            cands = [(1, 1)] + [(q, p_) for q, p_ in ((2, 2), (2, 4), (3, 3), (4, 4))
+            cands = [(1, 1)] + [(q, p_) for q, p_ in ((2, 2), (2, 4), (4, 4))
                                 if splittable and batch % p_ == 0 and batch // p_ >= 4]
         else:
             q, _, p_ = want.partition("x")
             q, p_ = int(q), int(p_ or q)
             cands = [(q, p_) if splittable and p_ >= q >= 1 and batch % p_ == 0 else (1, 1)]
+        progs = {}
+
+        def program_for(P):
+            """The fused program with conv algorithms (direct vs Winograd) picked for the shapes a
+            sub-batch of batch/P images really has."""
+            if P not in progs:
+                sub = dict(shapes)
+                if P > 1:
+                    for k, shp in shapes.items():
+                        if k not in self.inits and shp and len(shp) >= 1 and shp[0] == batch:
+                            sub[k] = (batch // P,) + tuple(shp[1:])
+                progs[P] = self._fuse(sub, self.use_fusion)
+            return progs[P]
         best = None
         for Q, P in cands:
+            prog, nfused = program_for(P)
             try:
                 cand = self._build_plan(prog, xs, Q, P, nfused)
             except _NotSplittable:
