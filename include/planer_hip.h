@@ -117,6 +117,32 @@ int pl_conv2d_prepare_weights_f32(pl_ctx *ctx, const float *w, int Cout, int Cin
  * stride 1 / pad 1 / group 1 convs with Cin % 16 == 0: input transform + 16 GEMMs (one grouped
  * 1x1 conv on the MFMA kernel) + output transform with the fused tail. */
 int pl_conv2d_prepare_winograd_f32(pl_ctx *ctx, const float *w, int Cout, int Cin, float *out);
+/* ---- channel-quad ("Q4") activations: the compiled plan's internal layout ----
+ * A Q4 tensor holds the reference's (N,C,H,W) array as [N][ceil(C/4)][H][W][4]
+ * (channel c -> quad c/4, lane c%4; padding lanes are zero), 16-byte aligned.
+ * It exists because on gfx950 one b128 load per (pixel, 4 channels) keeps the
+ * fp32 MFMA pipe 13-17 % busier than the four dword loads NCHW needs (DESIGN.md
+ * section 4).  Semantics stay layer.Conv2d's (layer.py:22-26, util.py:17-44):
+ * pl_q4_to_nchw(pl_conv2d_q4(pl_nchw_to_q4(x))) == pl_conv2d_fused(x) up to
+ * fp32 summation order.  Conversions are done by the plan at graph inputs /
+ * outputs and around layers that have no Q4 kernel. */
+int pl_nchw_to_q4_f32(pl_ctx *ctx, const float *x, float *yq, int N, int C, int HW);
+int pl_q4_to_nchw_f32(pl_ctx *ctx, const float *xq, float *y, int N, int C, int HW);
+/* Filter for pl_conv2d_q4_f32: OIHW -> wq[group][q][Cout/group][4] with
+ * q = tap*ceil(Cin_g/4) + cin/4, zero padded to a multiple of 8 k-quads; made
+ * once per model.  `elems` = floats the packed filter occupies. */
+int pl_conv2d_q4_filter_elems(int Cout, int Cin_g, int kh, int kw, int group, size_t *elems);
+int pl_conv2d_prepare_q4_f32(pl_ctx *ctx, const float *w, int Cout, int Cin_g, int kh, int kw,
+                             int group, float *out);
+/* pl_conv2d_fused_f32 on Q4 tensors: xq, resq, yq are Q4 (Cin / Cout / Cout
+ * channels); bias/scale/shift stay plain per-channel arrays.  group > 1 needs
+ * Cin/group and Cout/group to be multiples of 4 (else PL_EUNSUPPORTED). */
+int pl_conv2d_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W,
+                     const float *wq, int Cout, int kh, int kw, const float *bias,
+                     float *yq, int sh, int sw, int dh, int dw, int pt, int pl,
+                     int pb, int pr, int group, const float *scale,
+                     const float *shift, const float *resq, int act, double alpha);
+
 /* First call for a new conv shape times every applicable tile configuration
  * and remembers the fastest (on by default; PLANER_HIP_AUTOTUNE=0 or 0 here
  * selects the static heuristic). Never runs during graph capture. */

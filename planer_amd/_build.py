@@ -47,7 +47,8 @@ def build(force=False, verbose=True):
 
     def compile_one(job):
         s, o = job
-        cmd = [hipcc, "-x", "hip"] + FLAGS + ["-c", s, "-o", o]
+        # PLANER_HIP_EXTRA_FLAGS: experiment builds only (e.g. -DPL_Q4_SIMPLE=1)
+        cmd = [hipcc, "-x", "hip"] + FLAGS + os.environ.get("PLANER_HIP_EXTRA_FLAGS", "").split() + ["-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

@@ -51,6 +51,12 @@ SIGNATURES = {
                            + [_P, _P, _P, _I, c_double, _I],
     "pl_conv2d_prepare_weights_f32": [_P, _P, _I, _I, _I, _I, _P],
     "pl_conv2d_prepare_winograd_f32": [_P, _P, _I, _I, _P],
+    "pl_nchw_to_q4_f32": [_P, _P, _P, _I, _I, _I],
+    "pl_q4_to_nchw_f32": [_P, _P, _P, _I, _I, _I],
+    "pl_conv2d_q4_filter_elems": [_I, _I, _I, _I, _I, POINTER(c_size_t)],
+    "pl_conv2d_prepare_q4_f32": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "pl_conv2d_q4_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P] + [_I] * 9
+                        + [_P, _P, _P, _I, c_double],
     "pl_set_autotune": [_P, _I],
     "pl_tune_cache_save": [_P, c_char_p],
     "pl_tune_cache_load": [_P, c_char_p, POINTER(c_int)],

@@ -63,6 +63,9 @@ struct ConvArgs {
     int tile_count;   // tiles this launch covers (slab stride of the split pass)
     int splits, k_per_split;    // k_per_split: K elements (generic) or BK-chunks (tap-major)
     int x_bytes, w_bytes;
+    // channel-quad (Q4) layout only: input quads per group / in total, output quads in total,
+    // k-quads per group (real / padded)
+    int cqg, Cq, Coq, Qtot, Qpad;
     FastDiv divKhw, divKw, divHoWo, divWo, divMt, divCpt;
     Epilogue ep;
 };
@@ -646,6 +649,8 @@ __global__ void __launch_bounds__(256) permute_weights_kernel(const float *w, fl
     }
 }
 
+#include "conv_q4_kernel.h"
+
 // ---- configurations ---------------------------------------------------------
 typedef Cfg<128, 128, 16, 2, 2> C128x128;
 typedef Cfg<64, 128, 16, 2, 2> C64x128;
@@ -669,9 +674,24 @@ typedef TapCfg<32, 128, 32, 1, 4> T32x128x32;
 typedef TapCfg<256, 64, 16, 4, 1> T256x64x16;
 typedef TapCfg<64, 256, 16, 1, 4> T64x256x16;
 
+typedef QuadCfg<128, 128, 16, 2, 2> Q128x128x16;
+typedef QuadCfg<128, 128, 32, 2, 2> Q128x128x32;
+typedef QuadCfg<64, 128, 16, 2, 2> Q64x128x16;
+typedef QuadCfg<64, 128, 32, 2, 2> Q64x128x32;
+typedef QuadCfg<128, 64, 16, 2, 2> Q128x64x16;
+typedef QuadCfg<128, 64, 32, 2, 2> Q128x64x32;
+typedef QuadCfg<64, 64, 16, 2, 2> Q64x64x16;
+typedef QuadCfg<64, 64, 32, 2, 2> Q64x64x32;
+typedef QuadCfg<128, 32, 32, 4, 1> Q128x32x32;
+typedef QuadCfg<32, 128, 32, 1, 4> Q32x128x32;
+typedef QuadCfg<256, 64, 16, 4, 1> Q256x64x16;
+typedef QuadCfg<64, 256, 16, 1, 4> Q64x256x16;
+
 struct CfgInfo {
     const char *name;
-    int tap;  // 0: generic (OIHW weights, any shape)   1: tap-major (prepared weights, cin_g % bk == 0)
+    // 0: generic (OIHW weights, any shape)   1: tap-major (prepared weights, cin_g % bk == 0)
+    // 2: channel-quad activations + k-quad-major filters (conv_q4_kernel.h)
+    int tap;
     int bm, bn, bk, lds;
     void (*vec)(const ConvArgs);
     void (*scl)(const ConvArgs);
@@ -688,6 +708,10 @@ struct CfgInfo {
     { nm, 1, T::BM, T::BN, T::BK, T::LDS_BYTES, conv_tap_kernel<T>, conv_tap_kernel<T>, \
       reduce_tiles_kernel<T::BM, T::BN, false>, reduce_tiles_kernel<T::BM, T::BN, true> }
 
+#define Q4_ENTRY(T, nm) \
+    { nm, 2, T::BM, T::BN, T::BK, T::LDS_BYTES, conv_q4_kernel<T>, conv_q4_kernel<T>, \
+      reduce_tiles_q4_kernel<T::BM, T::BN>, reduce_tiles_q4_kernel<T::BM, T::BN> }
+
 const CfgInfo kCfgs[] = {
     CFG_ENTRY(C128x128, "128x128"), CFG_ENTRY(C64x128, "64x128"), CFG_ENTRY(C128x64, "128x64"),
     CFG_ENTRY(C64x64, "64x64"),     CFG_ENTRY(C32x128, "32x128"), CFG_ENTRY(C32x256, "32x256"),
@@ -698,13 +722,20 @@ const CfgInfo kCfgs[] = {
     TAP_ENTRY(T64x64x16, "t64x64x16"),     TAP_ENTRY(T64x64x32, "t64x64x32"),
     TAP_ENTRY(T128x32x32, "t128x32x32"),   TAP_ENTRY(T32x128x32, "t32x128x32"),
     TAP_ENTRY(T256x64x16, "t256x64x16"),   TAP_ENTRY(T64x256x16, "t64x256x16"),
+    Q4_ENTRY(Q128x128x16, "q128x128x16"),  Q4_ENTRY(Q128x128x32, "q128x128x32"),
+    Q4_ENTRY(Q64x128x16, "q64x128x16"),    Q4_ENTRY(Q64x128x32, "q64x128x32"),
+    Q4_ENTRY(Q128x64x16, "q128x64x16"),    Q4_ENTRY(Q128x64x32, "q128x64x32"),
+    Q4_ENTRY(Q64x64x16, "q64x64x16"),      Q4_ENTRY(Q64x64x32, "q64x64x32"),
+    Q4_ENTRY(Q128x32x32, "q128x32x32"),    Q4_ENTRY(Q32x128x32, "q32x128x32"),
+    Q4_ENTRY(Q256x64x16, "q256x64x16"),    Q4_ENTRY(Q64x256x16, "q64x256x16"),
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 constexpr int kLdsPerCu = 160 * 1024;
 
+// weight layouts: 0 OIHW (generic kernel), 1 tap-major, 2 Q4 (activations AND filter in quad form)
 bool cfg_applies(const CfgInfo &ci, int layout, int cin_g) {
-    if (ci.tap != (layout ? 1 : 0)) return false;
-    return !ci.tap || cin_g % ci.bk == 0;
+    if (ci.tap != layout) return false;
+    return ci.tap != 1 || cin_g % ci.bk == 0;
 }
 
 // How one conv is run.  Tiles [0, t1) take the data-parallel pass with the
@@ -743,7 +774,14 @@ int launch_pass(pl_ctx *ctx, ConvArgs a, const CfgInfo &ci, bool avec, int tile_
                 int occ, float *out, int *used_splits) {
     *used_splits = 0;
     if (tile_count <= 0) return PL_OK;
-    if (ci.tap) {
+    if (ci.tap == 2) {
+        const int kg = ci.bk / 4;
+        const int total_chunks = (a.Qtot + kg - 1) / kg;
+        const int cps = (total_chunks + splits - 1) / splits;
+        splits = (total_chunks + cps - 1) / cps;
+        a.k_per_split = cps;
+        a.divCpt = FastDiv(a.cqg);
+    } else if (ci.tap) {
         const int total_chunks = a.K / ci.bk;
         const int cps = (total_chunks + splits - 1) / splits;
         splits = (total_chunks + cps - 1) / cps;
@@ -806,9 +844,9 @@ int run_plan(pl_ctx *ctx, const ConvArgs &a0, const Plan &pl, bool avec, float *
         r.splits = used;
         r.tile_offset = t1;
         r.tile_count = tail;
-        const bool vec4 = a.HoWo % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15u) == 0 &&
-                          (!a.ep.res || (reinterpret_cast<uintptr_t>(a.ep.res) & 15u) == 0);
-        const int rows = vec4 ? std::min(ci.bm, REDUCE_ROWS * 4) : REDUCE_ROWS;
+        const bool vec4 = ci.tap == 2 || (a.HoWo % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15u) == 0 &&
+                                          (!a.ep.res || (reinterpret_cast<uintptr_t>(a.ep.res) & 15u) == 0));
+        const int rows = ci.tap == 2 ? REDUCE_Q4_QUADS * 4 : vec4 ? std::min(ci.bm, REDUCE_ROWS * 4) : REDUCE_ROWS;
         hipLaunchKernelGGL(vec4 ? ci.reduce4 : ci.reduce, dim3((unsigned)tail, (unsigned)((ci.bm + rows - 1) / rows)),
                            dim3(256), 0, ctx->stream, r, (const float *)ws, y);
         hipError_t le = hipGetLastError();
@@ -984,7 +1022,7 @@ int conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const
     PL_REQUIRE(pt == pb && pl == pr, PL_EUNSUPPORTED, "asymmetric pads are undefined in the reference (util.py:8)");
     PL_REQUIRE(Cin % group == 0 && Cout % group == 0, PL_EUNSUPPORTED, "group must divide Cin and Cout");
     PL_REQUIRE(act >= 0 && act <= 2, PL_EINVAL, "conv2d: bad activation code");
-    PL_REQUIRE(layout == 0 || layout == 1 || layout == 3, PL_EINVAL, "conv2d: bad weight layout");
+    PL_REQUIRE(layout >= 0 && layout <= 3, PL_EINVAL, "conv2d: bad weight layout");
     if (layout == 3) {
         PL_REQUIRE(kh == 3 && kw == 3 && sh == 1 && sw == 1 && dh == 1 && dw == 1 && pt == 1 && pl == 1 && pb == 1 &&
                        pr == 1 && group == 1, PL_EINVAL, "winograd filters serve 3x3 / stride 1 / pad 1 / group 1 only");
@@ -998,11 +1036,19 @@ int conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const
     PL_REQUIRE(H + 2 * pt < 16384 && W + 2 * pl < 16384 && kh * dh < 16384 && kw * dw < 16384, PL_EUNSUPPORTED,
                "conv2d: spatial extent above 16383");
     if (N == 0) return PL_OK;
-    const size_t out_elems = (size_t)N * Cout * Ho * Wo, in_elems = (size_t)N * Cin * H * W;
-    const size_t w_elems = (size_t)Cout * (Cin / group) * kh * kw;
-    PL_REQUIRE(out_elems < (1ull << 31) && in_elems <= (1ull << 29) && w_elems <= (1ull << 29),
+    size_t out_elems = (size_t)N * Cout * Ho * Wo, in_elems = (size_t)N * Cin * H * W;
+    size_t w_elems = (size_t)Cout * (Cin / group) * kh * kw;
+    const int cqg = (Cin / group + 3) / 4, q_tot = kh * kw * cqg, q_pad = (q_tot + 7) / 8 * 8;
+    if (layout == 2) {
+        PL_REQUIRE(group == 1 || ((Cin / group) % 4 == 0 && (Cout / group) % 4 == 0), PL_EUNSUPPORTED,
+                   "conv2d (Q4): grouped convs need Cin/group and Cout/group to be multiples of 4");
+        in_elems = (size_t)N * ((Cin + 3) / 4) * 4 * H * W;
+        out_elems = (size_t)N * ((Cout + 3) / 4) * 4 * Ho * Wo;
+        w_elems = (size_t)group * q_pad * (Cout / group) * 4;
+    }
+    PL_REQUIRE(out_elems < (1ull << 31) && in_elems < (1ull << 29) && w_elems < (1ull << 29),
                PL_EUNSUPPORTED, "conv2d: input/filter above 2 GiB or output above 2^31 elements");
-    PL_REQUIRE(layout == 0 || (Cin / group) % 16 == 0, PL_EINVAL, "conv2d: tap-major weights need Cin/group %% 16 == 0");
+    PL_REQUIRE(layout != 1 || (Cin / group) % 16 == 0, PL_EINVAL, "conv2d: tap-major weights need Cin/group %% 16 == 0");
     CtxGuard guard(ctx);
 
     ConvArgs a;
@@ -1011,7 +1057,8 @@ int conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const
     a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.Ho = Ho; a.Wo = Wo;
     a.kh = kh; a.kw = kw; a.sh = sh; a.sw = sw; a.dh = dh; a.dw = dw; a.pt = pt; a.pl = pl;
     a.groups = group; a.cin_g = Cin / group; a.cout_g = Cout / group;
-    a.K = a.cin_g * kh * kw;
+    a.K = layout == 2 ? q_tot * 4 : a.cin_g * kh * kw;
+    a.cqg = cqg; a.Cq = (Cin + 3) / 4; a.Coq = (Cout + 3) / 4; a.Qtot = q_tot; a.Qpad = q_pad;
     a.cols = N * Ho * Wo;
     a.HoWo = Ho * Wo; a.HW = H * W;
     a.x_bytes = (int)(in_elems * 4); a.w_bytes = (int)(w_elems * 4);
@@ -1247,6 +1294,71 @@ int pl_conv2d_prepare_weights_f32(pl_ctx *ctx, const float *w, int Cout, int Cin
                                                            FastDiv(kh * kw));
     PL_LAUNCH_CHECK();
     return PL_OK;
+}
+
+int pl_conv2d_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const float *wq, int Cout, int kh,
+                     int kw, const float *bias, float *yq, int sh, int sw, int dh, int dw, int pt, int pl, int pb,
+                     int pr, int group, const float *scale, const float *shift, const float *resq, int act,
+                     double alpha) {
+    PL_REQUIRE(!xq || !yq || ((reinterpret_cast<uintptr_t>(xq) | reinterpret_cast<uintptr_t>(yq) |
+                               reinterpret_cast<uintptr_t>(wq) | reinterpret_cast<uintptr_t>(resq)) & 15u) == 0,
+               PL_EINVAL, "pl_conv2d_q4_f32: Q4 tensors must be 16-byte aligned");
+    return conv_launch(ctx, xq, N, Cin, H, W, wq, Cout, kh, kw, bias, yq, sh, sw, dh, dw, pt, pl, pb, pr, group,
+                       scale, shift, resq, act, alpha, 2);
+}
+
+int pl_conv2d_q4_filter_elems(int Cout, int Cin_g, int kh, int kw, int group, size_t *elems) {
+    PL_REQUIRE(elems && Cout > 0 && Cin_g > 0 && kh > 0 && kw > 0 && group > 0 && Cout % group == 0, PL_EINVAL,
+               "pl_conv2d_q4_filter_elems: bad argument");
+    const size_t q_pad = ((size_t)kh * kw * ((Cin_g + 3) / 4) + 7) / 8 * 8;
+    *elems = (size_t)group * q_pad * (Cout / group) * 4;
+    return PL_OK;
+}
+
+int pl_conv2d_prepare_q4_f32(pl_ctx *ctx, const float *w, int Cout, int Cin_g, int kh, int kw, int group,
+                             float *out) {
+    PL_REQUIRE(ctx && w && out, PL_EINVAL, "pl_conv2d_prepare_q4_f32: null pointer");
+    PL_REQUIRE(Cout > 0 && Cin_g > 0 && kh > 0 && kw > 0 && group > 0 && Cout % group == 0, PL_EINVAL,
+               "pl_conv2d_prepare_q4_f32: bad shape");
+    PL_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15u) == 0, PL_EINVAL, "pl_conv2d_prepare_q4_f32: unaligned output");
+    const int cout_g = Cout / group, cqg = (Cin_g + 3) / 4, q_tot = kh * kw * cqg, q_pad = (q_tot + 7) / 8 * 8;
+    const size_t total = (size_t)group * q_pad * cout_g;       // float4s
+    PL_REQUIRE(total * 4 < (1ull << 29) && (size_t)Cout * Cin_g * kh * kw < (1ull << 31), PL_EUNSUPPORTED,
+               "filter too large");
+    CtxGuard g(ctx);
+    unsigned blocks = (unsigned)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    pack_filter_q4_kernel<<<blocks, 256, 0, ctx->stream>>>(w, out, (unsigned)total, cout_g, Cin_g, kh * kw, cqg, q_tot,
+                                                          q_pad, FastDiv(cout_g), FastDiv(q_pad), FastDiv(cqg));
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
+
+static int q4_convert(pl_ctx *ctx, const float *x, float *y, int N, int C, int HW, bool to_q4) {
+    PL_REQUIRE(ctx && x && y, PL_EINVAL, "q4 layout conversion: null pointer");
+    PL_REQUIRE(N >= 0 && C > 0 && HW > 0, PL_EINVAL, "q4 layout conversion: bad shape");
+    const int Cq = (C + 3) / 4;
+    const size_t total = (size_t)N * Cq * HW;
+    PL_REQUIRE(total < (1ull << 29), PL_EUNSUPPORTED, "q4 layout conversion: tensor above 2 GiB");
+    PL_REQUIRE((reinterpret_cast<uintptr_t>(to_q4 ? y : x) & 15u) == 0, PL_EINVAL,
+               "q4 layout conversion: Q4 tensor must be 16-byte aligned");
+    if (total == 0) return PL_OK;
+    CtxGuard g(ctx);
+    const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 16);
+    if (to_q4)
+        nchw_to_q4_kernel<<<blocks, 256, 0, ctx->stream>>>(x, y, (unsigned)total, C, Cq, HW, FastDiv(HW), FastDiv(Cq));
+    else
+        q4_to_nchw_kernel<<<blocks, 256, 0, ctx->stream>>>(x, y, (unsigned)total, C, Cq, HW, FastDiv(HW), FastDiv(Cq));
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
+
+int pl_nchw_to_q4_f32(pl_ctx *ctx, const float *x, float *yq, int N, int C, int HW) {
+    return q4_convert(ctx, x, yq, N, C, HW, true);
+}
+
+int pl_q4_to_nchw_f32(pl_ctx *ctx, const float *xq, float *y, int N, int C, int HW) {
+    return q4_convert(ctx, xq, y, N, C, HW, false);
 }
 
 // Plans are stored by configuration NAME so a cache survives re-ordering of the table.

@@ -131,13 +131,14 @@ class DeviceArray:
     context pool when it is garbage collected, which is what implements the
     reference's liveness-based freeing of intermediates (net.py:51-53)."""
 
-    __slots__ = ("shape", "dtype", "ptr", "ctx", "base", "host", "_owned", "__weakref__")
+    __slots__ = ("shape", "dtype", "ptr", "ctx", "base", "host", "chan", "_owned", "__weakref__")
 
     def __init__(self, shape, dtype=numpy.float32, ctx=None, ptr=None, base=None, host=None):
         self.shape = tuple(int(s) for s in shape)
         self.dtype = numpy.dtype(dtype)
         self.ctx = ctx or (base.ctx if base is not None else context())
         self.base, self.host, self._owned = base, host, False
+        self.chan = None      # channel-quad (Q4) tensors: logical channel count (planer_amd/q4.py)
         if ptr is None:
             p = c_void_p()
             _lib.call("pl_alloc", self.ctx.handle, max(self.nbytes, 1), byref(p))
@@ -200,7 +201,9 @@ class DeviceArray:
         if not 0 <= lo <= hi <= n:
             raise IndexError((lo, hi))
         step = self.nbytes // n if n else 0
-        return self._view((hi - lo,) + self.shape[1:], lo * step)
+        v = self._view((hi - lo,) + self.shape[1:], lo * step)
+        v.chan = self.chan
+        return v
 
     def __getitem__(self, i):
         """a[i] for an integer i: the i-th slab along axis 0 (net.py:101)."""

@@ -1,0 +1,137 @@
+"""Channel-quad (Q4) layout on a real MI355X: layout conversions are bit-exact, the Q4
+implicit-GEMM conv (every tile configuration, split-K, fused tail, groups, odd channel counts)
+matches the reference vectors / the oracle to 1e-4 of max|ref| (tests/conftest.RTOL)."""
+import numpy as np
+import pytest
+
+from oracle import planer_np as onp
+from tests.cases import layer_cases
+from tests.conftest import RTOL, assert_close
+
+pytestmark = pytest.mark.gpu
+CASES = layer_cases()
+CONV_CASES = [c for c in CASES if c[1] == "conv"]
+
+
+@pytest.fixture(scope="module")
+def pa():
+    import planer_amd
+    planer_amd.hip.context()
+    return planer_amd
+
+
+def q4_host(x):
+    """numpy statement of the layout: (N,C,H,W) -> (N,ceil(C/4),H,W,4), zero padded."""
+    n, c, h, w = x.shape
+    cq = (c + 3) // 4
+    pad = np.zeros((n, cq * 4, h, w), x.dtype)
+    pad[:, :c] = x
+    return np.ascontiguousarray(pad.reshape(n, cq, 4, h, w).transpose(0, 1, 3, 4, 2))
+
+
+@pytest.mark.parametrize("shape", [(2, 1, 5, 7), (1, 3, 9, 4), (3, 4, 6, 6), (2, 5, 3, 11), (2, 64, 7, 7), (1, 255, 13, 13)])
+def test_layout_round_trip_is_bit_exact(pa, shape):
+    from planer_amd import q4
+    x = np.random.default_rng(sum(shape)).standard_normal(shape).astype(np.float32)
+    xq = q4.to_q4(pa.asarray(x))
+    assert xq.chan == shape[1] and xq.shape == q4_host(x).shape
+    np.testing.assert_array_equal(xq.get(), q4_host(x))
+    np.testing.assert_array_equal(q4.from_q4(xq).get(), x)
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_q4_conv_vs_reference_vectors(pa, case, golden_layers):
+    from planer_amd import q4
+    name, kind, args, params = case
+    z, _ = golden_layers
+    ref = z["%s/out0" % name]
+    x, k = args[0], args[1]
+    b = pa.asarray(args[2]) if len(args) > 2 and args[2] is not None else None
+    group = params.get("group", 1)
+    if not q4.q4_conv_eligible(k.shape, **params):
+        with pytest.raises(NotImplementedError):
+            q4.ConvQ4(q4.to_q4(pa.asarray(x)), q4.prepare_q4_weights(pa.asarray(k), group), b, **params)
+        return
+    yq = q4.ConvQ4(q4.to_q4(pa.asarray(x)), q4.prepare_q4_weights(pa.asarray(k), group), b, **params)
+    assert q4.logical_shape(yq) == ref.shape
+    assert_close(q4.from_q4(yq).get(), ref, RTOL, name)
+    # padding lanes of the last quad stay zero (consumers multiply them by zero weights)
+    raw = yq.get()
+    np.testing.assert_array_equal(raw, q4_host(q4.from_q4(yq).get()))
+
+
+def _cfg_names(pa):
+    import ctypes
+    lib = pa._lib.load()
+    names = []
+    for c in range(lib.pl_conv2d_num_configs()):
+        buf = ctypes.create_string_buffer(32)
+        lib.pl_conv2d_config_name(c, buf, 32)
+        names.append(buf.value.decode())
+    return names
+
+
+def test_q4_conv_every_tile_config_and_split_k(pa):
+    from planer_amd import q4
+    ctx = pa.hip.context()
+    names = _cfg_names(pa)
+    qnames = [n for n in names if n.startswith("q")]
+    assert len(qnames) >= 8
+    rng = np.random.default_rng(11)
+    shapes = [((3, 32, 14, 14), (40, 32, 3, 3), dict(strides=[1, 1], pads=[1, 1, 1, 1])),
+              ((2, 3, 33, 35), (20, 3, 7, 7), dict(strides=[2, 2], pads=[3, 3, 3, 3])),
+              ((2, 64, 7, 7), (130, 64, 1, 1), dict(strides=[1, 1], pads=[0, 0, 0, 0])),
+              ((2, 20, 13, 11), (70, 20, 3, 3), dict(strides=[2, 2], pads=[1, 1, 1, 1])),
+              ((2, 6, 10, 9), (9, 6, 3, 5), dict(strides=[1, 2], pads=[1, 2, 1, 2])),
+              ((2, 64, 9, 9), (48, 32, 3, 3), dict(strides=[1, 1], pads=[2, 2, 2, 2], dilations=[2, 2], group=2))]
+    try:
+        for xs, ks, p in shapes:
+            x = rng.standard_normal(xs).astype(np.float32)
+            k = (rng.standard_normal(ks) * 0.1).astype(np.float32)
+            b = rng.standard_normal(ks[0]).astype(np.float32)
+            ref = np.ascontiguousarray(onp.conv2d(x, k, b, **p))
+            xq, db = q4.to_q4(pa.asarray(x)), pa.asarray(b)
+            kq = q4.prepare_q4_weights(pa.asarray(k), p.get("group", 1))
+            for name in qnames:
+                for split in (1, 2, 3):
+                    ctx.set_conv_config(names.index(name), split)
+                    y = q4.from_q4(q4.ConvQ4(xq, kq, db, **p)).get()
+                    assert_close(y, ref, RTOL, "cfg %s split %d %s" % (name, split, xs))
+    finally:
+        ctx.set_conv_config(-1, 0)
+
+
+def test_q4_fused_tail_and_hybrid_plans_are_deterministic(pa):
+    from planer_amd import q4
+    ctx = pa.hip.context()
+    names = _cfg_names(pa)
+    rng = np.random.default_rng(23)
+    for cout in (128, 126):
+        x = rng.standard_normal((8, 64, 28, 28)).astype(np.float32)
+        k = (rng.standard_normal((cout, 64, 3, 3)) * 0.05).astype(np.float32)
+        sc = rng.uniform(0.5, 1.5, (1, cout, 1, 1)).astype(np.float32)
+        sh = rng.standard_normal((1, cout, 1, 1)).astype(np.float32)
+        res = rng.standard_normal((8, cout, 28, 28)).astype(np.float32)
+        ref = onp.relu(onp.batchnorm(np.ascontiguousarray(onp.conv2d(x, k, pads=[1, 1, 1, 1])), sc, sh) + res)
+        xq, kq, rq = q4.to_q4(pa.asarray(x)), q4.prepare_q4_weights(pa.asarray(k)), q4.to_q4(pa.asarray(res))
+        dsc, dsh = pa.asarray(sc), pa.asarray(sh)
+        try:
+            for name, dp, split, occ in [("q64x64x16", 0, 4, 0), ("q64x64x16", 64, 6, 0), ("q128x64x16", 0, 9, 0),
+                                         ("q64x64x32", 128, 2, 4), ("q128x128x16", 0, 1, 0), ("q128x32x32", 8, 5, 2)]:
+                ctx.set_conv_plan(names.index(name), dp, split, occ)
+                first = None
+                for it in range(6):
+                    yq = q4.ConvQ4(xq, kq, None, dsc, dsh, rq, pads=[1, 1, 1, 1], act=1)
+                    y = q4.from_q4(yq).get()
+                    if first is None:
+                        first = y
+                        assert_close(y, ref, RTOL, "%s dp%d s%d" % (name, dp, split))
+                        np.testing.assert_array_equal(yq.get(), q4_host(y))
+                    else:
+                        np.testing.assert_array_equal(y, first)
+        finally:
+            ctx.set_conv_config(-1, 0)
+    # autotuned plan + leaky relu
+    y = q4.from_q4(q4.ConvQ4(xq, kq, None, dsc, dsh, None, pads=[1, 1, 1, 1], act=2, alpha=0.1)).get()
+    ref = onp.leakyrelu(onp.batchnorm(np.ascontiguousarray(onp.conv2d(x, k, pads=[1, 1, 1, 1])), sc, sh), 0.1)
+    assert_close(y, ref, RTOL, "autotuned leaky")
