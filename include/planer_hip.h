@@ -143,6 +143,30 @@ int pl_conv2d_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W,
                      int pb, int pr, int group, const float *scale,
                      const float *shift, const float *resq, int act, double alpha);
 
+/* Winograd F(2x2,3x3) on Q4 tensors for 3x3 / stride 1 / pad 1 / group 1 convs with
+ * Cin % 4 == 0 and Cout % 4 == 0: uq = [16][k-quad][Cout][4] filters made once per
+ * model; float4 input/output transforms around one grouped 1x1 Q4 conv. */
+int pl_conv2d_winograd_q4_filter_elems(int Cout, int Cin, size_t *elems);
+int pl_conv2d_prepare_winograd_q4_f32(pl_ctx *ctx, const float *w, int Cout, int Cin, float *out);
+int pl_conv2d_winograd_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W,
+                              const float *uq, int Cout, const float *bias, float *yq,
+                              const float *scale, const float *shift, const float *resq,
+                              int act, double alpha);
+
+/* HBM-bound layers on Q4 tensors (same semantics as their NCHW namesakes below:
+ * util.pool util.py:79-92, layer.UpSample layer.py:80-82, layer.GlobalAveragePool
+ * layer.py:77-78, layer.BatchNorm layer.py:125-127).  pl_gap_q4_f32 writes a
+ * plain [N][C] array.  Element-wise layers (relu, leakyrelu, add ...) are layout
+ * agnostic and run the ordinary kernels on the padded buffer. */
+int pl_pool2d_q4_f32(pl_ctx *ctx, const float *xq, float *yq, int N, int C, int H, int W,
+                     int kh, int kw, int sh, int sw, int pt, int pl, int pb, int pr,
+                     int mode);
+int pl_upsample_nearest_q4_f32(pl_ctx *ctx, const float *xq, float *yq, int N, int C,
+                               int H, int W, int fh, int fw);
+int pl_gap_q4_f32(pl_ctx *ctx, const float *xq, float *y, int N, int C, int HW);
+int pl_scale_shift_q4_f32(pl_ctx *ctx, const float *xq, float *yq, const float *scale,
+                          const float *shift, int N, int C, int HW);
+
 /* First call for a new conv shape times every applicable tile configuration
  * and remembers the fastest (on by default; PLANER_HIP_AUTOTUNE=0 or 0 here
  * selects the static heuristic). Never runs during graph capture. */

@@ -57,6 +57,13 @@ SIGNATURES = {
     "pl_conv2d_prepare_q4_f32": [_P, _P, _I, _I, _I, _I, _I, _P],
     "pl_conv2d_q4_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P] + [_I] * 9
                         + [_P, _P, _P, _I, c_double],
+    "pl_conv2d_winograd_q4_filter_elems": [_I, _I, POINTER(c_size_t)],
+    "pl_conv2d_prepare_winograd_q4_f32": [_P, _P, _I, _I, _P],
+    "pl_conv2d_winograd_q4_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, c_double],
+    "pl_pool2d_q4_f32": [_P, _P, _P] + [_I] * 13,
+    "pl_upsample_nearest_q4_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I],
+    "pl_gap_q4_f32": [_P, _P, _P, _I, _I, _I],
+    "pl_scale_shift_q4_f32": [_P, _P, _P, _P, _P, _I, _I, _I],
     "pl_set_autotune": [_P, _I],
     "pl_tune_cache_save": [_P, c_char_p],
     "pl_tune_cache_load": [_P, c_char_p, POINTER(c_int)],

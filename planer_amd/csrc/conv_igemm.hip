@@ -64,8 +64,8 @@ struct ConvArgs {
     int splits, k_per_split;    // k_per_split: K elements (generic) or BK-chunks (tap-major)
     int x_bytes, w_bytes;
     // channel-quad (Q4) layout only: input quads per group / in total, output quads in total,
-    // k-quads per group (real / padded)
-    int cqg, Cq, Coq, Qtot, Qpad;
+    // k-quads per group (real / padded), and whether a BK chunk always sits inside one filter tap
+    int cqg, Cq, Coq, Qtot, Qpad, uni;
     FastDiv divKhw, divKw, divHoWo, divWo, divMt, divCpt;
     Epilogue ep;
 };
@@ -780,6 +780,7 @@ int launch_pass(pl_ctx *ctx, ConvArgs a, const CfgInfo &ci, bool avec, int tile_
         const int cps = (total_chunks + splits - 1) / splits;
         splits = (total_chunks + cps - 1) / cps;
         a.k_per_split = cps;
+        a.uni = a.cqg % kg == 0;
         a.divCpt = FastDiv(a.cqg);
     } else if (ci.tap) {
         const int total_chunks = a.K / ci.bk;
@@ -1263,6 +1264,165 @@ int winograd_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, c
     return rc;
 }
 
+// ---- Winograd F(2x2,3x3) on channel-quad tensors ------------------------------------------------
+// Same algebra as above with every scalar replaced by the float4 of a channel quad: the input
+// transform reads x Q4 and writes V as the Q4 tensor (1, 16*Cin, 1, T) = [16*Cin/4][T][4]; the 16
+// GEMMs are ONE grouped (group = 16) 1x1 conv on conv_q4_kernel; the output transform reads
+// M = [16*Cout/4][T][4], applies the fused tail and writes y Q4.  Needs Cin % 4 == 0 and
+// Cout % 4 == 0 (a group may not split a quad).
+__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 f4sum(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// Uq[f][q][co][4] (q = cin/4, zero padded to Qpad quads) = (G g G^T)[f]
+__global__ void __launch_bounds__(256) wino_filter_q4_kernel(const float *w, float *Uq, unsigned total, int Cin,
+                                                             int Cout, int Qpad) {
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;   // (co, c) pair
+    if (i >= total) return;
+    const int co = (int)(i / (unsigned)Cin), c = (int)(i - (unsigned)co * Cin);
+    const float *g = w + (size_t)i * 9;
+    float t[4][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float g0 = g[j], g1 = g[3 + j], g2 = g[6 + j];
+        t[0][j] = g0;
+        t[1][j] = 0.5f * (g0 + g1 + g2);
+        t[2][j] = 0.5f * (g0 - g1 + g2);
+        t[3][j] = g2;
+    }
+    const size_t plane = (size_t)Qpad * Cout * 4;
+    float *up = Uq + ((size_t)(c >> 2) * Cout + co) * 4 + (c & 3);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float a = t[r][0], b = t[r][1], cc = t[r][2];
+        up[(size_t)(r * 4 + 0) * plane] = a;
+        up[(size_t)(r * 4 + 1) * plane] = 0.5f * (a + b + cc);
+        up[(size_t)(r * 4 + 2) * plane] = 0.5f * (a - b + cc);
+        up[(size_t)(r * 4 + 3) * plane] = cc;
+    }
+}
+
+__global__ void __launch_bounds__(256) wino_input_q4_kernel(const float4 *x, float4 *V, const WinoArgs p, int Cq,
+                                                            unsigned total) {
+    const unsigned stride = gridDim.x * 256;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        unsigned cq, t, n, r, ty, tx;
+        p.divT.divmod(i, cq, t);              // i = cq*T + t : consecutive lanes = consecutive tiles
+        p.divTw.divmod(t, r, tx);
+        p.divTh.divmod(r, n, ty);
+        const int h0 = (int)ty * 2 - 1, w0 = (int)tx * 2 - 1;
+        const float4 *xp = x + ((size_t)n * Cq + cq) * p.H * p.W;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 d[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int hi = h0 + a;
+            const bool hok = (unsigned)hi < (unsigned)p.H;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int wi = w0 + b;
+                d[a][b] = (hok && (unsigned)wi < (unsigned)p.W) ? xp[(size_t)hi * p.W + wi] : z;
+            }
+        }
+        float4 m[4][4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            m[0][b] = f4sub(d[0][b], d[2][b]);
+            m[1][b] = f4sum(d[1][b], d[2][b]);
+            m[2][b] = f4sub(d[2][b], d[1][b]);
+            m[3][b] = f4sub(d[1][b], d[3][b]);
+        }
+        const size_t plane = (size_t)Cq * p.T;
+        float4 *vp = V + (size_t)cq * p.T + t;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            vp[(size_t)(a * 4 + 0) * plane] = f4sub(m[a][0], m[a][2]);
+            vp[(size_t)(a * 4 + 1) * plane] = f4sum(m[a][1], m[a][2]);
+            vp[(size_t)(a * 4 + 2) * plane] = f4sub(m[a][2], m[a][1]);
+            vp[(size_t)(a * 4 + 3) * plane] = f4sub(m[a][1], m[a][3]);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) wino_output_q4_kernel(const float4 *M, float4 *y, const WinoArgs p, int Coq,
+                                                             unsigned total) {
+    const unsigned stride = gridDim.x * 256;
+    const float4 *res4 = reinterpret_cast<const float4 *>(p.ep.res);
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        unsigned coq, t, n, r, ty, tx;
+        p.divT.divmod(i, coq, t);             // i = coq*T + t
+        p.divTw.divmod(t, r, tx);
+        p.divTh.divmod(r, n, ty);
+        const size_t plane = (size_t)Coq * p.T;
+        const float4 *mp = M + (size_t)coq * p.T + t;
+        float4 m[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) m[a][b] = mp[(size_t)(a * 4 + b) * plane];
+        float4 s[2][4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            s[0][b] = f4sum(f4sum(m[0][b], m[1][b]), m[2][b]);
+            s[1][b] = f4sub(f4sub(m[1][b], m[2][b]), m[3][b]);
+        }
+        float bs[4], sc[4], sh[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) load_chan_params(p.ep, (int)coq * 4 + e, bs[e], sc[e], sh[e]);   // Cout % 4 == 0
+        const float4 bias = make_float4(bs[0], bs[1], bs[2], bs[3]), scale = make_float4(sc[0], sc[1], sc[2], sc[3]);
+        const float4 shift = make_float4(sh[0], sh[1], sh[2], sh[3]);
+        const int ho = (int)ty * 2, wo = (int)tx * 2;
+        const size_t obase = (((size_t)n * Coq + coq) * p.Ho + ho) * p.Wo + wo;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            if (ho + a >= p.Ho) continue;
+            const float4 y0 = f4sum(f4sum(s[a][0], s[a][1]), s[a][2]);
+            const float4 y1 = f4sub(f4sub(s[a][1], s[a][2]), s[a][3]);
+            const size_t idx = obase + (size_t)a * p.Wo;
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            y[idx] = apply_epilogue4(p.ep, bias, scale, shift, res4 ? res4[idx] : z, 4, y0);
+            if (wo + 1 < p.Wo) y[idx + 1] = apply_epilogue4(p.ep, bias, scale, shift, res4 ? res4[idx + 1] : z, 4, y1);
+        }
+    }
+}
+
+int winograd_q4_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const float *Uq, int Cout,
+                       const float *bias, float *yq, const float *scale, const float *shift, const float *resq,
+                       int act, double alpha) {
+    WinoArgs p;
+    p.N = N; p.C = Cin; p.H = H; p.W = W; p.Cout = Cout; p.Ho = H; p.Wo = W;
+    p.th = (H + 1) / 2; p.tw = (W + 1) / 2; p.T = N * p.th * p.tw;
+    const int Cq = Cin / 4, Coq = Cout / 4;
+    const size_t vin = (size_t)16 * Cin * p.T, vout = (size_t)16 * Cout * p.T;
+    PL_REQUIRE(vin < (1ull << 29) && vout < (1ull << 31) && (size_t)Cq * p.T < (1ull << 32) &&
+                   (size_t)Coq * p.T < (1ull << 32), PL_EUNSUPPORTED, "winograd: tensor too large");
+    p.divT = FastDiv(p.T); p.divTw = FastDiv(p.tw); p.divTh = FastDiv(p.th);
+    p.ep = Epilogue{bias, scale, shift, resq, act, (float)alpha, (float)(1.0 - alpha)};
+    float *V = nullptr, *M = nullptr;
+    int rc = pl_alloc(ctx, vin * sizeof(float), (void **)&V);
+    if (rc != PL_OK) return rc;
+    rc = pl_alloc(ctx, vout * sizeof(float), (void **)&M);
+    if (rc != PL_OK) {
+        pl_free(ctx, V);
+        return rc;
+    }
+    const unsigned cap = (unsigned)(ctx->cu_count > 0 ? ctx->cu_count : 256) * 8;
+    const unsigned tin = (unsigned)((size_t)Cq * p.T), tout = (unsigned)((size_t)Coq * p.T);
+    wino_input_q4_kernel<<<std::min(cap, (tin + 255) / 256), 256, 0, ctx->stream>>>((const float4 *)xq, (float4 *)V, p, Cq, tin);
+    rc = conv_launch(ctx, V, 1, 16 * Cin, 1, p.T, Uq, 16 * Cout, 1, 1, nullptr, M, 1, 1, 1, 1, 0, 0, 0, 0, 16, nullptr,
+                     nullptr, nullptr, PL_ACT_NONE, 0.0, 2);
+    if (rc == PL_OK) {
+        wino_output_q4_kernel<<<std::min(cap, (tout + 255) / 256), 256, 0, ctx->stream>>>((const float4 *)M, (float4 *)yq, p, Coq, tout);
+        hipError_t le = hipGetLastError();
+        if (le != hipSuccess) {
+            pl_set_error("winograd transform launch: %s", hipGetErrorString(le));
+            rc = PL_EHIP;
+        }
+    }
+    pl_free(ctx, M);
+    pl_free(ctx, V);
+    return rc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1305,6 +1465,42 @@ int pl_conv2d_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W,
                PL_EINVAL, "pl_conv2d_q4_f32: Q4 tensors must be 16-byte aligned");
     return conv_launch(ctx, xq, N, Cin, H, W, wq, Cout, kh, kw, bias, yq, sh, sw, dh, dw, pt, pl, pb, pr, group,
                        scale, shift, resq, act, alpha, 2);
+}
+
+int pl_conv2d_winograd_q4_filter_elems(int Cout, int Cin, size_t *elems) {
+    PL_REQUIRE(elems && Cout > 0 && Cin > 0, PL_EINVAL, "pl_conv2d_winograd_q4_filter_elems: bad argument");
+    *elems = (size_t)16 * (((size_t)Cin / 4 + 7) / 8 * 8) * Cout * 4;
+    return PL_OK;
+}
+
+int pl_conv2d_prepare_winograd_q4_f32(pl_ctx *ctx, const float *w, int Cout, int Cin, float *out) {
+    PL_REQUIRE(ctx && w && out, PL_EINVAL, "pl_conv2d_prepare_winograd_q4_f32: null pointer");
+    PL_REQUIRE(Cout > 0 && Cin > 0 && Cin % 4 == 0 && Cout % 4 == 0, PL_EINVAL,
+               "winograd Q4 filters need Cin %% 4 == 0 and Cout %% 4 == 0");
+    const size_t pairs = (size_t)Cout * Cin;
+    size_t elems = 0;
+    pl_conv2d_winograd_q4_filter_elems(Cout, Cin, &elems);
+    PL_REQUIRE(elems < (1ull << 29), PL_EUNSUPPORTED, "filter too large");
+    CtxGuard g(ctx);
+    PL_HIP(hipMemsetAsync(out, 0, elems * sizeof(float), ctx->stream));       // k-quad padding
+    wino_filter_q4_kernel<<<(unsigned)((pairs + 255) / 256), 256, 0, ctx->stream>>>(w, out, (unsigned)pairs, Cin, Cout,
+                                                                                   (Cin / 4 + 7) / 8 * 8);
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
+
+int pl_conv2d_winograd_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const float *uq, int Cout,
+                              const float *bias, float *yq, const float *scale, const float *shift,
+                              const float *resq, int act, double alpha) {
+    PL_REQUIRE(ctx && xq && uq && yq, PL_EINVAL, "pl_conv2d_winograd_q4_f32: null pointer");
+    PL_REQUIRE(N >= 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0 && Cin % 4 == 0 && Cout % 4 == 0, PL_EINVAL,
+               "pl_conv2d_winograd_q4_f32: bad shape (Cin, Cout must be multiples of 4)");
+    PL_REQUIRE(act >= 0 && act <= 2, PL_EINVAL, "pl_conv2d_winograd_q4_f32: bad activation code");
+    PL_REQUIRE(((reinterpret_cast<uintptr_t>(xq) | reinterpret_cast<uintptr_t>(yq) | reinterpret_cast<uintptr_t>(uq) |
+                 reinterpret_cast<uintptr_t>(resq)) & 15u) == 0, PL_EINVAL, "Q4 tensors must be 16-byte aligned");
+    if (N == 0) return PL_OK;
+    CtxGuard guard(ctx);
+    return winograd_q4_launch(ctx, xq, N, Cin, H, W, uq, Cout, bias, yq, scale, shift, resq, act, alpha);
 }
 
 int pl_conv2d_q4_filter_elems(int Cout, int Cin_g, int kh, int kw, int group, size_t *elems) {

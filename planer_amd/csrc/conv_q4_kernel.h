@@ -268,27 +268,63 @@ conv_q4_kernel(const ConvArgs p) {
     float4 breg0[C::B_PASSES], breg1[C::B_PASSES];
     float4 areg0[C::A_PER_THREAD], areg1[C::A_PER_THREAD];
 
-    // Straight-line on purpose: a uniform `if` here becomes a real branch that cuts the hot loop
-    // into basic blocks, and the loads can then no longer be scheduled under the MFMAs.  Every
-    // k-quad derives its own (tap, channel quad) -- scalar ALU work when the k-quad index is
-    // wave-uniform -- and past-the-end quads (K padding) are pushed out of bounds arithmetically.
+    // Where chunk c sits on the K axis.  Common case (p.uni: Cin_g/4 is a multiple of the chunk's
+    // k-quads, so a chunk never straddles two filter taps): the tap position is carried as scalar
+    // state and advanced by compare/select -- the two exact divisions per k-quad that the general
+    // case needs are ~55 scalar instructions per chunk, which a lone wave per SIMD cannot hide
+    // (it issues at most one instruction every 4 cycles; the matrix pipe drains after 64).
+    // General case (small or odd Cin, e.g. the 3->4 channel stem): every k-quad derives its own
+    // (tap, channel quad); past-the-end quads (K padding) are pushed out of bounds arithmetically.
+    int st_c = 0, st_cq0, st_a, st_b;
+    {
+        const int q0 = cbeg * C::KG;
+        const unsigned tap = p.divCpt.div((unsigned)q0);
+        unsigned a, b;
+        p.divKw.divmod(tap, a, b);
+        st_cq0 = q0 - (int)tap * p.cqg;
+        st_a = (int)a;
+        st_b = (int)b;
+    }
     auto load_chunk = [&](int c, float4 (&breg)[C::B_PASSES], float4 (&areg)[C::A_PER_THREAD]) {
         const int q0 = (cbeg + c) * C::KG;                      // first k-quad of the chunk (uniform)
-#pragma unroll
-        for (int ps = 0; ps < C::B_PASSES; ++ps) {
-            const int q = q0 + kg0 + ps * C::KG_PER_PASS;
-            const unsigned tap = p.divCpt.div((unsigned)q);
-            const int cq = q - (int)tap * p.cqg;
-            unsigned a, b;
-            p.divKw.divmod(tap, a, b);
-            const int dy = q < p.Qtot ? (int)a * p.dh : (1 << 15), dx = (int)b * p.dw;   // |hbase| < 2^14
+        if (p.uni) {
+            // chunks are requested in order, each at most one further than the last (c is clamped at the end)
+            const int ncq = st_cq0 + (c - st_c) * C::KG;
+            st_c = c;
+            const bool wrap = ncq >= p.cqg;
+            st_cq0 = wrap ? 0 : ncq;
+            const int nb = st_b + (wrap ? 1 : 0);
+            const bool wb = nb >= p.kw;
+            st_b = wb ? 0 : nb;
+            st_a += wb ? 1 : 0;
+            const int dy = st_a * p.dh, dx = st_b * p.dw;
             const bool ok = (unsigned)(hbase + dy) < (unsigned)p.H && (unsigned)(wbase + dx) < (unsigned)p.W;
-            const int voff = (int)((unsigned)(cbase + dy * p.W + dx) << 4);   // garbage when !ok, never used
-            const int coff = (cq * p.HW) << 4;
-            if constexpr (KG_UNIFORM)      // channel-plane offset is scalar: rides in the soffset operand
-                breg[ps] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? voff : OOB, coff, 0));
-            else
-                breg[ps] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? voff + coff : OOB, 0, 0));
+            const int voff = ok ? (int)((unsigned)(cbase + dy * p.W + dx) << 4) : OOB;
+#pragma unroll
+            for (int ps = 0; ps < C::B_PASSES; ++ps) {
+                const int coff = ((st_cq0 + kg0 + ps * C::KG_PER_PASS) * p.HW) << 4;
+                if constexpr (KG_UNIFORM)      // channel-plane offset is scalar: rides in the soffset operand
+                    breg[ps] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, coff, 0));
+                else
+                    breg[ps] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? voff + coff : OOB, 0, 0));
+            }
+        } else {
+#pragma unroll
+            for (int ps = 0; ps < C::B_PASSES; ++ps) {
+                const int q = q0 + kg0 + ps * C::KG_PER_PASS;
+                const unsigned tap = p.divCpt.div((unsigned)q);
+                const int cq = q - (int)tap * p.cqg;
+                unsigned a, b;
+                p.divKw.divmod(tap, a, b);
+                const int dy = q < p.Qtot ? (int)a * p.dh : (1 << 15), dx = (int)b * p.dw;   // |hbase| < 2^14
+                const bool ok = (unsigned)(hbase + dy) < (unsigned)p.H && (unsigned)(wbase + dx) < (unsigned)p.W;
+                const int voff = (int)((unsigned)(cbase + dy * p.W + dx) << 4);   // garbage when !ok, never used
+                const int coff = (cq * p.HW) << 4;
+                if constexpr (KG_UNIFORM)
+                    breg[ps] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? voff : OOB, coff, 0));
+                else
+                    breg[ps] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? voff + coff : OOB, 0, 0));
+            }
         }
         const int ksoff = (q0 * p.cout_g) << 4;                 // scalar: chunk start along q
 #pragma unroll

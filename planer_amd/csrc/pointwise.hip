@@ -260,6 +260,104 @@ __global__ void __launch_bounds__(TPB) splitk_reduce_kernel(const float *ws, int
     }
 }
 
+// ---- channel-quad (Q4) variants ---------------------------------------------------
+// Same semantics as the kernels above on tensors stored [N][C/4][H][W][4] (include/planer_hip.h):
+// every thread handles one pixel of one channel quad, i.e. one float4 per tap.  Padding lanes of
+// the last quad stay zero: max(-1e4, 0, ...) = 0, 0-sums, and the affine kernel writes them as 0.
+__device__ __forceinline__ float4 f4max(float4 a, float4 b) {
+    return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
+}
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) {
+    return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(TPB) pool2d_q4_kernel(const float4 *x, float4 *y, unsigned total, int H, int W,
+                                                        int Ho, int Wo, int kh, int kw, int sh, int sw, int pt,
+                                                        int pl, FastDiv divWo, FastDiv divHo) {
+    unsigned stride = gridDim.x * TPB;
+    for (unsigned i = blockIdx.x * TPB + threadIdx.x; i < total; i += stride) {
+        unsigned row, ow, nc, oh;
+        divWo.divmod(i, row, ow);
+        divHo.divmod(row, nc, oh);
+        const float4 *xp = x + (size_t)nc * H * W;
+        const float init = MODE == 0 ? -1e4f : 0.f;
+        float4 acc = make_float4(init, init, init, init);
+        const int h0 = (int)oh * sh - pt, w0 = (int)ow * sw - pl;
+        for (int r = 0; r < kh; ++r) {
+            const int hi = h0 + r;
+            const bool hok = (unsigned)hi < (unsigned)H;
+            for (int q = 0; q < kw; ++q) {
+                const int wi = w0 + q;
+                const float4 v = (hok && (unsigned)wi < (unsigned)W) ? xp[(size_t)hi * W + wi] : make_float4(0.f, 0.f, 0.f, 0.f);
+                acc = MODE == 0 ? f4max(v, acc) : f4add(acc, v);
+            }
+        }
+        if (MODE == 1) {
+            const float d = (float)(kh * kw);
+            acc = make_float4(__fdiv_rn(acc.x, d), __fdiv_rn(acc.y, d), __fdiv_rn(acc.z, d), __fdiv_rn(acc.w, d));
+        }
+        y[i] = acc;
+    }
+}
+
+__global__ void __launch_bounds__(TPB) upsample_q4_kernel(const float4 *x, float4 *y, unsigned total, int H, int W,
+                                                          int OH, int OW, FastDiv divOW, FastDiv divOH,
+                                                          FastDiv divFh, FastDiv divFw) {
+    unsigned stride = gridDim.x * TPB;
+    for (unsigned i = blockIdx.x * TPB + threadIdx.x; i < total; i += stride) {
+        unsigned row, ow, nc, oh;
+        divOW.divmod(i, row, ow);
+        divOH.divmod(row, nc, oh);
+        y[i] = x[((size_t)nc * H + divFh.div(oh)) * W + divFw.div(ow)];
+    }
+}
+
+// global average pool: one wave64 per (n, channel quad); output is plain [N][C]
+__global__ void __launch_bounds__(TPB) gap_q4_kernel(const float4 *x, float *y, int rows, int Cq, int C, int inner,
+                                                     float inv) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * TPB + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * TPB) >> 6;
+    for (int r = wave; r < rows; r += nwaves) {
+        const float4 *xp = x + (size_t)r * inner;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = lane; i < inner; i += 64) s = f4add(s, xp[i]);
+        for (int off = 32; off > 0; off >>= 1) {
+            s.x += __shfl_down(s.x, off, 64); s.y += __shfl_down(s.y, off, 64);
+            s.z += __shfl_down(s.z, off, 64); s.w += __shfl_down(s.w, off, 64);
+        }
+        if (lane == 0) {
+            const int n = r / Cq, cq = r - n * Cq;
+            float *yp = y + (size_t)n * C + cq * 4;
+            const int left = C - cq * 4;
+            yp[0] = s.x * inv;
+            if (left > 1) yp[1] = s.y * inv;
+            if (left > 2) yp[2] = s.z * inv;
+            if (left > 3) yp[3] = s.w * inv;
+        }
+    }
+}
+
+// BatchNorm (layer.py:125-127) on a Q4 tensor: y = x*scale[c] + shift[c], two roundings
+__global__ void __launch_bounds__(TPB) affine_q4_kernel(const float4 *x, float4 *y, const float *scale,
+                                                        const float *shift, unsigned total, int C, int Cq,
+                                                        FastDiv divInner, FastDiv divCq) {
+    unsigned stride = gridDim.x * TPB;
+    for (unsigned i = blockIdx.x * TPB + threadIdx.x; i < total; i += stride) {
+        const unsigned plane = divInner.div(i);
+        const int cq = (int)(plane - divCq.div(plane) * (unsigned)Cq);
+        const float4 v = x[i];
+        float r[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = cq * 4 + e;
+            r[e] = c < C ? __fadd_rn(__fmul_rn(r[e], scale[c]), shift[c]) : 0.f;
+        }
+        y[i] = make_float4(r[0], r[1], r[2], r[3]);
+    }
+}
+
 // ---- second-wave operators -----------------------------------
 struct OpMath {
     int op;       // 0 exp 1 log 2 tanh 3 sqrt 4 reciprocal 5 hardsigmoid 6 clip
@@ -536,6 +634,77 @@ int pl_gap_f32(pl_ctx *ctx, const float *x, float *y, int rows, int inner) {
     if (!rows) return PL_OK;
     CtxGuard g(ctx);
     gap_kernel<<<stream_grid(ctx, (size_t)rows * 64), TPB, 0, ctx->stream>>>(x, y, rows, inner, 1.f / (float)inner);
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
+
+int pl_pool2d_q4_f32(pl_ctx *ctx, const float *xq, float *yq, int N, int C, int H, int W, int kh, int kw, int sh,
+                     int sw, int pt, int pl, int pb, int pr, int mode) {
+    PL_REQUIRE(ctx && xq && yq, PL_EINVAL, "pl_pool2d_q4_f32: null argument");
+    PL_REQUIRE(N >= 0 && C > 0 && H > 0 && W > 0 && kh > 0 && kw > 0 && sh > 0 && sw > 0, PL_EINVAL,
+               "pl_pool2d_q4_f32: bad shape");
+    PL_REQUIRE(mode == 0 || mode == 1, PL_EINVAL, "pl_pool2d_q4_f32: mode must be 0 (max) or 1 (avg)");
+    PL_REQUIRE(pt == pb && pl == pr, PL_EUNSUPPORTED, "asymmetric pads are undefined in the reference (util.py:8)");
+    PL_REQUIRE(aligned16(xq) && aligned16(yq), PL_EINVAL, "pl_pool2d_q4_f32: Q4 tensors must be 16-byte aligned");
+    const int Ho = (H + pt + pb - kh + sh) / sh, Wo = (W + pl + pr - kw + sw) / sw;  // util.py:84-85
+    PL_REQUIRE(Ho > 0 && Wo > 0, PL_EINVAL, "pl_pool2d_q4_f32: empty output");
+    const size_t NC = (size_t)N * ((C + 3) / 4), total = NC * Ho * Wo;
+    if (!total) return PL_OK;
+    PL_REQUIRE(total < (1ull << 30) && NC * H * W < (1ull << 30), PL_EUNSUPPORTED, "pool: tensor too large");
+    CtxGuard g(ctx);
+    const unsigned grid = stream_grid(ctx, total);
+    if (mode == 0)
+        pool2d_q4_kernel<0><<<grid, TPB, 0, ctx->stream>>>((const float4 *)xq, (float4 *)yq, (unsigned)total, H, W, Ho, Wo,
+                                                         kh, kw, sh, sw, pt, pl, FastDiv(Wo), FastDiv(Ho));
+    else
+        pool2d_q4_kernel<1><<<grid, TPB, 0, ctx->stream>>>((const float4 *)xq, (float4 *)yq, (unsigned)total, H, W, Ho, Wo,
+                                                         kh, kw, sh, sw, pt, pl, FastDiv(Wo), FastDiv(Ho));
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
+
+int pl_upsample_nearest_q4_f32(pl_ctx *ctx, const float *xq, float *yq, int N, int C, int H, int W, int fh, int fw) {
+    PL_REQUIRE(ctx && xq && yq, PL_EINVAL, "pl_upsample_nearest_q4_f32: null argument");
+    PL_REQUIRE(N >= 0 && C > 0 && H > 0 && W > 0 && fh > 0 && fw > 0, PL_EINVAL, "pl_upsample_nearest_q4_f32: bad shape");
+    PL_REQUIRE(aligned16(xq) && aligned16(yq), PL_EINVAL, "pl_upsample_nearest_q4_f32: Q4 tensors must be 16-byte aligned");
+    const size_t total = (size_t)N * ((C + 3) / 4) * H * fh * W * fw;
+    if (!total) return PL_OK;
+    PL_REQUIRE(total < (1ull << 30), PL_EUNSUPPORTED, "upsample: tensor too large");
+    CtxGuard g(ctx);
+    upsample_q4_kernel<<<stream_grid(ctx, total), TPB, 0, ctx->stream>>>(
+        (const float4 *)xq, (float4 *)yq, (unsigned)total, H, W, H * fh, W * fw, FastDiv(W * fw), FastDiv(H * fh),
+        FastDiv(fh), FastDiv(fw));
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
+
+int pl_gap_q4_f32(pl_ctx *ctx, const float *xq, float *y, int N, int C, int HW) {
+    PL_REQUIRE(ctx && xq && y, PL_EINVAL, "pl_gap_q4_f32: null argument");
+    PL_REQUIRE(N >= 0 && C > 0 && HW > 0, PL_EINVAL, "pl_gap_q4_f32: bad shape");
+    PL_REQUIRE(aligned16(xq), PL_EINVAL, "pl_gap_q4_f32: Q4 tensor must be 16-byte aligned");
+    const int Cq = (C + 3) / 4;
+    const size_t rows = (size_t)N * Cq;
+    if (!rows) return PL_OK;
+    PL_REQUIRE(rows < (1ull << 31), PL_EUNSUPPORTED, "gap: tensor too large");
+    CtxGuard g(ctx);
+    gap_q4_kernel<<<stream_grid(ctx, rows * 64), TPB, 0, ctx->stream>>>((const float4 *)xq, y, (int)rows, Cq, C, HW,
+                                                                     1.f / (float)HW);
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
+
+int pl_scale_shift_q4_f32(pl_ctx *ctx, const float *xq, float *yq, const float *scale, const float *shift, int N,
+                          int C, int HW) {
+    PL_REQUIRE(ctx && xq && yq && scale && shift, PL_EINVAL, "pl_scale_shift_q4_f32: null argument");
+    PL_REQUIRE(N >= 0 && C > 0 && HW > 0, PL_EINVAL, "pl_scale_shift_q4_f32: bad shape");
+    PL_REQUIRE(aligned16(xq) && aligned16(yq), PL_EINVAL, "pl_scale_shift_q4_f32: Q4 tensors must be 16-byte aligned");
+    const int Cq = (C + 3) / 4;
+    const size_t total = (size_t)N * Cq * HW;
+    if (!total) return PL_OK;
+    PL_REQUIRE(total < (1ull << 30), PL_EUNSUPPORTED, "scale_shift: tensor too large");
+    CtxGuard g(ctx);
+    affine_q4_kernel<<<stream_grid(ctx, total), TPB, 0, ctx->stream>>>((const float4 *)xq, (float4 *)yq, scale, shift,
+                                                                   (unsigned)total, C, Cq, FastDiv(HW), FastDiv(Cq));
     PL_LAUNCH_CHECK();
     return PL_OK;
 }

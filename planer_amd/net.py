@@ -26,8 +26,11 @@ import numpy
 from . import _lib
 from . import hip
 from .hip import DeviceArray
+from . import q4 as _q4
 from .layer import layer_map, wrap
-from .plan import fuse_flow
+from .plan import assign_layouts, fuse_flow
+
+_q4.register(layer_map)
 
 _ALIGN = 256
 
@@ -134,6 +137,8 @@ class Net:
         self.use_graph = os.environ.get("PLANER_HIP_GRAPH", "1") != "0"
         self.use_fusion = os.environ.get("PLANER_HIP_FUSE", "1") != "0"
         self.profile = os.environ.get("PLANER_HIP_PROFILE", "0") == "1"
+        # compiled plans keep activations channel-quad (Q4) between layers that have Q4 kernels
+        self.use_q4 = os.environ.get("PLANER_HIP_Q4", "1") != "0"
         # streams: how many sub-batch graphs a forward pass is fanned out to ("auto" measures 1/2/4)
         self.streams = os.environ.get("PLANER_HIP_STREAMS", "auto")
         self._side = []
@@ -276,6 +281,8 @@ class Net:
             body, flow, nfused = fuse_flow(self.layer, self.flow, self.inits, shapes)
         else:
             body, flow, nfused = [list(b) for b in self.layer], [list(f) for f in self.flow], 0
+        if self.use_q4:
+            body, flow, _ = assign_layouts(body, flow, self.inits, shapes)
         if os.environ.get("PLANER_HIP_TAPMAJOR", "1") != "0":
             body, flow = self._prepare_filters(body, flow, shapes)
         return _Program(body, flow), nfused
@@ -293,7 +300,21 @@ class Net:
             name = names[0] if isinstance(names, list) else names
             entry = kinds[name]
             srcs = list(src) if isinstance(src, list) else [src]
-            if entry[1] in ("conv", "conv_fused") and len(srcs) >= 2 and srcs[1] in wmap:
+            if entry[1] == "conv_q4":
+                K = wmap[srcs[1]]
+                group = int(entry[2].get("group", 1))
+                para = {k: v for k, v in entry[2].items() if k in ("group", "strides", "dilations", "pads")}
+                lay = 2
+                if (use_wino and _q4.winograd_q4_eligible(K.shape, **para)
+                        and shapes.get(srcs[0].split("@")[0]) is not None):
+                    lay = self._pick_conv_algo(_q4.ConvQ4, K, srcs, entry[2], shapes, wmap, q4=True)
+                key = "%s@q4g%d" % (srcs[1], group) if lay == 2 else srcs[1] + "@winoq4"
+                if key not in self._extra:
+                    self._extra[key] = (_q4.prepare_q4_weights(K, group) if lay == 2
+                                        else _q4.prepare_winograd_q4_weights(K))
+                srcs[1] = key
+                out_body[name] = [name, "conv_q4", dict(entry[2], w_layout=lay)]
+            elif entry[1] in ("conv", "conv_fused") and len(srcs) >= 2 and srcs[1] in wmap:
                 K = wmap[srcs[1]]
                 if K.ndim == 4 and K.dtype == numpy.float32 and K.shape[1] % 16 == 0:
                     para = {k: v for k, v in entry[2].items() if k in ("group", "strides", "dilations", "pads")}
@@ -308,13 +329,13 @@ class Net:
             out_flow.append([srcs, [name], dst])
         return [out_body[b[0]] for b in body], out_flow
 
-    def _pick_conv_algo(self, ConvFused, K, srcs, para, shapes, wmap):
-        """Time the direct (tap-major implicit GEMM) and the Winograd pipeline for this conv's
-        real shape and epilogue; -> w_layout 1 or 3.  Cached per shape signature."""
+    def _pick_conv_algo(self, ConvFused, K, srcs, para, shapes, wmap, q4=False):
+        """Time the direct implicit GEMM and the Winograd pipeline for this conv's real shape and
+        epilogue; -> w_layout 1 or 3 (NCHW), 2 or 4 (channel-quad).  Cached per shape signature."""
         from .layer import prepare_conv_weights, prepare_winograd_weights
-        xs = tuple(shapes[srcs[0]])
+        xs = tuple(shapes[srcs[0].split("@")[0]])
         has = [i < len(srcs) and srcs[i] != "None" for i in range(2, 6)]       # B, scale, shift, res
-        sig = (xs, tuple(K.shape), tuple(has), para.get("act", 0))
+        sig = (q4, xs, tuple(K.shape), tuple(has), para.get("act", 0))
         if sig in self._algo:
             return self._algo[sig]
         ctx = self.ctx
@@ -323,11 +344,15 @@ class Net:
         chan = hip.zeros((1, cout, 1, 1), numpy.float32, ctx)
         out_shape = (xs[0], cout, xs[2], xs[3])
         res = hip.zeros(out_shape, numpy.float32, ctx) if has[3] else None
+        cands = ((1, prepare_conv_weights), (3, prepare_winograd_weights))
+        if q4:
+            x, res = _q4.to_q4(x), (_q4.to_q4(res) if res is not None else None)
+            cands = ((2, _q4.prepare_q4_weights), (4, _q4.prepare_winograd_q4_weights))
         args = [hip.zeros((cout,), numpy.float32, ctx) if has[0] else None, chan if has[1] else None,
                 chan if has[2] else None, res]
         kw = {k: v for k, v in para.items() if k != "w_layout"}
-        best, best_ms = 1, None
-        for lay, prep in ((1, prepare_conv_weights), (3, prepare_winograd_weights)):
+        best, best_ms = cands[0][0], None
+        for lay, prep in cands:
             try:
                 Kp = prep(K)
                 run = lambda: ConvFused(x, Kp, *args, w_layout=lay, **kw)
@@ -473,7 +498,7 @@ class Net:
         kinds = {b[0]: b[1] for b in prog_body(prog)}
         inplace = set()
         for src, names, dst in prog.flow:
-            if kinds.get(_as_list(names)[0]) in ("relu", "flatten", "identity", "return"):
+            if kinds.get(_as_list(names)[0]) in ("relu", "relu_q4", "flatten", "identity", "return"):
                 inplace.update(_as_list(src))
         _lib.call("pl_capture_begin", ctx.handle)
         try:

@@ -101,3 +101,130 @@ def fuse_flow(layers, flow, init_names, shapes):
             add_layer([name, kind, para])
             out_flow.append([srcs, [name], dst])
     return body, out_flow, nfused
+
+
+# ---- activation layout assignment -------------------------------------------------------------
+# Kinds that have a channel-quad (Q4) kernel besides conv (planer_amd/q4.py).  A step of one of
+# these kinds runs in Q4 when one of its activation inputs already is Q4 -- layouts are "sticky"
+# downstream of a conv -- and everything else reads NCHW, with a conversion step inserted where a
+# value is needed in the layout it was not produced in (converted copies are cached per value).
+Q4_POINTWISE = ("maxpool", "averagepool", "gap", "upsample", "batchnorm", "relu", "leakyrelu", "sigmoid",
+                "add", "concat")
+TO_Q4, FROM_Q4 = "@to_q4", "@from_q4"
+
+
+def _is4d(shapes, key):
+    s = shapes.get(key)
+    return s is not None and len(s) == 4
+
+
+def q4_conv_ok(srcs, para, inits, shapes):
+    """A conv step can take the Q4 kernel: constant 4-D filter (and constant bias / scale / shift),
+    4-D input, symmetric pads, and groups that do not split a channel quad."""
+    if len(srcs) < 2 or srcs[1] not in inits or not _is4d(shapes, srcs[1]) or not _is4d(shapes, srcs[0]):
+        return False
+    if any(k != "None" and k not in inits for k in srcs[2:5]):
+        return False
+    cout, cin_g = shapes[srcs[1]][0], shapes[srcs[1]][1]
+    group = int(para.get("group", 1))
+    pads = list(para.get("pads", (0, 0, 0, 0)))
+    if len(pads) == 4 and (pads[0] != pads[2] or pads[1] != pads[3]):
+        return False
+    return group == 1 or (cin_g % 4 == 0 and (cout // group) % 4 == 0)
+
+
+def _q4_pointwise_ok(kind, srcs, para, inits, shapes):
+    acts = [k for k in srcs if k != "None" and k not in inits]
+    if not acts or not all(_is4d(shapes, k) for k in acts):
+        return False
+    c = shapes[acts[0]][1]
+    if kind == "add":
+        return len(srcs) == 2 and len(acts) == 2 and tuple(shapes[srcs[0]]) == tuple(shapes[srcs[1]])
+    if kind == "concat":
+        return para.get("axis", 0) in (1, -3) and len(acts) == len(srcs) and all(shapes[k][1] % 4 == 0 for k in srcs)
+    if kind == "sigmoid":
+        return c % 4 == 0
+    if kind == "batchnorm":
+        return len(srcs) == 3 and srcs[1] in inits and srcs[2] in inits
+    if kind == "upsample":
+        return len(srcs) == 2 and srcs[1] in inits and para.get("mode", "nearest") == "nearest"
+    return len(acts) == 1
+
+
+def assign_layouts(body, flow, init_names, shapes):
+    """-> (body', flow', number of Q4 steps).  Rewrites conv / conv_fused steps to `conv_q4` and the
+    HBM-bound layers that follow them to their `*_q4` kinds, inserting `to_q4` / `from_q4` steps at
+    the edges.  The program's observable values (its last step's outputs) stay NCHW."""
+    kinds = {name: (kind, para) for name, kind, para in body}
+    inits = set(init_names)
+    steps = expand_steps(flow)
+    q4 = set()          # keys whose primary copy is Q4
+    copies = {}         # (key, layout) -> key of the cached converted copy
+    out_body, out_flow, seen = [], [], set()
+    nq4 = 0
+
+    def add_layer(entry):
+        if entry[0] not in seen:
+            seen.add(entry[0])
+            out_body.append(list(entry))
+
+    def need(key, want_q4):
+        if key == "None" or key in inits or (key in q4) == want_q4:
+            return key
+        ck = copies.get((key, want_q4))
+        if ck is None:
+            ck = key + ("@q4" if want_q4 else "@nchw")
+            conv_name = TO_Q4 if want_q4 else FROM_Q4
+            add_layer([conv_name, conv_name[1:], {}])
+            out_flow.append([[key], [conv_name], ck])
+            copies[(key, want_q4)] = ck
+            if want_q4:
+                q4.add(ck)
+        return ck
+
+    def drop_copies(key):
+        for lay in (True, False):
+            copies.pop((key, lay), None)
+
+    last = len(steps) - 1
+    for i, (srcs, name, dst) in enumerate(steps):
+        kind, para = kinds[name]
+        single = isinstance(dst, str)
+        as_q4 = False
+        if kind in ("conv", "conv_fused") and single and q4_conv_ok(srcs, para, inits, shapes):
+            as_q4 = True
+            full = list(srcs) + ["None"] * (6 - len(srcs))
+            res = full[5]
+            if res != "None" and (res in inits or not _is4d(shapes, res)):
+                as_q4 = False
+            else:
+                args = [need(full[0], True)] + full[1:5] + [need(res, True)]
+                new_kind = "conv_q4"
+        elif kind in Q4_POINTWISE and single and _q4_pointwise_ok(kind, srcs, para, inits, shapes) \
+                and any(k in q4 for k in srcs):
+            as_q4 = True
+            args = [need(k, True) for k in srcs]
+            new_kind = kind + "_q4"
+        if not as_q4:
+            args = [need(k, False) for k in srcs]
+            new_kind = kind
+        if kind == "relu":                       # in place (layer.py:46): cached copies of the input go stale
+            drop_copies(srcs[0])
+        out_key = dst
+        produces_q4 = as_q4 and kind != "gap"
+        if produces_q4 and i == last:
+            out_key = dst + "@q4"                # the program's result is handed back as NCHW below
+        add_layer([name, new_kind, para])
+        out_flow.append([args, [name], out_key])
+        for k in _as_list(dst):
+            q4.discard(k)
+            drop_copies(k)
+        if produces_q4:
+            q4.add(out_key)
+            nq4 += 1
+            if i == last:
+                add_layer([FROM_Q4, FROM_Q4[1:], {}])
+                out_flow.append([[out_key], [FROM_Q4], dst])
+        elif as_q4:
+            nq4 += 1
+    return out_body, out_flow, nq4

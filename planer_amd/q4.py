@@ -76,9 +76,32 @@ def prepare_q4_weights(K, group=1):
     return out
 
 
+def winograd_q4_eligible(k_shape, group=1, strides=(1, 1), dilations=(1, 1), pads=(0, 0, 0, 0), **_):
+    """3x3 / stride 1 / pad 1 / no dilation / no groups, Cin and Cout multiples of 4."""
+    cout, cin_g, kh, kw = k_shape
+    return (kh == 3 and kw == 3 and group == 1 and cin_g % 4 == 0 and cout % 4 == 0 and list(strides) == [1, 1]
+            and list(dilations) == [1, 1] and list(pads) == [1, 1, 1, 1])
+
+
+def prepare_winograd_q4_weights(K):
+    """OIHW 3x3 filters -> Winograd-domain Q4 filters [16][k-quad][Cout][4] (ConvQ4 w_layout=4)."""
+    _f32(K)
+    cout, cin, kh, kw = K.shape
+    if (kh, kw) != (3, 3) or cin % 4 or cout % 4:
+        raise ValueError("winograd Q4 filters need 3x3 kernels, Cin % 4 == 0 and Cout % 4 == 0")
+    n = ctypes.c_size_t()
+    _lib.call("pl_conv2d_winograd_q4_filter_elems", cout, cin, ctypes.byref(n))
+    out = empty((n.value,), ctx=K.ctx)
+    _lib.call("pl_conv2d_prepare_winograd_q4_f32", K.ctx.handle, K.ptr, cout, cin, out.ptr)
+    out.shape = K.shape
+    return out
+
+
 def ConvQ4(xq, Kq, B=None, scale=None, shift=None, resq=None, group=1, strides=(1, 1),
-           dilations=(1, 1), pads=(0, 0, 0, 0), act=ACT_NONE, alpha=0.0, **_):
-    """layer.ConvFused on Q4 tensors: act((conv(x,K)+B)*scale + shift + res), all activations Q4."""
+           dilations=(1, 1), pads=(0, 0, 0, 0), act=ACT_NONE, alpha=0.0, w_layout=2, **_):
+    """layer.ConvFused on Q4 tensors: act((conv(x,K)+B)*scale + shift + res), all activations Q4.
+    w_layout=2: Kq from prepare_q4_weights(); w_layout=4: Winograd filters from
+    prepare_winograd_q4_weights()."""
     _f32(xq, Kq, B, scale, shift, resq)
     if not is_q4(xq) or (resq is not None and not is_q4(resq)):
         raise TypeError("ConvQ4 needs Q4 activations (planer_amd.q4.to_q4)")
@@ -93,8 +116,139 @@ def ConvQ4(xq, Kq, B=None, scale=None, shift=None, resq=None, group=1, strides=(
     y = _new_q4(n, cout, ho, wo, xq.ctx)
     if resq is not None and resq.shape != y.shape:
         raise ValueError("fused residual shape %s != conv output %s" % (resq.shape, y.shape))
+    if w_layout == 4:
+        if not winograd_q4_eligible(Kq.shape, group, strides, dilations, pads):
+            raise ValueError("winograd Q4 filters serve 3x3 / stride 1 / pad 1 / group 1 convs only")
+        _lib.call("pl_conv2d_winograd_q4_f32", xq.ctx.handle, xq.ptr, n, cin, h, w, Kq.ptr, cout, _ptr(B), y.ptr,
+                  _ptr(scale), _ptr(shift), _ptr(resq), int(act), float(alpha))
+        return y
     _lib.call("pl_conv2d_q4_f32", xq.ctx.handle, xq.ptr, n, cin, h, w, Kq.ptr, cout, kh, kw,
               _ptr(B), y.ptr, strides[0], strides[1], dilations[0], dilations[1],
               pads[0], pads[1], pads[2], pads[3], int(group),
               _ptr(scale), _ptr(shift), _ptr(resq), int(act), float(alpha))
     return y
+
+
+# ---- HBM-bound layers on Q4 tensors ---------------------------------------------------------
+def _like(x, shape=None):
+    y = empty(shape or x.shape, ctx=x.ctx)
+    y.chan = x.chan
+    return y
+
+
+def _pool_q4(xq, w, pads, strides, mode):
+    _f32(xq)
+    n, c, h, wd = logical_shape(xq)
+    kh, kw = int(w[0]), int(w[1])
+    sh, sw = int(strides[0]), int(strides[1])
+    pads = [int(p) for p in pads]
+    ho = (h + pads[0] + pads[2] - kh + sh) // sh        # util.py:84
+    wo = (wd + pads[1] + pads[3] - kw + sw) // sw       # util.py:85
+    y = _new_q4(n, c, ho, wo, xq.ctx)
+    _lib.call("pl_pool2d_q4_f32", xq.ctx.handle, xq.ptr, y.ptr, n, c, h, wd, kh, kw, sh, sw,
+              pads[0], pads[1], pads[2], pads[3], mode)
+    return y
+
+
+def MaxpoolQ4(xq, w=(2, 2), pads=(0, 0, 0, 0), strides=(2, 2)):
+    """layer.Maxpool (layer.py:71-72) on a Q4 tensor."""
+    return _pool_q4(xq, w, pads, strides, 0)
+
+
+def AveragePoolQ4(xq, w=(2, 2), pads=(0, 0, 0, 0), strides=(2, 2)):
+    """layer.AveragePool (layer.py:74-75) on a Q4 tensor."""
+    return _pool_q4(xq, w, pads, strides, 1)
+
+
+def GlobalAveragePoolQ4(xq):
+    """layer.GlobalAveragePool (layer.py:77-78): Q4 in, plain (N, C, 1, 1) out."""
+    _f32(xq)
+    n, c, h, w = logical_shape(xq)
+    y = empty((n, c, 1, 1), ctx=xq.ctx)
+    _lib.call("pl_gap_q4_f32", xq.ctx.handle, xq.ptr, y.ptr, n, c, h * w)
+    return y
+
+
+def UpSampleQ4(xq, k, mode="nearest"):
+    """layer.UpSample (layer.py:80-82) on a Q4 tensor."""
+    _f32(xq)
+    if mode != "nearest":
+        raise NotImplementedError("upsample mode %r is not on the HIP path" % mode)
+    kv = _host_values(k)
+    if kv.size == 0:
+        raise ValueError("upsample needs scales (the reference's size-only branch is broken, layer.py:81)")
+    fh, fw = [int(v) for v in kv[-2:].astype(int).tolist()]
+    n, c, h, w = logical_shape(xq)
+    y = _new_q4(n, c, h * fh, w * fw, xq.ctx)
+    _lib.call("pl_upsample_nearest_q4_f32", xq.ctx.handle, xq.ptr, y.ptr, n, c, h, w, fh, fw)
+    return y
+
+
+def BatchNormQ4(xq, K, B):
+    """layer.BatchNorm (layer.py:125-127) on a Q4 tensor (only reached when it could not be fused)."""
+    _f32(xq, K, B)
+    n, c, h, w = logical_shape(xq)
+    if K.size != c or B.size != c:
+        raise ValueError("batchnorm: K/B must hold one value per channel")
+    y = _like(xq)
+    _lib.call("pl_scale_shift_q4_f32", xq.ctx.handle, xq.ptr, y.ptr, K.ptr, B.ptr, n, c, h * w)
+    return y
+
+
+def ReLUQ4(xq):
+    """layer.ReLU (layer.py:44-46): in place on the padded buffer (relu(0) = 0 keeps the padding)."""
+    _lib.call("pl_relu_f32", xq.ctx.handle, xq.ptr, xq.ptr, xq.size)
+    return xq
+
+
+def LeakyReLUQ4(xq, alpha=0.2):
+    y = _like(xq)
+    _lib.call("pl_leakyrelu_f32", xq.ctx.handle, xq.ptr, y.ptr, xq.size, float(alpha))
+    return y
+
+
+def SigmoidQ4(xq):
+    """Only scheduled for C % 4 == 0 (sigmoid(0) = 0.5 would dirty the padding lanes)."""
+    y = _like(xq)
+    _lib.call("pl_sigmoid_f32", xq.ctx.handle, xq.ptr, y.ptr, xq.size)
+    return y
+
+
+def AddQ4(x1, x2):
+    """layer.Add (layer.py:93-95), equal shapes, both Q4."""
+    if not (is_q4(x1) and is_q4(x2)) or x1.shape != x2.shape or x1.chan != x2.chan:
+        raise ValueError("AddQ4 needs two Q4 tensors of one shape")
+    y = _like(x1)
+    _lib.call("pl_add_f32", x1.ctx.handle, x1.ptr, x2.ptr, y.ptr, x1.size)
+    return y
+
+
+def ConcatenateQ4(*xs, axis=1):
+    """layer.Concatenate (layer.py:90-91) along channels; every input needs C % 4 == 0 so that the
+    quads of consecutive inputs abut."""
+    if axis != 1 or any(not is_q4(a) or a.chan % 4 for a in xs):
+        raise ValueError("ConcatenateQ4: channel axis, C % 4 == 0 inputs only")
+    n, _, h, w, _ = xs[0].shape
+    if any(a.shape[0] != n or a.shape[2:] != xs[0].shape[2:] for a in xs):
+        raise ValueError("concat: shapes differ off the axis: %s" % [logical_shape(b) for b in xs])
+    total = sum(a.chan for a in xs)
+    y = _new_q4(n, total, h, w, xs[0].ctx)
+    off, pitch = 0, (total // 4) * h * w * 4
+    for a in xs:
+        width = a.shape[1] * h * w * 4
+        if width and n:
+            _lib.call("pl_copy2d_f32", y.ctx.handle, y.ptr + off * 4, pitch, a.ptr, width, width, n)
+        off += width
+    return y
+
+
+# kind -> Q4 implementation, for plan.assign_layouts (conv kinds are handled by the plan compiler)
+Q4_LAYERS = {"maxpool": MaxpoolQ4, "averagepool": AveragePoolQ4, "gap": GlobalAveragePoolQ4,
+             "upsample": UpSampleQ4, "batchnorm": BatchNormQ4, "relu": ReLUQ4, "leakyrelu": LeakyReLUQ4,
+             "sigmoid": SigmoidQ4, "add": AddQ4, "concat": ConcatenateQ4}
+
+
+def register(layer_map):
+    """Plan-internal kinds (never present in a user's IR)."""
+    layer_map.update({"to_q4": to_q4, "from_q4": from_q4, "conv_q4": ConvQ4})
+    layer_map.update({k + "_q4": f for k, f in Q4_LAYERS.items()})

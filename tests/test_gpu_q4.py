@@ -135,3 +135,58 @@ def test_q4_fused_tail_and_hybrid_plans_are_deterministic(pa):
     y = q4.from_q4(q4.ConvQ4(xq, kq, None, dsc, dsh, None, pads=[1, 1, 1, 1], act=2, alpha=0.1)).get()
     ref = onp.leakyrelu(onp.batchnorm(np.ascontiguousarray(onp.conv2d(x, k, pads=[1, 1, 1, 1])), sc, sh), 0.1)
     assert_close(y, ref, RTOL, "autotuned leaky")
+
+
+def test_winograd_q4_matches_oracle(pa):
+    """Winograd F(2x2,3x3) on Q4 tensors (float4 transforms around one grouped 1x1 Q4 conv), odd and
+    even maps, channel counts that are multiples of 4 but not of 16, with and without the fused tail."""
+    from planer_amd import q4
+    rng = np.random.default_rng(19)
+    for (n, cin, h, w, cout) in [(2, 16, 7, 7, 24), (3, 20, 14, 14, 44), (1, 64, 9, 13, 64), (2, 48, 28, 28, 32)]:
+        x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+        k = (rng.standard_normal((cout, cin, 3, 3)) * 0.1).astype(np.float32)
+        b = rng.standard_normal(cout).astype(np.float32)
+        sc = rng.uniform(0.5, 1.5, (1, cout, 1, 1)).astype(np.float32)
+        sh = rng.standard_normal((1, cout, 1, 1)).astype(np.float32)
+        res = rng.standard_normal((n, cout, h, w)).astype(np.float32)
+        xq = q4.to_q4(pa.asarray(x))
+        U = q4.prepare_winograd_q4_weights(pa.asarray(k))
+        y = q4.from_q4(q4.ConvQ4(xq, U, pa.asarray(b), pads=[1, 1, 1, 1], w_layout=4)).get()
+        ref = np.ascontiguousarray(onp.conv2d(x, k, b, pads=[1, 1, 1, 1]))
+        assert_close(y, ref, RTOL, "winograd q4 %s" % ((n, cin, h, w, cout),))
+        y = q4.from_q4(q4.ConvQ4(xq, U, None, pa.asarray(sc), pa.asarray(sh), q4.to_q4(pa.asarray(res)),
+                                 pads=[1, 1, 1, 1], act=1, w_layout=4)).get()
+        ref = onp.relu(onp.batchnorm(np.ascontiguousarray(onp.conv2d(x, k, pads=[1, 1, 1, 1])), sc, sh) + res)
+        assert_close(y, ref, RTOL, "winograd q4 fused")
+    with pytest.raises(ValueError):
+        q4.ConvQ4(xq, U, pads=[0, 0, 0, 0], w_layout=4)
+
+
+def test_pointwise_q4_layers_match_nchw_kernels(pa):
+    """Every HBM-bound Q4 layer equals its NCHW namesake bit for bit (same arithmetic, other layout);
+    channel counts that are not multiples of 4 keep their padding lanes zero."""
+    from planer_amd import q4
+    rng = np.random.default_rng(5)
+    for c in (3, 8, 13):
+        x = rng.standard_normal((2, c, 12, 10)).astype(np.float32)
+        dx = pa.asarray(x)
+        xq = q4.to_q4(dx)
+        pairs = [(q4.MaxpoolQ4(xq, (3, 3), (1, 1, 1, 1), (2, 2)), pa.Maxpool(dx, (3, 3), (1, 1, 1, 1), (2, 2))),
+                 (q4.MaxpoolQ4(xq), pa.Maxpool(dx)),
+                 (q4.AveragePoolQ4(xq, (2, 2), (0, 0, 0, 0), (2, 2)), pa.AveragePool(dx, (2, 2), (0, 0, 0, 0), (2, 2))),
+                 (q4.UpSampleQ4(xq, np.array([1, 1, 2, 3], np.float32)), pa.UpSample(dx, np.array([1, 1, 2, 3], np.float32))),
+                 (q4.LeakyReLUQ4(xq, 0.1), pa.LeakyReLU(dx, 0.1)),
+                 (q4.AddQ4(xq, q4.to_q4(pa.asarray(x[::-1].copy()))), pa.Add(dx, pa.asarray(x[::-1].copy())))]
+        k = pa.asarray(rng.uniform(0.5, 1.5, (1, c, 1, 1)).astype(np.float32))
+        b = pa.asarray(rng.standard_normal((1, c, 1, 1)).astype(np.float32))
+        pairs.append((q4.BatchNormQ4(xq, k, b), pa.BatchNorm(dx, k, b)))
+        for got, want in pairs:
+            np.testing.assert_array_equal(q4.from_q4(got).get(), want.get())
+            np.testing.assert_array_equal(got.get(), q4_host(want.get()))
+        np.testing.assert_array_equal(q4.GlobalAveragePoolQ4(xq).get(), pa.GlobalAveragePool(dx).get())
+        r = q4.ReLUQ4(q4.to_q4(pa.asarray(x)))
+        np.testing.assert_array_equal(q4.from_q4(r).get(), pa.ReLU(pa.asarray(x.copy())).get())
+    a, b2 = rng.standard_normal((2, 8, 5, 6)).astype(np.float32), rng.standard_normal((2, 12, 5, 6)).astype(np.float32)
+    got = q4.ConcatenateQ4(q4.to_q4(pa.asarray(a)), q4.to_q4(pa.asarray(b2)), axis=1)
+    np.testing.assert_array_equal(q4.from_q4(got).get(), np.concatenate([a, b2], axis=1))
+    np.testing.assert_array_equal(q4.from_q4(q4.SigmoidQ4(q4.to_q4(pa.asarray(a)))).get(), pa.Sigmoid(pa.asarray(a)).get())
