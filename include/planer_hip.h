@@ -41,6 +41,9 @@ extern "C" {
 #define PL_ACT_NONE 0
 #define PL_ACT_RELU 1
 #define PL_ACT_LEAKY 2
+/* OR-ed into an activation code: the fused residual is added AFTER the activation
+ * (conv -> batchnorm -> leakyrelu -> add, the order YOLO-v3's blocks use) instead of before it */
+#define PL_ACT_RES_AFTER 16
 
 typedef struct pl_ctx pl_ctx;     /* one device + one stream + one memory pool */
 typedef struct pl_graph pl_graph; /* a captured forward pass (hipGraphExec)     */
@@ -98,7 +101,8 @@ int pl_conv2d_f32(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W,
 /* Conv2d with the layers that follow it folded into the epilogue, used by
  * the compiled plan:  y = act( (conv(x,w)+bias) * scale[c] + shift[c] + res )
  * i.e. conv -> batchnorm (layer.py:125-127) -> add (layer.py:93-95) ->
- * relu/leakyrelu (layer.py:44-51).  scale/shift/res/bias may each be NULL. */
+ * relu/leakyrelu (layer.py:44-51).  scale/shift/res/bias may each be NULL.
+ * With act | PL_ACT_RES_AFTER:  y = act( (conv+bias)*scale + shift ) + res. */
 int pl_conv2d_fused_f32(pl_ctx *ctx, const float *x, int N, int Cin, int H,
                         int W, const float *w, int Cout, int kh, int kw,
                         const float *bias, float *y, int sh, int sw, int dh,

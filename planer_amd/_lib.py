@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(HERE, "libplaner_hip.so")
 
 PL_OK, PL_EINVAL, PL_EUNSUPPORTED, PL_ENOMEM, PL_EHIP, PL_ERCCL = range(6)
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+ACT_RES_AFTER = 16
 UNIQUE_ID_BYTES = 128
 
 _P = c_void_p

@@ -1022,7 +1022,7 @@ int conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const
     // util.pad only honours pads[0]/pads[1] (util.py:8): anything else is undefined there
     PL_REQUIRE(pt == pb && pl == pr, PL_EUNSUPPORTED, "asymmetric pads are undefined in the reference (util.py:8)");
     PL_REQUIRE(Cin % group == 0 && Cout % group == 0, PL_EUNSUPPORTED, "group must divide Cin and Cout");
-    PL_REQUIRE(act >= 0 && act <= 2, PL_EINVAL, "conv2d: bad activation code");
+    PL_REQUIRE(act >= 0 && (act & 15) <= 2 && (act & ~31) == 0, PL_EINVAL, "conv2d: bad activation code");
     PL_REQUIRE(layout >= 0 && layout <= 3, PL_EINVAL, "conv2d: bad weight layout");
     if (layout == 3) {
         PL_REQUIRE(kh == 3 && kw == 3 && sh == 1 && sw == 1 && dh == 1 && dw == 1 && pt == 1 && pl == 1 && pb == 1 &&
@@ -1066,7 +1066,7 @@ int conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const
     a.divKhw = FastDiv(kh * kw); a.divKw = FastDiv(kw);
     a.divHoWo = FastDiv(a.HoWo); a.divWo = FastDiv(Wo);
     a.divMt = FastDiv(1); a.divCpt = FastDiv(1);
-    a.ep = Epilogue{bias, scale, shift, res, act, (float)alpha, (float)(1.0 - alpha)};
+    a.ep = make_epilogue(bias, scale, shift, res, act, alpha);
     const bool avec = (a.K % 4 == 0) && ((reinterpret_cast<uintptr_t>(w) & 15u) == 0);
 
     // forced configuration (tests / tuning tools): split > 1 means split-K over all tiles
@@ -1236,7 +1236,7 @@ int winograd_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, c
     PL_REQUIRE(vin < (1ull << 29) && vout < (1ull << 31) && (size_t)Cin * p.T < (1ull << 32) &&
                    (size_t)Cout * p.T < (1ull << 32), PL_EUNSUPPORTED, "winograd: tensor too large");
     p.divT = FastDiv(p.T); p.divTw = FastDiv(p.tw); p.divTh = FastDiv(p.th);
-    p.ep = Epilogue{bias, scale, shift, res, act, (float)alpha, (float)(1.0 - alpha)};
+    p.ep = make_epilogue(bias, scale, shift, res, act, alpha);
     float *V = nullptr, *M = nullptr;
     int rc = pl_alloc(ctx, vin * sizeof(float), (void **)&V);
     if (rc != PL_OK) return rc;
@@ -1396,7 +1396,7 @@ int winograd_q4_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int 
     PL_REQUIRE(vin < (1ull << 29) && vout < (1ull << 31) && (size_t)Cq * p.T < (1ull << 32) &&
                    (size_t)Coq * p.T < (1ull << 32), PL_EUNSUPPORTED, "winograd: tensor too large");
     p.divT = FastDiv(p.T); p.divTw = FastDiv(p.tw); p.divTh = FastDiv(p.th);
-    p.ep = Epilogue{bias, scale, shift, resq, act, (float)alpha, (float)(1.0 - alpha)};
+    p.ep = make_epilogue(bias, scale, shift, resq, act, alpha);
     float *V = nullptr, *M = nullptr;
     int rc = pl_alloc(ctx, vin * sizeof(float), (void **)&V);
     if (rc != PL_OK) return rc;
@@ -1495,7 +1495,7 @@ int pl_conv2d_winograd_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int 
     PL_REQUIRE(ctx && xq && uq && yq, PL_EINVAL, "pl_conv2d_winograd_q4_f32: null pointer");
     PL_REQUIRE(N >= 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0 && Cin % 4 == 0 && Cout % 4 == 0, PL_EINVAL,
                "pl_conv2d_winograd_q4_f32: bad shape (Cin, Cout must be multiples of 4)");
-    PL_REQUIRE(act >= 0 && act <= 2, PL_EINVAL, "pl_conv2d_winograd_q4_f32: bad activation code");
+    PL_REQUIRE(act >= 0 && (act & 15) <= 2 && (act & ~31) == 0, PL_EINVAL, "pl_conv2d_winograd_q4_f32: bad activation code");
     PL_REQUIRE(((reinterpret_cast<uintptr_t>(xq) | reinterpret_cast<uintptr_t>(yq) | reinterpret_cast<uintptr_t>(uq) |
                  reinterpret_cast<uintptr_t>(resq)) & 15u) == 0, PL_EINVAL, "Q4 tensors must be 16-byte aligned");
     if (N == 0) return PL_OK;

@@ -67,7 +67,7 @@ __device__ __forceinline__ float4 apply_epilogue4(const Epilogue &e, float4 bias
 #pragma unroll
         for (int i = 0; i < 4; ++i) r[i] = __fadd_rn(r[i], sh[i]);
     }
-    if (e.res) {
+    if (e.res && !e.res_post) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) r[i] = __fadd_rn(r[i], rs[i]);
     }
@@ -77,6 +77,10 @@ __device__ __forceinline__ float4 apply_epilogue4(const Epilogue &e, float4 bias
     } else if (e.act == 2) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) r[i] = leaky_ref(r[i], e.la, e.lb);
+    }
+    if (e.res && e.res_post) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = __fadd_rn(r[i], rs[i]);
     }
     if (valid < 4) {
 #pragma unroll

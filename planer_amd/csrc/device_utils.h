@@ -31,7 +31,14 @@ struct Epilogue {
     const float *bias, *scale, *shift, *res;
     int act;
     float la, lb;  // leakyrelu: alpha, (1-alpha) rounded to fp32 (layer.py:49)
+    int res_post;  // residual is added AFTER the activation (conv->bn->leakyrelu->add, YOLO-v3's blocks)
 };
+
+// act_code = PL_ACT_* optionally OR-ed with PL_ACT_RES_AFTER (16)
+inline Epilogue make_epilogue(const float *bias, const float *scale, const float *shift, const float *res,
+                              int act_code, double alpha) {
+    return Epilogue{bias, scale, shift, res, act_code & 15, (float)alpha, (float)(1.0 - alpha), (act_code >> 4) & 1};
+}
 
 __device__ __forceinline__ float relu_ref(float v) {
     return v > 0.f ? v : __fmul_rn(v, 0.f);  // x*(x>0): negatives -> -0, NaN stays
@@ -45,8 +52,9 @@ __device__ __forceinline__ float apply_epilogue(const Epilogue &e, float v, int 
     if (e.bias) v = __fadd_rn(v, e.bias[c]);
     if (e.scale) v = __fmul_rn(v, e.scale[c]);
     if (e.shift) v = __fadd_rn(v, e.shift[c]);
-    if (e.res) v = __fadd_rn(v, e.res[idx]);
+    if (e.res && !e.res_post) v = __fadd_rn(v, e.res[idx]);
     if (e.act == 1) v = relu_ref(v);
     else if (e.act == 2) v = leaky_ref(v, e.la, e.lb);
+    if (e.res && e.res_post) v = __fadd_rn(v, e.res[idx]);
     return v;
 }

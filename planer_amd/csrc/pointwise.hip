@@ -717,7 +717,7 @@ int pl_splitk_reduce_f32(pl_ctx *ctx, const float *ws, int splits, float *y, int
     if (!total) return PL_OK;
     PL_REQUIRE(total < (1ull << 32), PL_EUNSUPPORTED, "splitk reduce: tensor too large");
     CtxGuard g(ctx);
-    Epilogue ep{bias, scale, shift, res, act, (float)alpha, (float)(1.0 - alpha)};
+    Epilogue ep = make_epilogue(bias, scale, shift, res, act, alpha);
     splitk_reduce_kernel<<<stream_grid(ctx, total), TPB, 0, ctx->stream>>>(ws, splits, total, y, (unsigned)total, C,
                                                                         FastDiv(inner), FastDiv(C), ep);
     PL_LAUNCH_CHECK();

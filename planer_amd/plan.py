@@ -4,13 +4,15 @@ The reference interprets the flow one layer at a time (net.py:37-72).  On
 MI355X the HBM-bound layers that follow a convolution -- folded BatchNorm
 (layer.py:125-127), residual Add (layer.py:93-95), ReLU / LeakyReLU
 (layer.py:44-51) -- cost more than the bytes they compute on, so the plan
-folds each chain  conv -> batchnorm -> [add] -> [relu|leakyrelu]  into the
-conv kernel's epilogue (`conv_fused`).  A link is absorbed only when the
+folds each chain  conv -> batchnorm -> [add] -> [relu|leakyrelu] -> [add]  into
+the conv kernel's epilogue (`conv_fused`; the residual goes before the
+activation in ResNet's blocks and after it in YOLO-v3's, never both).  A link is absorbed only when the
 intermediate tensor has exactly one reader and one writer, so nothing a user
 could observe disappears; the fused step sits where the LAST link of its
 chain was, so a residual operand produced after the conv is still available.
 """
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+ACT_RES_AFTER = 16      # OR-ed into `act`: the residual is added after the activation
 
 
 def _as_list(v):
@@ -48,7 +50,7 @@ def fuse_flow(layers, flow, init_names, shapes):
             continue
         chain, cur, stage = [i], dst, 0
         extra = {"scale": "None", "shift": "None", "res": "None", "act": ACT_NONE, "alpha": 0.0}
-        while stage < 3:
+        while stage < 4:
             r = readers.get(cur, [])
             if len(r) != 1 or writers.get(cur, 0) != 1:
                 break
@@ -65,13 +67,17 @@ def fuse_flow(layers, flow, init_names, shapes):
             if (jkind == "batchnorm" and stage < 1 and len(jsrcs) == 3 and jsrcs[0] == cur
                     and jsrcs[1] in inits and jsrcs[2] in inits):
                 extra["scale"], extra["shift"], stage = jsrcs[1], jsrcs[2], 1
-            elif (jkind == "add" and stage < 2 and len(jsrcs) == 2 and jsrcs.count(cur) == 1
+            elif (jkind == "add" and (stage < 2 or (stage == 3 and extra["res"] == "None"))
+                  and len(jsrcs) == 2 and jsrcs.count(cur) == 1
                   and shapes.get(jsrcs[0]) is not None
                   and tuple(shapes.get(jsrcs[0])) == tuple(shapes.get(jsrcs[1]) or ())):
-                extra["res"], stage = jsrcs[1 - jsrcs.index(cur)], 2
-            elif jkind == "relu":
+                extra["res"] = jsrcs[1 - jsrcs.index(cur)]
+                if stage == 3:
+                    extra["act"] |= ACT_RES_AFTER
+                stage = 2 if stage < 2 else 4
+            elif jkind == "relu" and stage < 3:
                 extra["act"], stage = ACT_RELU, 3
-            elif jkind == "leakyrelu":
+            elif jkind == "leakyrelu" and stage < 3:
                 extra["act"], extra["alpha"], stage = ACT_LEAKY, jpara.get("alpha", 0.2), 3
             else:
                 break

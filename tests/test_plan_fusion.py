@@ -5,7 +5,7 @@ import numpy as np
 
 from oracle import planer_np as onp
 from planer_amd.irgen import customnet, resnet18, yolov3
-from planer_amd.plan import ACT_LEAKY, ACT_RELU, fuse_flow
+from planer_amd.plan import ACT_LEAKY, ACT_RELU, ACT_RES_AFTER, assign_layouts, fuse_flow
 from tests.conftest import assert_close
 
 
@@ -15,12 +15,15 @@ def conv_fused_np(x, K, B=None, scale=None, shift=None, res=None, act=0, alpha=0
         y = y * scale.reshape(1, -1, 1, 1)
     if shift is not None:
         y = y + shift.reshape(1, -1, 1, 1)
-    if res is not None:
+    post, act = act & ACT_RES_AFTER, act & 15
+    if res is not None and not post:
         y = y + res
     if act == ACT_RELU:
         y = onp.relu(y)
     elif act == ACT_LEAKY:
         y = onp.leakyrelu(y, alpha)
+    if res is not None and post:
+        y = y + res
     return y
 
 
@@ -101,10 +104,12 @@ def test_fuse_resnet18():
 
 
 def test_fuse_yolov3():
-    body, flow = _check(yolov3, yolov3.make_input(1, size=64), 144)
+    # darknet's 23 residual adds follow the leakyrelu: folded as "residual after activation"
+    body, flow = _check(yolov3, yolov3.make_input(1, size=64), 144 + 23)
     kinds = [b[1] for b in body]
-    assert kinds.count("conv_fused") == 72 and kinds.count("conv") == 3
-    assert kinds.count("add") == 23          # darknet adds follow a leakyrelu, not a conv
+    assert kinds.count("conv_fused") == 72 and kinds.count("conv") == 3 and "add" not in kinds
+    post = [b for b in body if b[1] == "conv_fused" and b[2]["act"] & ACT_RES_AFTER]
+    assert len(post) == 23 and all(b[2]["act"] & 15 == ACT_LEAKY for b in post)
 
 
 def test_no_fusion_when_intermediate_has_two_readers():
@@ -119,3 +124,59 @@ def test_broadcast_add_is_not_fused():
     flow = [[["x", "K"], ["c"], "t"], [["t", "b"], ["a"], "v"]]
     _, out, nf = fuse_flow(layers, flow, ["K", "b"], {"t": (1, 4, 5, 5), "b": (1, 4, 1, 1)})
     assert nf == 0
+
+
+def test_add_after_activation_needs_a_free_residual_slot():
+    # conv -> add -> relu -> add: the first add takes the residual slot, the second stays a layer
+    layers = [["c", "conv", {}], ["a1", "add", {}], ["r", "relu", {}], ["a2", "add", {}]]
+    flow = [[["x", "K"], ["c"], "t"], [["t", "p"], ["a1"], "u"], ["u", ["r"], "v"], [["v", "q"], ["a2"], "w"]]
+    shp = {k: (1, 4, 5, 5) for k in "tpuvqw"}
+    body, out, nf = fuse_flow(layers, flow, ["K"], shp)
+    assert nf == 2 and [f[1][0] for f in out] == ["c+", "a2"]
+    assert body[0][2]["act"] == ACT_RELU
+
+
+# ---- activation layout assignment (channel-quad plans) ----------------------------------------
+def _layout_program(mod, x):
+    g, b = mod.build()
+    shapes = shapes_of(g, b, x)
+    inits = [i[0] for i in g["inits"]]
+    body, flow, _ = fuse_flow(g["layers"], g["flow"], inits, shapes)
+    body, flow, nq4 = assign_layouts(body, flow, inits, shapes)
+    kinds = {b_[0]: b_[1] for b_ in body}
+    return [(kinds[f[1][0]], f[0], f[2]) for f in flow], nq4
+
+
+def test_layouts_resnet18_one_conversion_in_none_out():
+    steps, nq4 = _layout_program(resnet18, resnet18.make_input(1, size=64))
+    kinds = [k for k, _, _ in steps]
+    assert kinds.count("to_q4") == 1 and kinds[0] == "to_q4" and "from_q4" not in kinds
+    assert kinds.count("conv_q4") == 20 and "conv_fused" not in kinds
+    assert "maxpool_q4" in kinds and "gap_q4" in kinds          # gap hands NCHW to flatten/dense
+    assert kinds[-3:] == ["flatten", "dense", "return"]
+    # residual operands are read in Q4 directly (no conversions around them)
+    assert all(not s.endswith("@nchw") for _, srcs, _ in steps for s in srcs)
+
+
+def test_layouts_yolov3_outputs_are_converted_back():
+    steps, _ = _layout_program(yolov3, yolov3.make_input(1, size=64))
+    kinds = [k for k, _, _ in steps]
+    assert kinds.count("to_q4") == 1
+    assert "upsample_q4" in kinds and "concat_q4" in kinds
+    # the three detection heads (255 channels -> padded quads) come back as NCHW for `return`
+    assert kinds.count("from_q4") == 3 and kinds[-1] == "return"
+    ret = steps[-1][1]
+    assert all(s.endswith("@nchw") for s in ret)
+
+
+def test_layouts_inplace_relu_invalidates_converted_copies():
+    layers = [["c", "conv", {}], ["f", "flatten", {}], ["r", "relu", {}], ["g", "flatten", {}],
+              ["return", "return", {}]]
+    flow = [[["x", "K"], ["c"], "t"], [["t"], ["f"], "a"], [["t"], ["r"], "u"], [["t"], ["g"], "b"],
+            [["a", "b"], ["return"], "plrst"]]
+    shp = {"x": (1, 4, 5, 5), "K": (8, 4, 3, 3), "t": (1, 8, 3, 3), "u": (1, 8, 3, 3)}
+    body, out, _ = assign_layouts(layers, flow, ["K"], shp)
+    kinds = {b_[0]: b_[1] for b_ in body}
+    seq = [kinds[f[1][0]] for f in out]
+    # t is converted for the first flatten, mutated in place by relu_q4, and converted AGAIN for the second
+    assert seq == ["to_q4", "conv_q4", "from_q4", "flatten", "relu_q4", "from_q4", "flatten", "return"]
