@@ -196,7 +196,7 @@ def main():
                           "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "dtype": "f32",
                           "config": {"workload": args.workload, "per_gpu_batch": n, "fused_steps": plan.fused_steps,
-                                     "sub_batch_streams": plan.streams},
+                                     "streams": plan.streams},
                           "conv_tflops_whole_step": round(tot / (ms_per_step * 1e-3) / 1e12, 2),
                           "by_class_ms": {k: round(v["ms"], 4) for k, v in sorted(classes.items())},
                           "pcie_inclusive_images_per_sec": e2e}))
@@ -236,7 +236,7 @@ def main():
                                   "channel-quad activations, fused conv epilogues, hipGraph replay" % n,
                       "global_batch": global_batch, "per_gpu_batch": n, "parallelism": "batch-shard x%d" % world,
                       "weight_bcast_ms": round(bcast_ms, 2), "fused_steps": plan.fused_steps,
-                      "sub_batch_streams": plan.streams,
+                      "streams": plan.streams,
                       "pcie_inclusive_images_per_sec": None if e2e is None else round(e2e, 1),
                       "device": ctx.arch, "cu_count": ctx.cu_count},
            "roofline": roofline}

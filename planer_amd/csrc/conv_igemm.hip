@@ -1249,8 +1249,10 @@ int winograd_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, c
     const unsigned tin = (unsigned)((size_t)Cin * p.T), tout = (unsigned)((size_t)Cout * p.T);
     wino_input_kernel<<<std::min(cap, (tin + 255) / 256), 256, 0, ctx->stream>>>(x, V, p, tin);
     // 16 GEMMs as one grouped 1x1 conv: input (1, 16*Cin, 1, T), filters (16*Cout, Cin, 1, 1), group 16
-    rc = conv_launch(ctx, V, 1, 16 * Cin, 1, p.T, U, 16 * Cout, 1, 1, nullptr, M, 1, 1, 1, 1, 0, 0, 0, 0, 16, nullptr,
-                     nullptr, nullptr, PL_ACT_NONE, 0.0, 1);
+    // (the tile axis is presented as an (N*th) x tw image: a 1x1 conv does not care, and it keeps both
+    // extents under the kernel's 14-bit spatial limit)
+    rc = conv_launch(ctx, V, 1, 16 * Cin, N * p.th, p.tw, U, 16 * Cout, 1, 1, nullptr, M, 1, 1, 1, 1, 0, 0, 0, 0, 16,
+                     nullptr, nullptr, nullptr, PL_ACT_NONE, 0.0, 1);
     if (rc == PL_OK) {
         wino_output_kernel<<<std::min(cap, (tout + 255) / 256), 256, 0, ctx->stream>>>(M, y, p, tout);
         hipError_t le = hipGetLastError();
@@ -1408,8 +1410,8 @@ int winograd_q4_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int 
     const unsigned cap = (unsigned)(ctx->cu_count > 0 ? ctx->cu_count : 256) * 8;
     const unsigned tin = (unsigned)((size_t)Cq * p.T), tout = (unsigned)((size_t)Coq * p.T);
     wino_input_q4_kernel<<<std::min(cap, (tin + 255) / 256), 256, 0, ctx->stream>>>((const float4 *)xq, (float4 *)V, p, Cq, tin);
-    rc = conv_launch(ctx, V, 1, 16 * Cin, 1, p.T, Uq, 16 * Cout, 1, 1, nullptr, M, 1, 1, 1, 1, 0, 0, 0, 0, 16, nullptr,
-                     nullptr, nullptr, PL_ACT_NONE, 0.0, 2);
+    rc = conv_launch(ctx, V, 1, 16 * Cin, N * p.th, p.tw, Uq, 16 * Cout, 1, 1, nullptr, M, 1, 1, 1, 1, 0, 0, 0, 0, 16,
+                     nullptr, nullptr, nullptr, PL_ACT_NONE, 0.0, 2);
     if (rc == PL_OK) {
         wino_output_q4_kernel<<<std::min(cap, (tout + 255) / 256), 256, 0, ctx->stream>>>((const float4 *)M, (float4 *)yq, p, Coq, tout);
         hipError_t le = hipGetLastError();

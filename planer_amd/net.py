@@ -128,6 +128,47 @@ class _MultiPlan:
             self.ctx.wait_for(c)
 
 
+class _PipelinePlan:
+    """Throughput mode only: R full-batch graphs ("replicas"), each on its own stream, used round
+    robin -- consecutive forward passes run on different streams, so one batch's kernel tails,
+    launch ramps and small kernels hide under the next batch's convs while every kernel keeps the
+    full batch (better tile efficiency than sub-batch graphs).  `outputs` are those of the replica
+    launched last; a replica's buffers are rewritten R launches later."""
+
+    def __init__(self, replicas, ctx, fused_steps):
+        self.replicas, self.ctx, self.fused_steps, self.ms = replicas, ctx, fused_steps, None
+        self.streams = "pipe%d" % len(replicas)
+        self.turn, self.last = 0, replicas[0]
+
+    @property
+    def inputs(self):
+        return self.last.inputs
+
+    @property
+    def outputs(self):
+        return self.last.outputs
+
+    def feed(self, xs):
+        rp = self.replicas[self.turn]
+        for dst, a in zip(rp.inputs, xs):
+            _lib.call("pl_d2d", rp.ctx.handle, dst.ptr, a.ptr, dst.nbytes)      # on the replica's stream
+
+    def launch(self, join=True):
+        rp = self.replicas[self.turn]
+        self.turn = (self.turn + 1) % len(self.replicas)
+        self.last = rp
+        if join:
+            rp.ctx.wait_for(self.ctx)
+        rp.launch()
+        if join:
+            self.join()
+
+    def join(self):
+        for rp in self.replicas:
+            if rp.ctx is not self.ctx:
+                self.ctx.wait_for(rp.ctx)
+
+
 class Net:
     def __init__(self, ctx=None):
         self.weights, self.body, self.flow = [], [], []
@@ -365,6 +406,10 @@ class Net:
                 ms = e0.elapsed_ms(e1) / 8
             except (NotImplementedError, ValueError, MemoryError):
                 continue
+            if os.environ.get("PLANER_CONV_TUNE_LOG"):
+                import sys
+                print("[planer_amd] conv %s k%s tail %s: w_layout %d = %.1f us" % (xs, tuple(K.shape), has, lay, ms * 1e3),
+                      file=sys.stderr)
             if best_ms is None or ms < best_ms:
                 best, best_ms = lay, ms
         self._algo[sig] = best
@@ -394,10 +439,16 @@ class Net:
         if want == "auto":
             cands = [(1, 1)] + [(q, p_) for q, p_ in ((2, 2), (2, 4), (4, 4))
                                 if splittable and batch % p_ == 0 and batch // p_ >= 4]
+        elif want.startswith("pipe"):
+            cands = []
         else:
             q, _, p_ = want.partition("x")
             q, p_ = int(q), int(p_ or q)
             cands = [(q, p_) if splittable and p_ >= q >= 1 and batch % p_ == 0 else (1, 1)]
+        # throughput mode may also pipeline whole batches over R streams (R full-batch graphs)
+        pipes = [2, 3] if (mode == "throughput" and want == "auto") else []
+        if want.startswith("pipe"):
+            cands, pipes = [], [int(want[4:] or 2)]
         progs = {}
 
         def program_for(P):
@@ -412,13 +463,25 @@ class Net:
                 progs[P] = self._fuse(sub, self.use_fusion)
             return progs[P]
         best = None
-        for Q, P in cands:
-            prog, nfused = program_for(P)
-            try:
-                cand = self._build_plan(prog, xs, Q, P, nfused)
-            except _NotSplittable:
-                continue
-            if len(cands) == 1:
+        todo = [("sub", c) for c in cands] + [("pipe", r) for r in pipes]
+        for how, c in todo:
+            if how == "sub":
+                Q, P = c
+                prog, nfused = program_for(P)
+                try:
+                    cand = self._build_plan(prog, xs, Q, P, nfused)
+                except _NotSplittable:
+                    continue
+            else:
+                prog, nfused = program_for(1)
+                reps = []
+                for r in range(c):
+                    cx = self._side_context(r)
+                    reps.append(self._capture(prog, [DeviceArray(a.shape, a.dtype, cx).copy_from(a) for a in xs],
+                                              cx, nfused))
+                    ctx.synchronize()
+                cand = _PipelinePlan(reps, ctx, nfused)
+            if len(todo) == 1:
                 best = cand
                 break
             def burst(k):
