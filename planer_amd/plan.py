@@ -157,10 +157,27 @@ def _q4_pointwise_ok(kind, srcs, para, inits, shapes):
     return len(acts) == 1
 
 
-def assign_layouts(body, flow, init_names, shapes):
+# Rough device rates for the go / no-go estimate below: the Q4 conv kernel saves ~15 % of a conv's
+# time at ~100 TFLOP/s; a layout conversion reads and writes its tensor once at ~4 TB/s.
+_Q4_CONV_GAIN_S_PER_FLOP = 0.15 / 100e12
+_CONVERT_S_PER_BYTE = 2.0 / 4e12
+
+
+def _nbytes(shape):
+    n = 4
+    for d in shape:
+        n *= d
+    return n
+
+
+def assign_layouts(body, flow, init_names, shapes, force=False):
     """-> (body', flow', number of Q4 steps).  Rewrites conv / conv_fused steps to `conv_q4` and the
     HBM-bound layers that follow them to their `*_q4` kinds, inserting `to_q4` / `from_q4` steps at
-    the edges.  The program's observable values (its last step's outputs) stay NCHW."""
+    the edges.  The program's observable values (its last step's outputs) stay NCHW.
+
+    Unless `force`, the rewrite is dropped (-> the input program, 0) when the conversions it needs
+    would cost more than the convs gain -- e.g. a lone conv whose large output has to be handed
+    back as NCHW right away."""
     kinds = {name: (kind, para) for name, kind, para in body}
     inits = set(init_names)
     steps = expand_steps(flow)
@@ -174,11 +191,15 @@ def assign_layouts(body, flow, init_names, shapes):
             seen.add(entry[0])
             out_body.append(list(entry))
 
+    est = {"gain": 0.0, "cost": 0.0}
+
     def need(key, want_q4):
         if key == "None" or key in inits or (key in q4) == want_q4:
             return key
         ck = copies.get((key, want_q4))
         if ck is None:
+            if shapes.get(key.split("@")[0]) is not None:
+                est["cost"] += _nbytes(shapes[key.split("@")[0]]) * _CONVERT_S_PER_BYTE
             ck = key + ("@q4" if want_q4 else "@nchw")
             conv_name = TO_Q4 if want_q4 else FROM_Q4
             add_layer([conv_name, conv_name[1:], {}])
@@ -206,6 +227,9 @@ def assign_layouts(body, flow, init_names, shapes):
             else:
                 args = [need(full[0], True)] + full[1:5] + [need(res, True)]
                 new_kind = "conv_q4"
+                if shapes.get(dst) is not None:
+                    k = shapes[srcs[1]]
+                    est["gain"] += 2.0 * (_nbytes(shapes[dst]) / 4) * k[1] * k[2] * k[3] * _Q4_CONV_GAIN_S_PER_FLOP
         elif kind in Q4_POINTWISE and single and _q4_pointwise_ok(kind, srcs, para, inits, shapes) \
                 and any(k in q4 for k in srcs):
             as_q4 = True
@@ -231,6 +255,10 @@ def assign_layouts(body, flow, init_names, shapes):
             if i == last:
                 add_layer([FROM_Q4, FROM_Q4[1:], {}])
                 out_flow.append([[out_key], [FROM_Q4], dst])
+                if shapes.get(dst) is not None:
+                    est["cost"] += _nbytes(shapes[dst]) * _CONVERT_S_PER_BYTE
         elif as_q4:
             nq4 += 1
+    if not force and est["cost"] > est["gain"]:
+        return [list(b) for b in body], [[list(srcs), [name], dst] for srcs, name, dst in steps], 0
     return out_body, out_flow, nq4

@@ -175,8 +175,20 @@ def test_layouts_inplace_relu_invalidates_converted_copies():
     flow = [[["x", "K"], ["c"], "t"], [["t"], ["f"], "a"], [["t"], ["r"], "u"], [["t"], ["g"], "b"],
             [["a", "b"], ["return"], "plrst"]]
     shp = {"x": (1, 4, 5, 5), "K": (8, 4, 3, 3), "t": (1, 8, 3, 3), "u": (1, 8, 3, 3)}
-    body, out, _ = assign_layouts(layers, flow, ["K"], shp)
+    body, out, _ = assign_layouts(layers, flow, ["K"], shp, force=True)
     kinds = {b_[0]: b_[1] for b_ in body}
     seq = [kinds[f[1][0]] for f in out]
     # t is converted for the first flatten, mutated in place by relu_q4, and converted AGAIN for the second
     assert seq == ["to_q4", "conv_q4", "from_q4", "flatten", "relu_q4", "from_q4", "flatten", "return"]
+
+
+def test_layouts_lone_conv_with_a_large_output_stays_nchw():
+    # BASELINE config 2: one 3->64 conv on (8,3,224,224); converting its 103 MB output back would
+    # cost more than the Q4 kernel saves
+    layers = [["c", "conv", {"pads": [1, 1, 1, 1]}]]
+    flow = [[["x", "K", "B"], ["c"], "y"]]
+    shp = {"x": (8, 3, 224, 224), "K": (64, 3, 3, 3), "B": (64,), "y": (8, 64, 224, 224)}
+    body, out, nq4 = assign_layouts(layers, flow, ["K", "B"], shp)
+    assert nq4 == 0 and [b_[1] for b_ in body] == ["conv"] and out == [[["x", "K", "B"], ["c"], "y"]]
+    _, out, nq4 = assign_layouts(layers, flow, ["K", "B"], shp, force=True)
+    assert nq4 == 1 and len(out) == 3
