@@ -96,7 +96,7 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with one process per GPU "
                      "(python -m torch.distributed.run --nproc-per-node %d bench.py ...)" % (args.gpus, args.gpus))
     ctx = planer_amd.hip.context()
-    comm = dist.init(ctx)
+    comm = dist.init(ctx, fallback=True)      # RCCL; same-node file fallback if it cannot come up
 
     # ---- model: graph on every rank, weights from rank 0 by RCCL broadcast -------
     if args.workload == "yolov3":
@@ -112,7 +112,9 @@ def main():
         in_shape, args.batch = (3, 224, 224), (args.batch if args.batch != PER_GPU_BATCH else 8)
     else:
         build, in_shape = resnet18.build, (3, 224, 224)
-    g, blob = build() if rank == 0 else (build()[0], None)
+    # weights come from rank 0 by ONE RCCL broadcast; only the file fallback regenerates the
+    # (seeded) blob on every rank
+    g, blob = build() if (rank == 0 or not comm.device_transport) else (build()[0], None)
     net = planer_amd.Net(ctx)
     net.load_json(g["input"], g["inits"], g["layers"], g["flow"])
     t0 = time.perf_counter()
@@ -235,7 +237,10 @@ def main():
            "config": {"workload": "ResNet-18 planer IR (70 layers), forward, batch %d per GPU, 224x224, fp32, "
                                   "channel-quad activations, fused conv epilogues, hipGraph replay" % n,
                       "global_batch": global_batch, "per_gpu_batch": n, "parallelism": "batch-shard x%d" % world,
-                      "weight_bcast_ms": round(bcast_ms, 2), "fused_steps": plan.fused_steps,
+                      "weight_bcast_ms": round(bcast_ms, 2),
+                      "weight_exchange": ("single process" if world == 1 else "one ncclBroadcast of the uint8 blob (RCCL)"
+                                          if comm.device_transport else "local upload per rank -- " + getattr(comm, "why", "")),
+                      "fused_steps": plan.fused_steps,
                       "streams": plan.streams,
                       "pcie_inclusive_images_per_sec": None if e2e is None else round(e2e, 1),
                       "device": ctx.arch, "cu_count": ctx.cu_count},

@@ -72,6 +72,7 @@ class Communicator:
     """What the sharded path needs from a transport.  `RcclCommunicator` is
     the product; tests drive the same host logic over torch.distributed/gloo."""
     rank, world = 0, 1
+    device_transport = True      # can move device memory between ranks (weight broadcast)
 
     def bcast_device(self, arr, root=0):
         raise NotImplementedError
@@ -142,14 +143,83 @@ class RcclCommunicator(Communicator):
         _lib.load().pl_comm_destroy(self.ctx.handle)
 
 
-def init(ctx=None):
-    """Communicator for this process from the launcher's environment."""
+class FileCommunicator(Communicator):
+    """Same-node fallback when RCCL cannot be brought up: barrier and max-over-ranks go through
+    small files next to the rendezvous file.  It cannot move device memory, so `load_weights`
+    needs the blob on every rank (the callers' weights are seeded and can be regenerated locally);
+    nothing in the forward pass depends on the transport."""
+    device_transport = False
+
+    def __init__(self, rank, world, base=None, timeout=600.0):
+        self.rank, self.world, self.timeout = rank, world, timeout
+        self.base = (base or _rendezvous_path()) + ".fc"
+        self.seq = 0
+
+    def _gather(self, value):
+        self.seq += 1
+        mine = "%s.%d.%d" % (self.base, self.seq, self.rank)
+        tmp = mine + ".tmp"
+        with open(tmp, "w") as f:
+            f.write(repr(float(value)))
+        os.replace(tmp, mine)
+        vals, deadline = [], time.time() + self.timeout
+        for r in range(self.world):
+            path = "%s.%d.%d" % (self.base, self.seq, r)
+            while True:
+                try:
+                    with open(path) as f:
+                        txt = f.read()
+                    if txt:
+                        vals.append(float(txt))
+                        break
+                except OSError:
+                    pass
+                if time.time() > deadline:
+                    raise TimeoutError("rank %d: rank %d never reached collective %d" % (self.rank, r, self.seq))
+                time.sleep(0.002)
+        if self.seq > 2:                       # everyone has passed collective seq-2 by now
+            try:
+                os.remove("%s.%d.%d" % (self.base, self.seq - 2, self.rank))
+            except OSError:
+                pass
+        return vals
+
+    def bcast_device(self, arr, root=0):
+        raise RuntimeError("FileCommunicator cannot broadcast device memory")
+
+    def barrier(self):
+        self._gather(0.0)
+
+    def max_over_ranks(self, value):
+        return max(self._gather(value))
+
+    def load_weights(self, net, blob, root=0):
+        if blob is None:
+            raise ValueError("the file fallback needs the weight blob on every rank")
+        net.load_weights(blob)
+        self.barrier()
+
+
+def init(ctx=None, fallback=False):
+    """Communicator for this process from the launcher's environment.  With `fallback`, a failure
+    to bring RCCL up yields a FileCommunicator (its `.why` says what went wrong) instead of raising."""
     from . import hip
     rank, world, _ = env_world()
     ctx = ctx or hip.context()
     if world == 1:
         return SingleProcess()
-    return RcclCommunicator(ctx, rank, world)
+    if os.environ.get("PLANER_DIST_TRANSPORT") == "file":
+        comm = FileCommunicator(rank, world)
+        comm.why = "PLANER_DIST_TRANSPORT=file"
+        return comm
+    try:
+        return RcclCommunicator(ctx, rank, world)
+    except Exception as e:                    # noqa: BLE001 -- any RCCL / rendezvous failure
+        if not fallback:
+            raise
+        comm = FileCommunicator(rank, world)
+        comm.why = "RCCL unavailable: %s" % (str(e)[:200],)
+        return comm
 
 
 def timed_steps(comm, step, sync, steps, warmup):

@@ -125,3 +125,46 @@ def test_stale_rendezvous_file_is_ignored(tmp_path):
         pass
     assert dist.exchange_bytes(b"y" * 128, 0, path) == b"y" * 128
     assert dist.exchange_bytes(None, 1, path, timeout=5) == b"y" * 128
+
+
+FILE_WORKER = textwrap.dedent("""
+    import os, sys, time
+    sys.path.insert(0, %(root)r)
+    from planer_amd import dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    comm = dist.FileCommunicator(rank, world, base=os.environ["PLANER_RDZV_FILE"], timeout=60)
+    assert not comm.device_transport
+    # many back-to-back collectives: values are per-collective, never mixed up; old files are removed
+    for i in range(40):
+        assert comm.max_over_ranks(rank * 10 + i) == (world - 1) * 10 + i
+        comm.barrier()
+    calls = []
+    def step():
+        calls.append(1); time.sleep(0.01 * (rank + 1))
+    el = dist.timed_steps(comm, step, lambda: None, steps=3, warmup=1)
+    assert len(calls) == 4 and el >= 0.03 * world * 0.9
+    class Net:
+        loaded = None
+        def load_weights(self, blob): self.loaded = blob
+    n = Net(); comm.load_weights(n, b"weights"); assert n.loaded == b"weights"
+    try:
+        comm.load_weights(Net(), None); raise SystemExit("blob-less rank accepted")
+    except ValueError:
+        pass
+    print("rank", rank, "ok", "%%.6f" %% el)
+""")
+
+
+def test_file_communicator_two_ranks(tmp_path):
+    """The same-node fallback used when RCCL cannot be initialised: barrier + MAX over ranks."""
+    script = tmp_path / "fworker.py"
+    script.write_text(FILE_WORKER % {"root": ROOT})
+    env = dict(os.environ, WORLD_SIZE="3", PLANER_RDZV_FILE=str(tmp_path / "rdzv"))
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(3)]
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, o)
+    assert len({o.strip().split()[-1] for o in outs}) == 1          # everyone got the same MAX
+    left = [f for f in os.listdir(tmp_path) if ".fc." in f]
+    assert len(left) <= 3 * 2 + 3                                    # only the last two collectives remain
