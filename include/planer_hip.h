@@ -237,6 +237,16 @@ int pl_softmax_f32(pl_ctx *ctx, const float *x, float *y, int rows, int cols, in
 int pl_reduce_f32(pl_ctx *ctx, const float *x, float *y, int rows, int cols, int op);
 /* Transpose (layer.py:194): y = x.transpose(perm), up to 6 axes */
 int pl_transpose_f32(pl_ctx *ctx, const float *x, float *y, int ndim, const int *shape, const int *perm);
+/* General strided map, up to 6 axes: output index o_d reads input index
+ * t = o_d*step[d] + start[d] (wrap[d]: taken modulo extent[d]; div[d] > 1: only
+ * where t %% div[d] == 0, then t / div[d]) at in_stride[d] elements per index,
+ * and `fill` wherever an axis falls outside [0, extent[d]).  Serves layer.Slice
+ * (layer.py:188-196), constant layer.Pad (:241-245), Tile (:57), Expand
+ * (:198-200), Split (:170-172) and the zero-stuffing + filter flip/transpose of
+ * layer.ConvTranspose2d (:28-34). */
+int pl_strided_map_f32(pl_ctx *ctx, const float *x, float *y, int ndim, const int *out_shape,
+                       const long long *in_stride, const int *start, const int *step,
+                       const int *div, const int *extent, const int *wrap, double fill);
 /* split-K combine + epilogue (internal to conv, exported for tests) */
 int pl_splitk_reduce_f32(pl_ctx *ctx, const float *ws, int splits, float *y,
                          int N, int C, int inner, const float *bias,

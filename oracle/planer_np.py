@@ -304,7 +304,54 @@ def resize(x, roi, k, size=None, mode="nearest", coordinate_transformation_mode=
     return upsample(x, np.asarray(k)[-2:], "nearest")
 
 
-OPS = {"sub": sub, "mul": mul, "div": div, "pow": power, "exp": lambda x: np.exp(x),
+def slice_(x, start, end, axis=None, step=None):
+    """layer.Slice (layer.py:188-196)"""
+    if step is None:
+        step = np.ones(len(start), dtype=np.uint32)
+    if axis is None:
+        axis = np.arange(len(start))
+    start, end, axis, step = [i.tolist() for i in (start, end, axis, step)]
+    slis = [slice(None, None, None)] * x.ndim
+    for s, e, a, st in zip(start, end, axis, step):
+        slis[a] = slice(s, e, st)
+    return x[tuple(slis)]
+
+
+def pad(x, pads, constant_value=0, mode="constant"):
+    """layer.Pad (layer.py:241-245)"""
+    pads = pads.reshape(2, -1).T.tolist()
+    para = {"mode": mode}
+    if mode == "constant":
+        para["constant_values"] = constant_value
+    return np.pad(x, pads, **para)
+
+
+def expand(x, shp):
+    """layer.Expand (layer.py:198-200)"""
+    return np.ones(shp.tolist(), dtype=x.dtype) * x
+
+
+def split(x, split=None, axis=0):
+    """layer.Split (layer.py:170-172): the leading slice is along axis 0 whatever `axis` is"""
+    seg = np.cumsum(np.array(split)).tolist()
+    return np.split(x[:seg[-1]], seg[:-1], axis)
+
+
+def convtranspose2d(x, K, B=None, strides=[2, 2], dilations=[1, 1], pads=[0, 0, 0, 0], output_padding=[0, 0],
+                    group=1):
+    """layer.ConvTranspose2d (layer.py:28-34): zero-stuffed input, flipped + transposed filter,
+    stride-1 Conv2d."""
+    (n, c, h, w), (s1, s2), (d1, d2), (H, W) = x.shape, strides, dilations, K.shape[2:]
+    low_h, high_h = ((H - 1) * d1 - pads[0]), ((H - 1) * d1 - pads[2] + output_padding[0])
+    low_w, high_w = ((W - 1) * d2 - pads[1]), ((W - 1) * d2 - pads[3] + output_padding[1])
+    buf = np.zeros((n, c, (h - 1) * s1 + low_h + high_h + 1, (w - 1) * s2 + low_w + high_w + 1), dtype=x.dtype)
+    buf[:, :, low_h:buf.shape[2] - high_h:s1, low_w:buf.shape[3] - high_w:s2] = x
+    return conv2d(buf, K.transpose(1, 0, 2, 3)[:, :, ::-1, ::-1], B, strides=[1, 1], dilations=dilations, group=group)
+
+
+OPS = {"slice": slice_, "pad": pad, "tile": lambda x, repeat: np.tile(x, repeat.tolist()), "expand": expand,
+       "split": split, "convtranspose": convtranspose2d,
+       "sub": sub, "mul": mul, "div": div, "pow": power, "exp": lambda x: np.exp(x),
        "log": lambda x: np.log(x), "tanh": lambda x: np.tanh(x), "sqrt": lambda x: np.sqrt(x),
        "reciprocal": lambda x: 1 / x, "hardsigmoid": hardsigmoid, "clip": clip,
        "softmax": softmax, "logsoftmax": logsoftmax, "reducesum": _reducer(np.sum),

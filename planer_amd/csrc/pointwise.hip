@@ -462,9 +462,75 @@ __global__ void __launch_bounds__(TPB) transpose_kernel(const float *x, float *y
     }
 }
 
+// General strided map of up to 6 axes: output index o_d reads input index
+//     t = o_d*step_d + start_d;  wrap_d: t mod extent_d;  div_d > 1: needs t % div_d == 0, t /= div_d
+// and takes `fill` whenever an axis lands outside [0, extent_d).  One kernel covers Slice (start /
+// step, negative steps), constant Pad (negative start), Tile (wrap), Expand (stride 0), Split, the
+// zero-stuffing of ConvTranspose2d (div = stride) and its filter flip + transpose (step -1,
+// permuted strides).
+struct MapArgs {
+    int ndim;
+    unsigned oshape[6];
+    long long istride[6];
+    int start[6], step[6], div[6], extent[6], wrap[6];
+    float fill;
+};
+__global__ void __launch_bounds__(TPB) strided_map_kernel(const float *x, float *y, size_t total, MapArgs p) {
+    const size_t stride = (size_t)gridDim.x * TPB;
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < total; i += stride) {
+        size_t rem = i;
+        long long src = 0;
+        bool ok = true;
+        for (int d = p.ndim - 1; d >= 0; --d) {
+            const size_t q = rem / p.oshape[d];
+            const int o = (int)(rem - q * p.oshape[d]);
+            rem = q;
+            int t = o * p.step[d] + p.start[d];
+            if (p.wrap[d]) {
+                t %= p.extent[d];
+                if (t < 0) t += p.extent[d];
+            }
+            if (p.div[d] > 1) {
+                ok = ok && t % p.div[d] == 0;
+                t /= p.div[d];
+            }
+            ok = ok && t >= 0 && t < p.extent[d];
+            src += (long long)t * p.istride[d];
+        }
+        y[i] = ok ? x[src] : p.fill;
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int pl_strided_map_f32(pl_ctx *ctx, const float *x, float *y, int ndim, const int *out_shape,
+                       const long long *in_stride, const int *start, const int *step, const int *div,
+                       const int *extent, const int *wrap, double fill) {
+    PL_REQUIRE(ctx && y && out_shape && in_stride && start && step && div && extent && wrap, PL_EINVAL,
+               "pl_strided_map_f32: null argument");
+    PL_REQUIRE(ndim >= 1 && ndim <= 6, PL_EUNSUPPORTED, "pl_strided_map_f32: 1..6 axes supported, got %d", ndim);
+    MapArgs p;
+    p.ndim = ndim;
+    p.fill = (float)fill;
+    size_t total = 1;
+    for (int d = 0; d < ndim; ++d) {
+        PL_REQUIRE(out_shape[d] >= 0 && extent[d] >= 0 && div[d] >= 1, PL_EINVAL, "pl_strided_map_f32: bad axis %d", d);
+        PL_REQUIRE(!wrap[d] || extent[d] > 0, PL_EINVAL, "pl_strided_map_f32: wrap on an empty axis");
+        p.oshape[d] = (unsigned)out_shape[d];
+        p.istride[d] = in_stride[d];
+        p.start[d] = start[d]; p.step[d] = step[d]; p.div[d] = div[d]; p.extent[d] = extent[d]; p.wrap[d] = wrap[d];
+        total *= (size_t)out_shape[d];
+    }
+    if (!total) return PL_OK;
+    PL_REQUIRE(x, PL_EINVAL, "pl_strided_map_f32: null input");
+    PL_REQUIRE(total < (1ull << 32), PL_EUNSUPPORTED, "pl_strided_map_f32: tensor too large");
+    CtxGuard g(ctx);
+    strided_map_kernel<<<stream_grid(ctx, total), TPB, 0, ctx->stream>>>(x, y, total, p);
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
 
 int pl_unary_f32(pl_ctx *ctx, const float *x, float *y, size_t n, int op, double p0, double p1) {
     PL_REQUIRE(op >= 0 && op <= 6, PL_EINVAL, "pl_unary_f32: bad op %d", op);

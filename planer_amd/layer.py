@@ -510,6 +510,133 @@ def Resize(x, roi, k, size=None, mode="nearest", coordinate_transformation_mode=
     return UpSample(x, numpy.array([1, 1, fh, fw], numpy.float32))
 
 
+# ---- structural operators on the strided-map kernel ------------------------------
+def _contig_strides(shape):
+    st, acc = [], 1
+    for d in reversed(shape):
+        st.append(acc)
+        acc *= d
+    return st[::-1]
+
+
+def _strided_map(x, out_shape, in_stride, start, step, div=None, extent=None, wrap=None, fill=0.0):
+    """y[o] = x[sum_d t_d*in_stride[d]], t_d = o_d*step[d] + start[d] (see pl_strided_map_f32)."""
+    _f32(x)
+    n = len(out_shape)
+    if n > 6:
+        raise NotImplementedError("more than 6 axes are not on the HIP path")
+    if n == 0:
+        out_shape, in_stride, start, step = [1], [0], [0], [0]
+        div, extent, wrap, n = None, [1], None, 1
+        scalar = True
+    else:
+        scalar = False
+    div = div or [1] * n
+    wrap = wrap or [0] * n
+    ci = _lib.c_int * n
+    y = empty(tuple(int(v) for v in out_shape), ctx=x.ctx)
+    _lib.call("pl_strided_map_f32", x.ctx.handle, x.ptr, y.ptr, n, ci(*[int(v) for v in out_shape]),
+              (_lib.ctypes.c_longlong * n)(*[int(v) for v in in_stride]), ci(*[int(v) for v in start]),
+              ci(*[int(v) for v in step]), ci(*[int(v) for v in div]), ci(*[int(v) for v in extent]),
+              ci(*[int(v) for v in wrap]), float(fill))
+    return y.reshape(()) if scalar else y
+
+
+def Slice(x, start, end, axis=None, step=None):
+    """layer.Slice (layer.py:188-196): x[tuple(slices)] with Python slice semantics (negative
+    indices, clamping, negative steps); materialised contiguous."""
+    start = _host_values(start).tolist()
+    end = _host_values(end).tolist()
+    axis = list(range(len(start))) if axis is None else _host_values(axis).tolist()
+    step = [1] * len(start) if step is None else _host_values(step).tolist()
+    nd = x.ndim
+    sl = [slice(None, None, None)] * nd
+    for s_, e_, a_, st_ in zip(start, end, axis, step):
+        sl[int(a_)] = slice(int(s_), int(e_), int(st_))
+    rng = [range(*sl[d].indices(x.shape[d])) for d in range(nd)]
+    return _strided_map(x, [len(r) for r in rng], _contig_strides(x.shape),
+                        [r.start for r in rng], [r.step for r in rng], extent=list(x.shape))
+
+
+def Pad(x, pads, constant_value=0, mode="constant"):
+    """layer.Pad (layer.py:241-245): np.pad(x, pads.reshape(2,-1).T, constant)."""
+    if mode != "constant":
+        raise NotImplementedError("pad mode %r is not on the HIP path" % mode)
+    pv = _host_values(pads).reshape(2, -1).T.astype(int).tolist()
+    if len(pv) != x.ndim or any(b < 0 or a < 0 for b, a in pv):
+        raise ValueError("pad: need one non-negative (before, after) pair per axis")
+    out = [x.shape[d] + pv[d][0] + pv[d][1] for d in range(x.ndim)]
+    return _strided_map(x, out, _contig_strides(x.shape), [-pv[d][0] for d in range(x.ndim)], [1] * x.ndim,
+                        extent=list(x.shape), fill=float(constant_value))
+
+
+def Tile(x, repeat):
+    """layer.Tile (layer.py:57): np.tile(x, repeat)."""
+    rep = [int(v) for v in _host_values(repeat).tolist()]
+    nd = max(len(rep), x.ndim)
+    rep = [1] * (nd - len(rep)) + rep
+    shp = (1,) * (nd - x.ndim) + tuple(x.shape)
+    return _strided_map(x, [shp[d] * rep[d] for d in range(nd)], _contig_strides(shp), [0] * nd, [1] * nd,
+                        extent=list(shp), wrap=[1] * nd)
+
+
+def Expand(x, shp):
+    """layer.Expand (layer.py:198-200): np.ones(shp) * x, i.e. numpy broadcasting of both shapes."""
+    want = [int(v) for v in _host_values(shp).tolist()]
+    out = list(numpy.broadcast_shapes(tuple(want), tuple(x.shape)))
+    nd = len(out)
+    xs = (1,) * (nd - x.ndim) + tuple(x.shape)
+    st = _contig_strides(xs)
+    stride = [0 if xs[d] == 1 else st[d] for d in range(nd)]
+    return _strided_map(x, out, stride, [0] * nd, [0 if xs[d] == 1 else 1 for d in range(nd)],
+                        extent=[max(v, 1) for v in xs])
+
+
+def Split(x, split=None, axis=0):
+    """layer.Split (layer.py:170-172): np.split(x[:seg[-1]], seg[:-1], axis) -- the leading slice is
+    along axis 0 whatever `axis` is, as in the reference."""
+    seg = numpy.cumsum(numpy.array(split)).tolist()
+    lead = min(int(seg[-1]), x.shape[0])
+    shp = (lead,) + tuple(x.shape[1:])
+    axis = axis + x.ndim if axis < 0 else axis
+    bounds = [0] + [int(v) for v in seg[:-1]] + [shp[axis]]
+    outs = []
+    for lo, hi in zip(bounds, bounds[1:]):
+        lo, hi = min(lo, shp[axis]), min(hi, shp[axis])
+        out = list(shp)
+        out[axis] = max(hi - lo, 0)
+        start = [0] * x.ndim
+        start[axis] = lo
+        outs.append(_strided_map(x, out, _contig_strides(x.shape), start, [1] * x.ndim, extent=list(x.shape)))
+    return outs
+
+
+def ConvTranspose2d(x, K, B=None, strides=[2, 2], dilations=[1, 1], pads=[0, 0, 0, 0], output_padding=[0, 0],
+                    group=1):
+    """layer.ConvTranspose2d (layer.py:28-34): scatter x into a zero-stuffed buffer (one strided-map
+    launch), flip + transpose the filter (one launch), then the stride-1 MFMA convolution."""
+    _f32(x, K, B)
+    if group != 1:
+        raise NotImplementedError("convtranspose with group > 1: the reference's filter transpose is only "
+                                  "shape-correct for group = 1 (layer.py:34)")
+    n, c, h, w = x.shape
+    s1, s2 = [int(v) for v in strides]
+    d1, d2 = [int(v) for v in dilations]
+    kh, kw = K.shape[2:]
+    low_h, high_h = (kh - 1) * d1 - pads[0], (kh - 1) * d1 - pads[2] + output_padding[0]
+    low_w, high_w = (kw - 1) * d2 - pads[1], (kw - 1) * d2 - pads[3] + output_padding[1]
+    if min(low_h, high_h, low_w, high_w) < 0:
+        raise NotImplementedError("convtranspose: pads larger than the dilated kernel reach are not on the HIP path")
+    bh, bw = (h - 1) * s1 + low_h + high_h + 1, (w - 1) * s2 + low_w + high_w + 1
+    buf = _strided_map(x, [n, c, bh, bw], _contig_strides(x.shape), [0, 0, -low_h, -low_w], [1, 1, 1, 1],
+                       div=[1, 1, s1, s2], extent=[n, c, h, w])
+    ci, co = K.shape[:2]
+    kst = _contig_strides(K.shape)
+    Kt = _strided_map(K, [co, ci, kh, kw], [kst[1], kst[0], kst[2], kst[3]], [0, 0, kh - 1, kw - 1], [1, 1, -1, -1],
+                      extent=[co, ci, kh, kw])
+    return Conv2d(buf, Kt, B, strides=[1, 1], dilations=[d1, d2])
+
+
 def _missing(kind):
     def op(*a, **k):
         raise NotImplementedError(
@@ -519,8 +646,8 @@ def _missing(kind):
     return op
 
 
-NOT_ON_DEVICE = ["const", "pad", "convtranspose", "tile", "lstm", "shape", "gather", "split",
-                 "constantofshape", "slice", "expand", "cast", "range", "equal", "where", "scatternd",
+NOT_ON_DEVICE = ["const", "lstm", "shape", "gather",
+                 "constantofshape", "cast", "range", "equal", "where", "scatternd",
                  "instancenormalization", "greater", "nonzero", "greaterorequal", "topk", "erf"]
 
 layer_map = {"dense": Dense, "conv": Conv2d, "relu": ReLU, "leakyrelu": LeakyReLU,
@@ -534,7 +661,8 @@ layer_map = {"dense": Dense, "conv": Conv2d, "relu": ReLU, "leakyrelu": LeakyReL
              "softmax": Softmax, "logsoftmax": LogSoftmax, "reducesum": ReduceSum,
              "reducemean": ReduceMean, "reducemax": ReduceMax, "reducemin": ReduceMin,
              "transpose": Transpose, "reshape": Reshape, "squeeze": Squeeze, "unsqueeze": Unsqueeze,
-             "resize": Resize,
+             "resize": Resize, "slice": Slice, "pad": Pad, "tile": Tile, "expand": Expand, "split": Split,
+             "convtranspose": ConvTranspose2d,
              # plan-compiler internal
              "conv_fused": ConvFused}
 layer_map.update({k: _missing(k) for k in NOT_ON_DEVICE})

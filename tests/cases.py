@@ -98,6 +98,27 @@ def layer_cases():
     c.append(("resize_asym_floor", "resize", [_r(461, 1, 2, 4, 4), np.zeros(0, np.float32),
                                               np.array([1, 1, 3, 2], np.float32)],
               {"mode": "nearest", "coordinate_transformation_mode": "asymmetric", "nearest_mode": "floor"}))
+    # ---- structural ops on the strided-map kernel + ConvTranspose2d ----
+    i64 = lambda *v: np.array(v, np.int64)
+    c.append(("slice_basic", "slice", [_r(500, 2, 6, 9, 11), i64(1, 2), i64(5, 9), i64(1, 3), i64(1, 1)], {}))
+    c.append(("slice_step_neg", "slice", [_r(501, 3, 8, 10), i64(0, -2, 1), i64(3, 0, 100), i64(0, 1, 2), i64(2, -3, 4)], {}))
+    c.append(("slice_default_axes", "slice", [_r(502, 5, 7), i64(1, 2), i64(-1, 6)], {}))
+    c.append(("pad_hw", "pad", [_r(510, 2, 3, 5, 6), i64(0, 0, 1, 2, 0, 0, 3, 0)], {}))
+    c.append(("pad_value", "pad", [_r(511, 3, 4), i64(2, 1, 0, 3)], {"constant_value": -1.5}))
+    c.append(("tile_2d", "tile", [_r(520, 3, 5), i64(2, 3)], {}))
+    c.append(("tile_more_reps", "tile", [_r(521, 2, 3), i64(2, 1, 2)], {}))
+    c.append(("expand_channel", "expand", [_r(530, 1, 4, 1, 1), i64(2, 4, 3, 5)], {}))
+    c.append(("expand_lower_rank", "expand", [_r(531, 5), i64(3, 1, 5)], {}))
+    c.append(("split_axis1", "split", [_r(540, 9, 7, 4)], {"split": [2, 4, 1], "axis": 1}))
+    c.append(("split_axis0", "split", [_r(541, 6, 5)], {"split": [1, 3], "axis": 0}))
+    c.append(("convtranspose_k2s2", "convtranspose", [_r(550, 2, 8, 7, 9), _r(551, 8, 6, 2, 2, scale=0.2)], {}))
+    c.append(("convtranspose_k3s2p1_op1_bias", "convtranspose",
+              [_r(552, 1, 16, 6, 5), _r(553, 16, 12, 3, 3, scale=0.1), _r(554, 12)],
+              {"strides": [2, 2], "pads": [1, 1, 1, 1], "output_padding": [1, 1]}))
+    c.append(("convtranspose_k4s2p1", "convtranspose", [_r(555, 2, 4, 5, 5), _r(556, 4, 3, 4, 4, scale=0.2)],
+              {"strides": [2, 2], "pads": [1, 1, 1, 1]}))
+    c.append(("convtranspose_s1_dil2", "convtranspose", [_r(557, 1, 3, 8, 8), _r(558, 3, 5, 3, 3, scale=0.2), _r(559, 5)],
+              {"strides": [1, 1], "dilations": [2, 2]}))
     return c
 
 

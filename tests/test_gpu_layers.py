@@ -22,7 +22,7 @@ def pa():
 def run_hip(pa, kind, args, params):
     dev = [pa.asarray(a.copy()) for a in args]
     out = pa.layer_map[kind](*dev, **params)
-    outs = out if isinstance(out, tuple) else (out,)
+    outs = tuple(out) if isinstance(out, (tuple, list)) else (out,)
     return dev, outs
 
 
@@ -46,7 +46,8 @@ EXACT = ["relu", "leakyrelu_0.1", "leakyrelu_default", "add", "batchnorm", "maxp
          "div_bcast_channel", "sub_scalar_lhs", "mul_scalar_lhs", "div_scalar_lhs", "add_scalar", "sqrt",
          "reciprocal", "hardsigmoid", "hardsigmoid_ab", "clip", "clip_relu6", "reducemax_hw", "reducemin_last",
          "transpose_0231", "transpose_10", "reshape_keep0", "squeeze", "unsqueeze", "resize_nearest_x2",
-         "resize_asym_floor"]
+         "resize_asym_floor", "slice_basic", "slice_step_neg", "slice_default_axes", "pad_hw", "pad_value", "tile_2d",
+         "tile_more_reps", "expand_channel", "expand_lower_rank", "split_axis1", "split_axis0"]
 
 
 @pytest.mark.parametrize("name", EXACT)
@@ -55,7 +56,8 @@ def test_copy_and_compare_ops_are_bit_exact(pa, name, golden_layers):
     z, meta = golden_layers
     _, kind, args, params = [c for c in CASES if c[0] == name][0]
     _, outs = run_hip(pa, kind, args, params)
-    np.testing.assert_array_equal(outs[0].get(), z["%s/out0" % name])
+    for i, o in enumerate(outs):
+        np.testing.assert_array_equal(o.get(), z["%s/out%d" % (name, i)])
 
 
 def _cfg_names(pa):

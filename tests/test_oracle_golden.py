@@ -20,7 +20,7 @@ def test_layer_matches_reference(case, golden_layers):
     ins = [a.copy() for a in args]
     with np.errstate(all="ignore"):
         out = onp.OPS[kind](*ins, **params)
-    outs = out if isinstance(out, tuple) else (out,)
+    outs = tuple(out) if isinstance(out, (tuple, list)) else (out,)
     assert len(outs) == meta[name]["n_out"]
     for i, o in enumerate(outs):
         assert_close(o, z["%s/out%d" % (name, i)], 2e-6, name)

@@ -35,7 +35,7 @@ def run_layers():
         fn = planer.layer_map[kind]
         ins = [a.copy() for a in args]
         out = fn(*ins, **params)
-        outs = out if isinstance(out, tuple) else (out,)
+        outs = tuple(out) if isinstance(out, (tuple, list)) else (out,)
         for i, a in enumerate(args):
             store["%s/in%d" % (name, i)] = a
         for i, o in enumerate(outs):
@@ -115,6 +115,7 @@ def run_nets():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     run_layers()
-    run_nets()
+    if "--layers-only" not in sys.argv:
+        run_nets()
     for f in sorted(os.listdir(OUT)):
         print("%8d  %s" % (os.path.getsize(os.path.join(OUT, f)), f))
