@@ -247,6 +247,18 @@ int pl_transpose_f32(pl_ctx *ctx, const float *x, float *y, int ndim, const int 
 int pl_strided_map_f32(pl_ctx *ctx, const float *x, float *y, int ndim, const int *out_shape,
                        const long long *in_stride, const int *start, const int *step,
                        const int *div, const int *extent, const int *wrap, double fill);
+/* ---- tiled large-image inference: the device side of util.tile (util.py:291-348) ----
+ * pl_resize_hwc_f32: util.resize (util.py:253-269) on an H x W x C image; ra/rs (OH entries) and
+ * ca/cs (OW entries) are the integer sample rows/columns and their fractions, device arrays
+ * computed by the host exactly as the reference does (float32 linspace, clip, floor).
+ * pl_tile_accumulate_f32: one window's result (h x w x C) into the blend buffers at (r0, c0):
+ * buf += rst * wt, count += wt with wt = min(distance to the window border, margin) + 1
+ * (util.py:327-343).  pl_tile_normalise_f32: buf /= count (util.py:344). */
+int pl_resize_hwc_f32(pl_ctx *ctx, const float *x, float *y, int H, int W, int C, int OH, int OW,
+                      const int *ra, const float *rs, const int *ca, const float *cs);
+int pl_tile_accumulate_f32(pl_ctx *ctx, const float *rst, float *buf, float *count, int h, int w,
+                           int C, int r0, int c0, int OH, int OW, int margin);
+int pl_tile_normalise_f32(pl_ctx *ctx, float *buf, const float *count, int OH, int OW, int C);
 /* split-K combine + epilogue (internal to conv, exported for tests) */
 int pl_splitk_reduce_f32(pl_ctx *ctx, const float *ws, int splits, float *y,
                          int N, int C, int inner, const float *bias,

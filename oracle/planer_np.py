@@ -367,6 +367,86 @@ OPS = {"slice": slice_, "pad": pad, "tile": lambda x, repeat: np.tile(x, repeat.
 
 
 # --------------------------------------------------------------------------
+# tiled large-image inference (util.py:236-348), SURVEY section 8(f) row F4
+# --------------------------------------------------------------------------
+def image_resize(img, size):
+    """util.resize (util.py:253-269): separable bilinear on an H x W (x C) image."""
+    d, (h, w) = img.ndim, img.shape[:2]
+    kh, kw = size[0] / h, size[1] / w
+    rs = np.linspace(-0.5 + 0.5 / kh, h - 0.5 - 0.5 / kh, size[0], dtype=np.float32)
+    cs = np.linspace(-0.5 + 0.5 / kw, w - 0.5 - 0.5 / kw, size[1], dtype=np.float32)
+    rs = np.clip(rs, 0, h - 1, out=rs)
+    cs = np.clip(cs, 0, w - 1, out=cs)
+    ra = np.floor(np.clip(rs, 0, h - 1.001)).astype(int)
+    ca = np.floor(np.clip(cs, 0, w - 1.001)).astype(int)
+    rs -= ra
+    cs -= ca
+    rb, cb = ra + 1, ca + 1
+    rs.shape, cs.shape = (-1, 1, 1)[:d], (1, -1, 1)[:d]
+    buf = img[:, ca] * (1 - cs) + img[:, cb] * cs
+    return buf[ra, :] * (1 - rs) + buf[rb, :] * rs
+
+
+def make_slice(l, w, mar):
+    """util.make_slice (util.py:236-238)"""
+    import math
+    r = np.linspace(0, l - w, math.ceil((l - mar) / (w - mar)))
+    return [slice(i, i + w) for i in r.astype(int).tolist()]
+
+
+def grid_slice(H, W, h, w, mar):
+    """util.grid_slice (util.py:240-242)"""
+    import itertools
+    return list(itertools.product(make_slice(H, h, mar), make_slice(W, w, mar)))
+
+
+def tile(f, img, sample=1, glob=1, window=1024, margin=0.1):
+    """util.tile (util.py:291-348) applied to `f` and one image (the decorator's body)."""
+    from math import ceil
+    h, w = img.shape[:2]
+    img = img.astype("float32")
+    ssz = list(sample) if isinstance(sample, tuple) else [int(h * sample), int(w * sample)]
+    wsz = wsh = wsw = window
+    if wsh > ssz[0]:
+        wsh = ssz[0] = ceil(ssz[0] / glob) * glob
+    if wsw > ssz[1]:
+        wsw = ssz[1] = ceil(ssz[1] / glob) * glob
+    if ssz != [h, w]:
+        img = image_resize(img, ssz)
+    mar = int(wsz * margin) if isinstance(margin, float) else margin
+    rcs = grid_slice(*ssz, wsh, wsw, mar)
+    rst = f(img[rcs[0]])
+    k = rst.shape[0] / (rcs[0][0].stop - rcs[0][0].start)
+    if len(rcs) == 1:
+        return image_resize(rst, (int(h * k), int(w * k))) if ssz != [h, w] else rst
+
+    def sk(ss):
+        return (slice(int(ss[0].start * k), int(ss[0].stop * k)), slice(int(ss[1].start * k), int(ss[1].stop * k)))
+    outshp = (int(img.shape[0] * k), int(img.shape[1] * k)) + rst.shape[2:]
+    weights = np.zeros(rst.shape[:2], dtype="uint16")
+    if rst.ndim == 3:
+        weights = weights[:, :, None]
+    weights += int(mar * k) + 1
+    for i in range(int(mar * k), 0, -1):
+        weights[i - 1, :] = weights[-i, :] = i
+        weights[:, i - 1] = weights[:, -i] = i
+    buf = np.zeros(outshp, dtype=np.float32)
+    count = np.zeros(outshp[:2], dtype="uint16")
+    if rst.ndim == 3:
+        count = count[:, :, None]
+    buf[sk(rcs[0])] = rst * weights
+    count[sk(rcs[0])] += weights
+    for i in range(1, len(rcs)):
+        rst = f(img[rcs[i]])
+        buf[sk(rcs[i])] += rst * weights
+        count[sk(rcs[i])] += weights
+    np.divide(buf, count, out=buf, casting="unsafe")
+    if ssz != [h, w]:
+        buf = image_resize(buf, (int(h * k), int(w * k)))
+    return buf.astype(rst.dtype)
+
+
+# --------------------------------------------------------------------------
 # graph interpreter (net.py) and loader (io.py)
 # --------------------------------------------------------------------------
 class OracleNet:

@@ -11,6 +11,7 @@ library; the first device operation loads it and raises loudly if it is
 missing -- there is no CPU fallback inside this package.
 """
 from . import hip
+from . import util  # noqa: F401  (tile / resize: tiled large-image inference, util.py:253-348)
 from .hip import DeviceArray
 from .io import from_graph, read_net
 from .layer import *  # noqa: F401,F403  (Conv2d, Dense, ..., layer_map, wrap)

@@ -90,6 +90,9 @@ SIGNATURES = {
     "pl_transpose_f32": [_P, _P, _P, _I, POINTER(c_int), POINTER(c_int)],
     "pl_strided_map_f32": [_P, _P, _P, _I, POINTER(c_int), POINTER(ctypes.c_longlong), POINTER(c_int), POINTER(c_int),
                            POINTER(c_int), POINTER(c_int), POINTER(c_int), c_double],
+    "pl_resize_hwc_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P],
+    "pl_tile_accumulate_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I],
+    "pl_tile_normalise_f32": [_P, _P, _P, _I, _I, _I],
     "pl_splitk_reduce_f32": [_P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _I, c_double],
     "pl_comm_unique_id": [_P],
     "pl_comm_init_rank": [_P, _I, _I, _P],

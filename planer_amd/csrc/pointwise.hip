@@ -501,9 +501,92 @@ __global__ void __launch_bounds__(TPB) strided_map_kernel(const float *x, float 
     }
 }
 
+// ---- tiled large-image inference (util.tile, util.py:291-348) -----------------------------------
+// util.resize (util.py:253-269) on an H x W x C image: separable bilinear with the reference's
+// order of roundings -- columns first: a*(1-cs) + b*cs, then rows on those.  The sample positions
+// (ra, rs, ca, cs) are computed on the host exactly like the reference's float32 linspace.
+__global__ void __launch_bounds__(TPB) resize_hwc_kernel(const float *x, float *y, unsigned total, int W, int C,
+                                                         int OW, const int *ra, const float *rs, const int *ca,
+                                                         const float *cs, FastDiv divC, FastDiv divOW) {
+    const unsigned stride = gridDim.x * TPB;
+    for (unsigned i = blockIdx.x * TPB + threadIdx.x; i < total; i += stride) {
+        unsigned pix, ch, oh, ow;
+        divC.divmod(i, pix, ch);
+        divOW.divmod(pix, oh, ow);
+        const int r0 = ra[oh], c0 = ca[ow];
+        const float fr = rs[oh], fc = cs[ow];
+        const float gc = __fsub_rn(1.f, fc), gr = __fsub_rn(1.f, fr);
+        const float *p0 = x + ((size_t)r0 * W + c0) * C + ch, *p1 = p0 + (size_t)W * C;
+        const float top = __fadd_rn(__fmul_rn(p0[0], gc), __fmul_rn(p0[C], fc));
+        const float bot = __fadd_rn(__fmul_rn(p1[0], gc), __fmul_rn(p1[C], fc));
+        y[i] = __fadd_rn(__fmul_rn(top, gr), __fmul_rn(bot, fr));
+    }
+}
+
+// One window's result into the blend buffers (util.py:333-343): weight = distance to the window
+// border + 1, capped at m + 1;  buf += rst * weight, count += weight.  Launches for overlapping
+// windows are ordered by the stream.
+__global__ void __launch_bounds__(TPB) tile_accumulate_kernel(const float *rst, float *buf, float *count, unsigned total,
+                                                              int h, int w, int C, int r0, int c0, int OW, int m,
+                                                              FastDiv divC, FastDiv divW) {
+    const unsigned stride = gridDim.x * TPB;
+    for (unsigned i = blockIdx.x * TPB + threadIdx.x; i < total; i += stride) {
+        unsigned pix, ch, r, c;
+        divC.divmod(i, pix, ch);
+        divW.divmod(pix, r, c);
+        const int dr = min((int)r, h - 1 - (int)r), dc = min((int)c, w - 1 - (int)c);
+        const float wt = (float)(min(min(dr, dc), m) + 1);
+        const size_t o = (size_t)(r0 + (int)r) * OW + (c0 + (int)c);
+        buf[o * C + ch] = __fadd_rn(buf[o * C + ch], __fmul_rn(rst[i], wt));
+        if (ch == 0) count[o] = __fadd_rn(count[o], wt);
+    }
+}
+
+__global__ void __launch_bounds__(TPB) tile_normalise_kernel(float *buf, const float *count, unsigned total, FastDiv divC) {
+    const unsigned stride = gridDim.x * TPB;
+    for (unsigned i = blockIdx.x * TPB + threadIdx.x; i < total; i += stride) buf[i] = __fdiv_rn(buf[i], count[divC.div(i)]);
+}
+
 }  // namespace
 
 extern "C" {
+
+int pl_resize_hwc_f32(pl_ctx *ctx, const float *x, float *y, int H, int W, int C, int OH, int OW, const int *ra,
+                      const float *rs, const int *ca, const float *cs) {
+    PL_REQUIRE(ctx && x && y && ra && rs && ca && cs, PL_EINVAL, "pl_resize_hwc_f32: null argument");
+    PL_REQUIRE(H > 1 && W > 1 && C > 0 && OH > 0 && OW > 0, PL_EINVAL, "pl_resize_hwc_f32: bad shape (needs H, W >= 2)");
+    const size_t total = (size_t)OH * OW * C;
+    PL_REQUIRE(total < (1ull << 32) && (size_t)H * W * C < (1ull << 32), PL_EUNSUPPORTED, "resize: image too large");
+    CtxGuard g(ctx);
+    resize_hwc_kernel<<<stream_grid(ctx, total), TPB, 0, ctx->stream>>>(x, y, (unsigned)total, W, C, OW, ra, rs, ca, cs,
+                                                                     FastDiv(C), FastDiv(OW));
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
+
+int pl_tile_accumulate_f32(pl_ctx *ctx, const float *rst, float *buf, float *count, int h, int w, int C, int r0, int c0,
+                           int OH, int OW, int margin) {
+    PL_REQUIRE(ctx && rst && buf && count, PL_EINVAL, "pl_tile_accumulate_f32: null argument");
+    PL_REQUIRE(h > 0 && w > 0 && C > 0 && r0 >= 0 && c0 >= 0 && r0 + h <= OH && c0 + w <= OW && margin >= 0, PL_EINVAL,
+               "pl_tile_accumulate_f32: window outside the output");
+    const size_t total = (size_t)h * w * C;
+    PL_REQUIRE(total < (1ull << 32), PL_EUNSUPPORTED, "tile: window too large");
+    CtxGuard g(ctx);
+    tile_accumulate_kernel<<<stream_grid(ctx, total), TPB, 0, ctx->stream>>>(rst, buf, count, (unsigned)total, h, w, C, r0,
+                                                                          c0, OW, margin, FastDiv(C), FastDiv(w));
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
+
+int pl_tile_normalise_f32(pl_ctx *ctx, float *buf, const float *count, int OH, int OW, int C) {
+    PL_REQUIRE(ctx && buf && count && OH > 0 && OW > 0 && C > 0, PL_EINVAL, "pl_tile_normalise_f32: bad argument");
+    const size_t total = (size_t)OH * OW * C;
+    PL_REQUIRE(total < (1ull << 32), PL_EUNSUPPORTED, "tile: image too large");
+    CtxGuard g(ctx);
+    tile_normalise_kernel<<<stream_grid(ctx, total), TPB, 0, ctx->stream>>>(buf, count, (unsigned)total, FastDiv(C));
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
 
 int pl_strided_map_f32(pl_ctx *ctx, const float *x, float *y, int ndim, const int *out_shape,
                        const long long *in_stride, const int *start, const int *step, const int *div,

@@ -127,3 +127,22 @@ def sample_index(size, count=4096, seed=12345):
     if size <= count:
         return np.arange(size)
     return np.sort(np.random.default_rng(seed).choice(size, count, replace=False))
+
+
+def tile_cases():
+    """(name, image, K, B, upsample factor of f, tile kwargs): scenarios for util.tile (util.py:291-348).
+    f(window) = relu(conv3x3(window) + B) [-> nearest upsample], returned as H x W x Cout."""
+    return [
+        # many windows, no resampling, float margin
+        ("tile_gray_multi", _r(600, 150, 170), _r(601, 3, 1, 3, 3, scale=0.3), _r(602, 3), 1,
+         dict(sample=1, window=64, margin=0.1)),
+        # resample up by 1.5, f doubles the resolution (k = 2), integer margin, colour image
+        ("tile_rgb_resample_k2", _r(610, 90, 110, 3), _r(611, 2, 3, 3, 3, scale=0.3), _r(612, 2), 2,
+         dict(sample=1.5, window=64, margin=8)),
+        # smaller than the window: grown to a multiple of glob, one window, result resized back
+        ("tile_small_glob", _r(620, 40, 50), _r(621, 2, 1, 3, 3, scale=0.3), _r(622, 2), 1,
+         dict(sample=1, window=64, glob=16, margin=0.1)),
+        # explicit target size
+        ("tile_size_tuple", _r(630, 70, 61, 2), _r(631, 2, 2, 3, 3, scale=0.3), _r(632, 2), 1,
+         dict(sample=(100, 96), window=48, margin=0.2)),
+    ]

@@ -49,6 +49,25 @@ def run_layers():
     print("layers.npz:", len(meta), "cases")
 
 
+def run_tile():
+    """util.tile (util.py:291-348) around a small conv function, run by the reference."""
+    from planer import util as rutil
+    from tests.cases import tile_cases
+    store = {}
+    for name, img, K, B, up, kw in tile_cases():
+        def f(win):
+            x = win[None, None] if win.ndim == 2 else win.transpose(2, 0, 1)[None]
+            y = planer.layer_map["relu"](planer.layer_map["conv"](np.ascontiguousarray(x), K, B, pads=[1, 1, 1, 1]))
+            if up > 1:
+                y = planer.layer_map["upsample"](y, np.array([1, 1, up, up], np.float32), "nearest")
+            return np.ascontiguousarray(y[0].transpose(1, 2, 0))
+        out = rutil.tile(progress=lambda *a: None, **kw)(f)(img.copy())
+        store[name + "/img"], store[name + "/K"], store[name + "/B"] = img, K, B
+        store[name + "/out"] = np.ascontiguousarray(out)
+        print(name, img.shape, "->", out.shape, out.dtype)
+    np.savez_compressed(os.path.join(OUT, "tile.npz"), **store)
+
+
 def ref_net(graph, blob):
     net = planer.Net()
     net.load_json(graph["input"], graph["inits"], graph["layers"], graph["flow"])
@@ -115,6 +134,7 @@ def run_nets():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     run_layers()
+    run_tile()
     if "--layers-only" not in sys.argv:
         run_nets()
     for f in sorted(os.listdir(OUT)):
