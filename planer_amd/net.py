@@ -491,10 +491,13 @@ class Net:
                     cand.launch(join=mode != "throughput")
                 cand.join()
                 ctx.synchronize()
-            burst(3)
-            t0 = time.perf_counter()
-            burst(10)
-            cand.ms = (time.perf_counter() - t0) / 10 * 1e3
+            burst(5)
+            cand.ms = None
+            for _ in range(3):                 # best of three: a noisy pick costs up to 7 % of throughput
+                t0 = time.perf_counter()
+                burst(20)
+                ms = (time.perf_counter() - t0) / 20 * 1e3
+                cand.ms = ms if cand.ms is None else min(cand.ms, ms)
             if best is None or cand.ms < best.ms:
                 best = cand
         self.timer = timer
