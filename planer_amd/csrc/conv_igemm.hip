@@ -38,13 +38,6 @@
 #include "common.h"
 #include "device_utils.h"
 
-#ifndef PL_SCHED
-#define PL_SCHED 0
-#endif
-#ifndef PL_ABL
-#define PL_ABL 0   // debug builds only: 1 no B gather, 2 no A loads, 3 neither, 4 no output stores, 8 no LDS stores
-#endif
-
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -129,9 +122,6 @@ __device__ __forceinline__ void store_tile(const ConvArgs &p, const TileCoord &t
                 const int row = tc.m0 + wm * WTM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                 if (row < p.cout_g) {
                     const size_t idx = obase + (size_t)row * p.HoWo;
-#if PL_ABL & 4
-                    if (acc[a][b][r] == 12345.678f)
-#endif
                     p.y[idx] = apply_epilogue(p.ep, acc[a][b][r], (int)tc.g * p.cout_g + row, idx);
                 }
             }
@@ -502,22 +492,14 @@ __global__ void __launch_bounds__(256) conv_tap_kernel(const ConvArgs p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int soff = ((cin0 + ps * C::KG_PER_PASS * 4 + e) * p.HW) << 2;   // scalar
-#if (PL_ABL & 3) == 1 || (PL_ABL & 3) == 3
-                tv[e] = (float)(voff + soff);
-#else
                 tv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, voff, soff, 0));
-#endif
             }
             breg[ps] = make_float4(tv[0], tv[1], tv[2], tv[3]);
         }
         const int ksoff = (ci * C::BK) << 2;                    // scalar: chunk start along K
 #pragma unroll
         for (int i = 0; i < C::A_PER_THREAD; ++i)
-#if (PL_ABL & 3) >= 2
-            areg[i] = make_float4((float)(aoff[i] + ksoff), 1.f, 2.f, 3.f);
-#else
             areg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, aoff[i], ksoff, 0));
-#endif
     };
 
     auto store_chunk = [&](int buf, const float4 (&breg)[C::B_PASSES], const float4 (&areg)[C::A_PER_THREAD]) {
