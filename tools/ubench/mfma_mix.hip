@@ -169,6 +169,82 @@ __global__ void __launch_bounds__(256) mix(const float *g, float *out, int chunk
     if (s == 1234.5f) out[tid] = s;
 }
 
+// V15: the Q4 pattern (V13) with direct global->LDS loads (buffer_load_dwordx4 ... lds, gfx950): no
+// VGPR staging, no ds_write; three LDS buffers so a chunk's loads are in flight for two chunk times.
+__global__ void __launch_bounds__(256) mix_dma(const float *g, float *out, int chunks) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];     // [3][A 2048 | B 2048] floats
+    typedef __attribute__((address_space(3))) void lds_t;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    f32x16 acc[2][2];
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g), 0, (1 << 28) + (1 << 24), 0x00020000);
+    const int pix = blockIdx.x * 128 + (tid & 127);
+    const int n = pix >> 10, h = (pix >> 5) & 31, w = pix & 31;
+    auto issue = [&](int c) {
+        float *buf = smem + (c % 3) * 4096;
+        const int tap = (c >> 3) % 9, cq0 = (c & 7) * 4;
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        const bool ok = (unsigned)(h + dy) < 32u && (unsigned)(w + dx) < 32u;
+        const int voff = ok ? ((n * 32 * 1024 + (h + dy) * 32 + (w + dx)) << 4) : (int)0x80000000;
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int kq = (wave >> 1) + ps * 2;                                   // wave-uniform k-quad
+            const int soff = ((cq0 + kq) * 1024) << 4;
+            // B: wave writes 64 consecutive columns of plane kq;  A: 64 consecutive rows of plane kq
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_t *)(buf + 2048 + (kq * 128 + (wave & 1) * 64) * 4), 16, voff, soff, 0, 0);
+            const int aoff = (1 << 28) + ((kq * 128 + (tid & 127)) << 4);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_t *)(buf + (kq * 128 + (wave & 1) * 64) * 4), 16, aoff, (c % 72) * 4 * 128 * 16, 0, 0);
+        }
+    };
+    // (hipcc waits vmcnt(0) before any LDS read that follows a DMA load, so the next chunk's loads
+    //  are issued AFTER this chunk's fragment reads: one chunk time of latency cover, two buffers)
+    issue(0);
+    __syncthreads();
+    const float *fa = smem + (lane >> 5) * 512 + (lane & 31) * 4;
+    for (int c = 0; c < chunks; ++c) {
+        const float *A = fa + (c % 3) * 4096, *B = fa + (c % 3) * 4096 + 2048;
+        float4 af[2][2], bf[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                af[u][t] = *reinterpret_cast<const float4 *>(A + ((wave >> 1) * 64 + t * 32) * 4 + u * 1024);
+                bf[u][t] = *reinterpret_cast<const float4 *>(B + ((wave & 1) * 64 + t * 32) * 4 + u * 1024);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        issue(c + 1);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const float av = s4 == 0 ? af[u][a].x : s4 == 1 ? af[u][a].y : s4 == 2 ? af[u][a].z : af[u][a].w;
+                        const float bv = s4 == 0 ? bf[u][b].x : s4 == 1 ? bf[u][b].y : s4 == 2 ? bf[u][b].z : bf[u][b].w;
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a][b], 0, 0, 0);
+                    }
+        __syncthreads();
+    }
+    float s = 0;
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int r = 0; r < 16; ++r) s += acc[a][b][r];
+    if (s == 1234.5f) out[tid] = s;
+}
+
+void run_dma(const float *g, float *out, int per_cu, int chunks) {
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipFuncSetAttribute((const void *)mix_dma, hipFuncAttributeMaxDynamicSharedMemorySize, 49152);
+    mix_dma<<<256 * per_cu, 256, 49152>>>(g, out, 16);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    for (int i = 0; i < 5; ++i) mix_dma<<<256 * per_cu, 256, 49152>>>(g, out, chunks);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+    double flops = 256.0 * per_cu * 4 * chunks * 8 * 4 * 4096.0;
+    printf("V15 tile 128x128  %d/CU: %.3f ms  %.1f TFLOP/s   (LDS-DMA)\n", per_cu, ms, flops / ms / 1e9);
+}
+
 template <int V, int TM, int TN>
 void run(const float *g, float *out, int per_cu, int chunks) {
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -199,7 +275,7 @@ int main() {
         run<5, 2, 2>(g, out, per, 72); run<6, 2, 2>(g, out, per, 72);
         run<7, 2, 2>(g, out, per, 72); run<8, 2, 2>(g, out, per, 72);
         run<9, 2, 2>(g, out, per, 72); run<10, 2, 2>(g, out, per, 72);
-        run<11, 2, 2>(g, out, per, 72); run<12, 2, 2>(g, out, per, 72); run<13, 2, 2>(g, out, per, 72); run<14, 2, 2>(g, out, per, 72);
+        run<11, 2, 2>(g, out, per, 72); run<12, 2, 2>(g, out, per, 72); run<13, 2, 2>(g, out, per, 72); run<14, 2, 2>(g, out, per, 72); run_dma(g, out, per, 72);
     }
     return 0;
     for (int ch : {72, 36, 16}) {
