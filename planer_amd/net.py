@@ -445,8 +445,11 @@ class Net:
             q, _, p_ = want.partition("x")
             q, p_ = int(q), int(p_ or q)
             cands = [(q, p_) if splittable and p_ >= q >= 1 and batch % p_ == 0 else (1, 1)]
-        # throughput mode may also pipeline whole batches over R streams (R full-batch graphs)
+        # throughput mode pipelines whole batches over R streams (R full-batch graphs); sub-batch plans
+        # are dominated there (28.4 k vs 34.8 k img/s on ResNet-18), so they are not even tried
         pipes = [2, 3] if (mode == "throughput" and want == "auto") else []
+        if pipes:
+            cands = [(1, 1)]
         if want.startswith("pipe"):
             cands, pipes = [], [int(want[4:] or 2)]
         progs = {}
@@ -493,10 +496,10 @@ class Net:
                 ctx.synchronize()
             burst(5)
             cand.ms = None
-            for _ in range(3):                 # best of three: a noisy pick costs up to 7 % of throughput
-                t0 = time.perf_counter()
-                burst(20)
-                ms = (time.perf_counter() - t0) / 20 * 1e3
+            for _ in range(5):                 # best of five short bursts: a noisy pick costs up to 7 % of
+                t0 = time.perf_counter()       # throughput; deeper bursts overflow rocprofv3's queue interception
+                burst(10)
+                ms = (time.perf_counter() - t0) / 10 * 1e3
                 cand.ms = ms if cand.ms is None else min(cand.ms, ms)
             if best is None or cand.ms < best.ms:
                 best = cand

@@ -12,8 +12,14 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 export PLANER_HIP_TUNE_CACHE=$out/${tag}_tune_cache.txt        # all passes run the same tile plans
 python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline "$@" > /dev/null 2>&1     # fills the cache
-rocprofv3 --kernel-trace --stats -d $out -o ${tag}_bench --output-format csv -- \
-    python $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline "$@" > $out/${tag}_bench_line_under_rocprof.json 2> $out/${tag}_stats.err
+# (rocprofv3's dispatch interception segfaults now and then when three graphs are in flight on three
+#  streams -- never without the tool -- so the pass is retried until its summary exists)
+for attempt in 1 2 3 4 5 6; do
+  rocprofv3 --kernel-trace --stats -d $out -o ${tag}_bench --output-format csv -- \
+      python $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline "$@" > $out/${tag}_bench_line_under_rocprof.json 2> $out/${tag}_stats.err
+  [ -s $out/${tag}_bench_kernel_stats.csv ] && break
+  echo "stats pass: attempt $attempt failed, retrying"
+done
 # the same with ONE stream: every launch is a full-batch layer, so a kernel's average duration here is
 # directly comparable with bench.py's per-layer HIP-event times (roofline.avg_launch_ms)
 PLANER_HIP_STREAMS=1x1 rocprofv3 --kernel-trace --stats -d $out -o ${tag}_bench_1stream --output-format csv -- \
