@@ -1407,6 +1407,42 @@ int winograd_q4_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int 
     return rc;
 }
 
+#include "conv_w1d_kernel.h"
+
+int w1d_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const float *uq, int Cout, const float *bias,
+               float *yq, const float *scale, const float *shift, const float *resq, int act, double alpha) {
+    ConvArgs a;
+    memset(&a, 0, sizeof a);
+    const int Tw = (W + 1) / 2;
+    a.x = xq; a.w = uq; a.y = yq;
+    a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.Ho = H; a.Wo = W;
+    a.kh = 3; a.kw = 3; a.sh = a.sw = a.dh = a.dw = 1; a.pt = a.pl = 1;
+    a.groups = 1; a.cin_g = Cin; a.cout_g = Cout;
+    a.cqg = Cin / 4; a.Cq = Cin / 4; a.Coq = (Cout + 3) / 4;
+    a.Qtot = 3 * a.cqg; a.Qpad = (a.Qtot + 7) / 8 * 8;
+    a.K = a.Qtot * 4;
+    a.cols = N * H * Tw;
+    a.HoWo = H * W; a.HW = H * W;
+    const size_t in_elems = (size_t)N * Cin * H * W, out_elems = (size_t)N * a.Coq * 4 * H * W;
+    const size_t w_elems = (size_t)4 * a.Qpad * Cout * 4;
+    PL_REQUIRE(in_elems < (1ull << 29) && out_elems < (1ull << 31) && w_elems < (1ull << 29) &&
+                   (size_t)N * H * Tw < (1ull << 31), PL_EUNSUPPORTED, "winograd-1d: tensor too large");
+    a.x_bytes = (int)(in_elems * 4); a.w_bytes = (int)(w_elems * 4);
+    a.divHoWo = FastDiv(H * Tw); a.divWo = FastDiv(Tw); a.divCpt = FastDiv(a.cqg);
+    a.divKhw = FastDiv(1); a.divKw = FastDiv(1);
+    a.mtiles = (Cout + W1dCfg::BM - 1) / W1dCfg::BM;
+    a.ntiles = (a.cols + W1dCfg::BN - 1) / W1dCfg::BN;
+    a.tiles = a.mtiles * a.ntiles;
+    a.divMt = FastDiv(a.mtiles);
+    a.tile_offset = 0; a.tile_count = a.tiles; a.splits = 1;
+    a.ep = make_epilogue(bias, scale, shift, resq, act, alpha);
+    int rc = ensure_lds_attr((const void *)conv_w1d_kernel, W1dCfg::LDS_BYTES);
+    if (rc != PL_OK) return rc;
+    hipLaunchKernelGGL(conv_w1d_kernel, dim3((unsigned)a.tiles), dim3(256), W1dCfg::LDS_BYTES, ctx->stream, a);
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1449,6 +1485,43 @@ int pl_conv2d_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W,
                PL_EINVAL, "pl_conv2d_q4_f32: Q4 tensors must be 16-byte aligned");
     return conv_launch(ctx, xq, N, Cin, H, W, wq, Cout, kh, kw, bias, yq, sh, sw, dh, dw, pt, pl, pb, pr, group,
                        scale, shift, resq, act, alpha, 2);
+}
+
+int pl_conv2d_w1d_q4_filter_elems(int Cout, int Cin, size_t *elems) {
+    PL_REQUIRE(elems && Cout > 0 && Cin > 0, PL_EINVAL, "pl_conv2d_w1d_q4_filter_elems: bad argument");
+    *elems = (size_t)4 * (((size_t)3 * (Cin / 4) + 7) / 8 * 8) * Cout * 4;
+    return PL_OK;
+}
+
+int pl_conv2d_prepare_w1d_q4_f32(pl_ctx *ctx, const float *w, int Cout, int Cin, float *out) {
+    PL_REQUIRE(ctx && w && out, PL_EINVAL, "pl_conv2d_prepare_w1d_q4_f32: null pointer");
+    PL_REQUIRE(Cout > 0 && Cin > 0 && Cin % 4 == 0, PL_EINVAL, "winograd-1d filters need Cin %% 4 == 0");
+    PL_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15u) == 0, PL_EINVAL, "pl_conv2d_prepare_w1d_q4_f32: unaligned output");
+    const int cqg = Cin / 4, q_tot = 3 * cqg, q_pad = (q_tot + 7) / 8 * 8;
+    const size_t total = (size_t)q_pad * Cout;
+    PL_REQUIRE(total * 16 < (1ull << 29), PL_EUNSUPPORTED, "filter too large");
+    CtxGuard g(ctx);
+    unsigned blocks = (unsigned)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    pack_filter_w1d_kernel<<<blocks, 256, 0, ctx->stream>>>(w, out, (unsigned)total, Cout, Cin, cqg, q_tot, q_pad,
+                                                           FastDiv(Cout), FastDiv(cqg));
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
+
+int pl_conv2d_w1d_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const float *uq, int Cout,
+                         const float *bias, float *yq, const float *scale, const float *shift, const float *resq,
+                         int act, double alpha) {
+    PL_REQUIRE(ctx && xq && uq && yq, PL_EINVAL, "pl_conv2d_w1d_q4_f32: null pointer");
+    PL_REQUIRE(N >= 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0 && Cin % 4 == 0, PL_EINVAL,
+               "pl_conv2d_w1d_q4_f32: bad shape (Cin must be a multiple of 4)");
+    PL_REQUIRE(H < 16384 && W < 16384, PL_EUNSUPPORTED, "pl_conv2d_w1d_q4_f32: spatial extent above 16383");
+    PL_REQUIRE(act >= 0 && (act & 15) <= 2 && (act & ~31) == 0, PL_EINVAL, "pl_conv2d_w1d_q4_f32: bad activation code");
+    PL_REQUIRE(((reinterpret_cast<uintptr_t>(xq) | reinterpret_cast<uintptr_t>(yq) | reinterpret_cast<uintptr_t>(uq) |
+                 reinterpret_cast<uintptr_t>(resq)) & 15u) == 0, PL_EINVAL, "Q4 tensors must be 16-byte aligned");
+    if (N == 0) return PL_OK;
+    CtxGuard guard(ctx);
+    return w1d_launch(ctx, xq, N, Cin, H, W, uq, Cout, bias, yq, scale, shift, resq, act, alpha);
 }
 
 int pl_conv2d_winograd_q4_filter_elems(int Cout, int Cin, size_t *elems) {

@@ -190,3 +190,31 @@ def test_pointwise_q4_layers_match_nchw_kernels(pa):
     got = q4.ConcatenateQ4(q4.to_q4(pa.asarray(a)), q4.to_q4(pa.asarray(b2)), axis=1)
     np.testing.assert_array_equal(q4.from_q4(got).get(), np.concatenate([a, b2], axis=1))
     np.testing.assert_array_equal(q4.from_q4(q4.SigmoidQ4(q4.to_q4(pa.asarray(a)))).get(), pa.Sigmoid(pa.asarray(a)).get())
+
+
+def test_winograd_1d_fused_matches_oracle(pa):
+    """Fused 1-D Winograd F(2,3) along W (conv_w1d_kernel): odd / even widths (a half tile at the
+    right edge), Cout not a multiple of 64 or of 4, K tails, with and without the fused tail."""
+    from planer_amd import q4
+    rng = np.random.default_rng(29)
+    for (n, cin, h, w, cout) in [(2, 16, 7, 7, 24), (3, 20, 14, 13, 44), (1, 64, 9, 12, 64), (2, 48, 28, 28, 130),
+                                 (1, 8, 5, 1, 6), (2, 4, 6, 2, 3)]:
+        x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+        k = (rng.standard_normal((cout, cin, 3, 3)) * 0.1).astype(np.float32)
+        b = rng.standard_normal(cout).astype(np.float32)
+        sc = rng.uniform(0.5, 1.5, (1, cout, 1, 1)).astype(np.float32)
+        sh = rng.standard_normal((1, cout, 1, 1)).astype(np.float32)
+        res = rng.standard_normal((n, cout, h, w)).astype(np.float32)
+        xq = q4.to_q4(pa.asarray(x))
+        U = q4.prepare_w1d_q4_weights(pa.asarray(k))
+        yq = q4.ConvQ4(xq, U, pa.asarray(b), pads=[1, 1, 1, 1], w_layout=5)
+        y = q4.from_q4(yq).get()
+        ref = np.ascontiguousarray(onp.conv2d(x, k, b, pads=[1, 1, 1, 1]))
+        assert_close(y, ref, RTOL, "winograd-1d %s" % ((n, cin, h, w, cout),))
+        np.testing.assert_array_equal(yq.get(), q4_host(y))            # padding lanes stay zero
+        y = q4.from_q4(q4.ConvQ4(xq, U, None, pa.asarray(sc), pa.asarray(sh), q4.to_q4(pa.asarray(res)),
+                                 pads=[1, 1, 1, 1], act=1, w_layout=5)).get()
+        ref = onp.relu(onp.batchnorm(np.ascontiguousarray(onp.conv2d(x, k, pads=[1, 1, 1, 1])), sc, sh) + res)
+        assert_close(y, ref, RTOL, "winograd-1d fused")
+    with pytest.raises(ValueError):
+        q4.ConvQ4(xq, U, pads=[0, 0, 0, 0], w_layout=5)

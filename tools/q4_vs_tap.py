@@ -76,5 +76,14 @@ if "--resnet" in sys.argv or len(sys.argv) == 1:
         xq, wq = q4.to_q4(x), q4.prepare_q4_weights(k)
         t_q4 = timeit(lambda: q4.ConvQ4(xq, wq, None, sc, sh, resq, act=1, **kw))
         fl = 2.0 * xs[0] * ks[0] * ho * ho * ks[1] * ks[2] * ks[3]
-        print("%-11s nchw %7.1f us %6.1f TF | q4 %7.1f us %6.1f TF | x%.2f" %
-              (label, t_old * 1e3, fl / t_old / 1e9, t_q4 * 1e3, fl / t_q4 / 1e9, t_old / t_q4), flush=True)
+        extra = ""
+        if q4.w1d_q4_eligible(ks, **kw):
+            uq = q4.prepare_w1d_q4_weights(k)
+            t_w = timeit(lambda: q4.ConvQ4(xq, uq, None, sc, sh, resq, act=1, w_layout=5, **kw))
+            extra = " | winograd-1d %7.1f us %6.1f TF (alg.)" % (t_w * 1e3, fl / t_w / 1e9)
+            if xs[0] <= 32:
+                u2 = q4.prepare_winograd_q4_weights(k)
+                t_2 = timeit(lambda: q4.ConvQ4(xq, u2, None, sc, sh, resq, act=1, w_layout=4, **kw))
+                extra += " | winograd-2d %7.1f us" % (t_2 * 1e3)
+        print("%-11s nchw %7.1f us %6.1f TF | q4 %7.1f us %6.1f TF | x%.2f%s" %
+              (label, t_old * 1e3, fl / t_old / 1e9, t_q4 * 1e3, fl / t_q4 / 1e9, t_old / t_q4, extra), flush=True)
