@@ -220,9 +220,11 @@ def main():
             traffic = round(sum((r["read_mb_per_launch_corrected"] * 1e6 + r["write_kb_per_launch"] * 1e3)
                                 * r["launches"] for r in fam) / launches)
             traffic_src = "profiles/r01_hbm_traffic.json: HBM bytes per conv-family kernel launch (PMC run of this command)"
-    roofline = {"bound": "mfma", "kernel": "conv_q4_kernel (channel-quad implicit GEMM; layer3/4 via Winograd F(2x2,3x3): "
-                                          "float4 transforms + one grouped 1x1 conv_q4_kernel): the 16 conv3x3 layers of one "
-                                          "forward, incl. their split-K tile-reduce and transform launches",
+    roofline = {"bound": "mfma", "kernel": "the 16 conv3x3 layers of one forward on channel-quad tensors, each on the fastest of "
+                                          "conv_q4_kernel (direct implicit GEMM, stride-2 layers), conv_w1d_kernel (fused 1-D "
+                                          "Winograd, layer1-2) and the 2-D Winograd pipeline (float4 transforms + one grouped 1x1 "
+                                          "conv_q4_kernel, layer3-4), incl. split-K tile-reduce and transform launches; "
+                                          "achieved = algorithmic FLOPs / time",
                 "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": round(c3["ms"] / c3["launches"], 4),

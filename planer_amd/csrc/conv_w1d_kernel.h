@@ -157,6 +157,7 @@ conv_w1d_kernel(const ConvArgs p) {
         if constexpr (P == 0) load_chunk(min(k + 2, last), breg0, areg0);
         else load_chunk(min(k + 2, last), breg1, areg1);
         mma(ha, hb);
+        __builtin_amdgcn_sched_barrier(0);     // keep the barrier (and the tail reads' wait) BEHIND the head MFMAs
         __syncthreads();
     };
     using P0 = std::integral_constant<int, 0>;
