@@ -213,7 +213,7 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
     if os.path.exists(tpath):
         fam = [r for r in json.load(open(tpath))
-               if any(t in r["kernel"] for t in ("conv_q4_kernel", "conv_tap_kernel", "conv_igemm_kernel",
+               if any(t in r["kernel"] for t in ("conv_q4_kernel", "conv_w1d_kernel", "conv_tap_kernel", "conv_igemm_kernel",
                                                  "reduce_tiles", "wino_"))]
         launches = sum(r["launches"] for r in fam)
         if launches:
