@@ -157,6 +157,20 @@ int pl_conv2d_winograd_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int 
                               const float *scale, const float *shift, const float *resq,
                               int act, double alpha);
 
+/* Row-packed convolution for inputs with 1..3 channels (the 7x7 / 3-channel stem): takes the
+ * reference's NCHW input directly, re-lays it as a zero-padded NHWC image (one HBM pass, replaces
+ * pl_nchw_to_q4_f32 for this layer) and runs conv_q4_kernel with K = kh rows x ceil(kw*Cin/4)
+ * quads instead of kh*kw taps x 1 padded quad (7x7x3: 168 instead of 196 k-values, no range checks
+ * in the gather).  wq from pl_conv2d_prepare_rowpack_f32; output and residual are Q4.
+ * group 1, dilation 1, symmetric pads. */
+int pl_conv2d_rowpack_filter_elems(int Cout, int Cin, int kh, int kw, size_t *elems);
+int pl_conv2d_prepare_rowpack_f32(pl_ctx *ctx, const float *w, int Cout, int Cin, int kh, int kw,
+                                  float *out);
+int pl_conv2d_rowpack_q4_f32(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W,
+                             const float *wq, int Cout, int kh, int kw, const float *bias,
+                             float *yq, int sh, int sw, int pt, int pl, const float *scale,
+                             const float *shift, const float *resq, int act, double alpha);
+
 /* Fused 1-D Winograd F(2,3) along W on Q4 tensors (3x3 / stride 1 / pad 1 / group 1, Cin %% 4 == 0):
  * 1.5x fewer multiplies than the direct conv with NO extra HBM traffic -- the input transform
  * happens between the global load and LDS, the output transform in registers (conv_w1d_kernel.h).

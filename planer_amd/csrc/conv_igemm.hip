@@ -59,6 +59,7 @@ struct ConvArgs {
     // channel-quad (Q4) layout only: input quads per group / in total, output quads in total,
     // k-quads per group (real / padded), and whether a BK chunk always sits inside one filter tap
     int cqg, Cq, Coq, Qtot, Qpad, uni;
+    int rp_rq;        // > 0: row-packed small-Cin input (x = padded NHWC, H/W = padded extents); quads per filter row
     FastDiv divKhw, divKw, divHoWo, divWo, divMt, divCpt;
     Epilogue ep;
 };
@@ -716,6 +717,7 @@ constexpr int kLdsPerCu = 160 * 1024;
 
 // weight layouts: 0 OIHW (generic kernel), 1 tap-major, 2 Q4 (activations AND filter in quad form)
 bool cfg_applies(const CfgInfo &ci, int layout, int cin_g) {
+    if (layout == 6) layout = 2;            // row-packed input: the channel-quad kernel with another gather
     if (ci.tap != layout) return false;
     return ci.tap != 1 || cin_g % ci.bk == 0;
 }
@@ -762,8 +764,8 @@ int launch_pass(pl_ctx *ctx, ConvArgs a, const CfgInfo &ci, bool avec, int tile_
         const int cps = (total_chunks + splits - 1) / splits;
         splits = (total_chunks + cps - 1) / cps;
         a.k_per_split = cps;
-        a.uni = a.cqg % kg == 0;
-        a.divCpt = FastDiv(a.cqg);
+        a.uni = a.rp_rq ? 0 : a.cqg % kg == 0;
+        a.divCpt = FastDiv(a.rp_rq ? a.rp_rq : a.cqg);
     } else if (ci.tap) {
         const int total_chunks = a.K / ci.bk;
         const int cps = (total_chunks + splits - 1) / splits;
@@ -990,6 +992,13 @@ Plan tune_plan(pl_ctx *ctx, int layout, const ConvArgs &a, bool avec, float *y, 
     return best.pl;
 }
 
+// pixels per row of the zero-padded NHWC image of the row-packed path: the padded width, and room for
+// the last window's quads to overrun (a filter row is read as whole quads: 4*RQ floats)
+inline int rowpack_row_pixels(int W, int pl, int Wo, int sw, int kw, int Cin) {
+    const int rq = (kw * Cin + 3) / 4;
+    return std::max(W + 2 * pl, (Wo - 1) * sw + (4 * rq + Cin - 1) / Cin + 1);
+}
+
 int winograd_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const float *U, int Cout,
                     const float *bias, float *y, const float *scale, const float *shift, const float *res, int act,
                     double alpha);
@@ -1005,7 +1014,7 @@ int conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const
     PL_REQUIRE(pt == pb && pl == pr, PL_EUNSUPPORTED, "asymmetric pads are undefined in the reference (util.py:8)");
     PL_REQUIRE(Cin % group == 0 && Cout % group == 0, PL_EUNSUPPORTED, "group must divide Cin and Cout");
     PL_REQUIRE(act >= 0 && (act & 15) <= 2 && (act & ~31) == 0, PL_EINVAL, "conv2d: bad activation code");
-    PL_REQUIRE(layout >= 0 && layout <= 3, PL_EINVAL, "conv2d: bad weight layout");
+    PL_REQUIRE((layout >= 0 && layout <= 3) || layout == 6, PL_EINVAL, "conv2d: bad weight layout");
     if (layout == 3) {
         PL_REQUIRE(kh == 3 && kw == 3 && sh == 1 && sw == 1 && dh == 1 && dw == 1 && pt == 1 && pl == 1 && pb == 1 &&
                        pr == 1 && group == 1, PL_EINVAL, "winograd filters serve 3x3 / stride 1 / pad 1 / group 1 only");
@@ -1022,6 +1031,15 @@ int conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const
     size_t out_elems = (size_t)N * Cout * Ho * Wo, in_elems = (size_t)N * Cin * H * W;
     size_t w_elems = (size_t)Cout * (Cin / group) * kh * kw;
     const int cqg = (Cin / group + 3) / 4, q_tot = kh * kw * cqg, q_pad = (q_tot + 7) / 8 * 8;
+    // layout 6: x is the zero-padded NHWC image [N][H+2pt][Wp][Cin] made by rowpack_launch below
+    const int rp_rq = layout == 6 ? (kw * Cin + 3) / 4 : 0;
+    const int rp_wp = layout == 6 ? rowpack_row_pixels(W, pl, Wo, sw, kw, Cin) : 0;
+    if (layout == 6) {
+        PL_REQUIRE(group == 1 && dh == 1 && dw == 1 && Cin < 4, PL_EUNSUPPORTED, "conv2d (row-packed): group 1, dilation 1, Cin < 4");
+        in_elems = (size_t)N * (H + 2 * pt) * rp_wp * Cin + 8;
+        out_elems = (size_t)N * ((Cout + 3) / 4) * 4 * Ho * Wo;
+        w_elems = (size_t)((kh * rp_rq + 7) / 8 * 8) * Cout * 4;
+    }
     if (layout == 2) {
         PL_REQUIRE(group == 1 || ((Cin / group) % 4 == 0 && (Cout / group) % 4 == 0), PL_EUNSUPPORTED,
                    "conv2d (Q4): grouped convs need Cin/group and Cout/group to be multiples of 4");
@@ -1042,6 +1060,11 @@ int conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const
     a.groups = group; a.cin_g = Cin / group; a.cout_g = Cout / group;
     a.K = layout == 2 ? q_tot * 4 : a.cin_g * kh * kw;
     a.cqg = cqg; a.Cq = (Cin + 3) / 4; a.Coq = (Cout + 3) / 4; a.Qtot = q_tot; a.Qpad = q_pad;
+    if (layout == 6) {
+        a.rp_rq = rp_rq;
+        a.Qtot = kh * rp_rq; a.Qpad = (a.Qtot + 7) / 8 * 8; a.K = a.Qtot * 4;
+        a.H = H + 2 * pt; a.W = rp_wp;          // padded extents: what the gather indexes
+    }
     a.cols = N * Ho * Wo;
     a.HoWo = Ho * Wo; a.HW = H * W;
     a.x_bytes = (int)(in_elems * 4); a.w_bytes = (int)(w_elems * 4);
@@ -1485,6 +1508,55 @@ int pl_conv2d_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W,
                PL_EINVAL, "pl_conv2d_q4_f32: Q4 tensors must be 16-byte aligned");
     return conv_launch(ctx, xq, N, Cin, H, W, wq, Cout, kh, kw, bias, yq, sh, sw, dh, dw, pt, pl, pb, pr, group,
                        scale, shift, resq, act, alpha, 2);
+}
+
+int pl_conv2d_rowpack_filter_elems(int Cout, int Cin, int kh, int kw, size_t *elems) {
+    PL_REQUIRE(elems && Cout > 0 && Cin > 0 && kh > 0 && kw > 0, PL_EINVAL, "pl_conv2d_rowpack_filter_elems: bad argument");
+    *elems = (size_t)(((size_t)kh * ((kw * Cin + 3) / 4) + 7) / 8 * 8) * Cout * 4;
+    return PL_OK;
+}
+
+int pl_conv2d_prepare_rowpack_f32(pl_ctx *ctx, const float *w, int Cout, int Cin, int kh, int kw, float *out) {
+    PL_REQUIRE(ctx && w && out, PL_EINVAL, "pl_conv2d_prepare_rowpack_f32: null pointer");
+    PL_REQUIRE(Cout > 0 && Cin > 0 && Cin < 4 && kh > 0 && kw > 0, PL_EINVAL, "row-packed filters are for Cin < 4");
+    PL_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15u) == 0, PL_EINVAL, "pl_conv2d_prepare_rowpack_f32: unaligned output");
+    const int rq = (kw * Cin + 3) / 4, q_tot = kh * rq, q_pad = (q_tot + 7) / 8 * 8;
+    const size_t total = (size_t)q_pad * Cout;
+    PL_REQUIRE(total * 16 < (1ull << 29), PL_EUNSUPPORTED, "filter too large");
+    CtxGuard g(ctx);
+    unsigned blocks = (unsigned)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    pack_filter_rowpack_kernel<<<blocks, 256, 0, ctx->stream>>>(w, out, (unsigned)total, Cout, Cin, kh, kw, rq, q_tot,
+                                                               FastDiv(Cout), FastDiv(rq));
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
+
+int pl_conv2d_rowpack_q4_f32(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const float *wq, int Cout, int kh,
+                             int kw, const float *bias, float *yq, int sh, int sw, int pt, int pl, const float *scale,
+                             const float *shift, const float *resq, int act, double alpha) {
+    PL_REQUIRE(ctx && x && wq && yq, PL_EINVAL, "pl_conv2d_rowpack_q4_f32: null pointer");
+    PL_REQUIRE(N >= 0 && Cin > 0 && Cin < 4 && H > 0 && W > 0 && Cout > 0 && kh > 0 && kw > 0 && sh > 0 && sw > 0 &&
+                   pt >= 0 && pl >= 0, PL_EINVAL, "pl_conv2d_rowpack_q4_f32: bad shape (Cin must be 1..3)");
+    PL_REQUIRE(((reinterpret_cast<uintptr_t>(yq) | reinterpret_cast<uintptr_t>(wq) | reinterpret_cast<uintptr_t>(resq)) & 15u) == 0,
+               PL_EINVAL, "Q4 tensors must be 16-byte aligned");
+    if (N == 0) return PL_OK;
+    const int Ho = (H + 2 * pt - kh + sh) / sh, Wo = (W + 2 * pl - kw + sw) / sw;
+    PL_REQUIRE(Ho > 0 && Wo > 0, PL_EINVAL, "pl_conv2d_rowpack_q4_f32: empty output");
+    const int Hp = H + 2 * pt, Wp = rowpack_row_pixels(W, pl, Wo, sw, kw, Cin);
+    const size_t pelems = ((size_t)N * Hp * Wp * Cin + 8 + 3) / 4 * 4;
+    PL_REQUIRE(pelems < (1ull << 29), PL_EUNSUPPORTED, "row-packed input above 2 GiB");
+    CtxGuard guard(ctx);
+    float *xp = nullptr;
+    int rc = pl_alloc(ctx, pelems * sizeof(float), (void **)&xp);
+    if (rc != PL_OK) return rc;
+    const unsigned total = (unsigned)((size_t)N * Hp * Wp * Cin), total4 = (unsigned)((pelems + 3) / 4);   // incl. the slack
+    nchw_to_rowpack_kernel<<<std::min<unsigned>((total4 + 255) / 256, 256 * 16), 256, 0, ctx->stream>>>(
+        x, xp, total4, total, Cin, H, W, Hp, Wp, pt, pl, FastDiv(Cin), FastDiv(Wp), FastDiv(Hp));
+    rc = conv_launch(ctx, xp, N, Cin, H, W, wq, Cout, kh, kw, bias, yq, sh, sw, 1, 1, pt, pl, pt, pl, 1, scale, shift, resq,
+                     act, alpha, 6);
+    pl_free(ctx, xp);            // stream-ordered
+    return rc;
 }
 
 int pl_conv2d_w1d_q4_filter_elems(int Cout, int Cin, size_t *elems) {

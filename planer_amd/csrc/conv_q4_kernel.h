@@ -244,7 +244,7 @@ conv_q4_kernel(const ConvArgs p) {
     const int kg0 = KG_UNIFORM ? wave / WPC : tid / C::BN;
     const int j = col0 + jl;
     const bool jok = j < p.cols && (C::B_ALL_ACTIVE || kg0 < C::KG);
-    int hbase = -(1 << 20), wbase = 0, cbase = 0;
+    int hbase = -(1 << 20), wbase = 0, cbase = 0, j_n = 0;
     if (jok) {
         unsigned n, pix, ho, wo;
         p.divHoWo.divmod((unsigned)j, n, pix);
@@ -252,8 +252,12 @@ conv_q4_kernel(const ConvArgs p) {
         hbase = (int)ho * p.sh - p.pt;
         wbase = (int)wo * p.sw - p.pl;
         cbase = ((int)n * p.Cq + (int)g * p.cqg) * p.HW + hbase * p.W + wbase;     // in quads
+        j_n = (int)n;
     }
     constexpr int OOB = (int)0x80000000;
+    // row-packed input: byte offset of (n, ho*sh, wo*sw, channel 0) in the padded NHWC image
+    // (hbase / wbase carry -pad; the padded image starts at -pad)
+    const int rp_base = (p.rp_rq && jok) ? (((j_n * p.H + hbase + p.pt) * p.W + wbase + p.pl) * p.Cin) << 2 : OOB;
     const __amdgpu_buffer_rsrc_t xrsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc =
@@ -291,7 +295,23 @@ conv_q4_kernel(const ConvArgs p) {
     }
     auto load_chunk = [&](int c, float4 (&breg)[C::B_PASSES], float4 (&areg)[C::A_PER_THREAD]) {
         const int q0 = (cbeg + c) * C::KG;                      // first k-quad of the chunk (uniform)
-        if (p.uni) {
+        if (p.rp_rq) {
+            // Row-packed small-Cin input (the 3-channel 7x7 stem): x is [N][H+2p][Wp][Cin] with the
+            // zero border already in place, so a filter row's kw*Cin floats are contiguous and K runs
+            // (filter row, quad of that row segment).  The thread's base offset never changes, the
+            // k-quad offset is scalar, there is nothing to range-check but the column itself.
+#pragma unroll
+            for (int ps = 0; ps < C::B_PASSES; ++ps) {
+                const int q = min(q0 + kg0 + ps * C::KG_PER_PASS, p.Qtot - 1);     // K padding: zero filter rows
+                const int a = (int)p.divCpt.div((unsigned)q);
+                const int off = (a * p.W * p.Cin + (q - a * p.rp_rq) * 4) << 2;     // p.W = padded row length
+                if constexpr (KG_UNIFORM)
+                    breg[ps] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, rp_base, off, 0));
+                else
+                    breg[ps] = __builtin_bit_cast(
+                        float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, jok ? rp_base + off : OOB, 0, 0));
+            }
+        } else if (p.uni) {
             // chunks are requested in order, each at most one further than the last (c is clamped at the end)
             const int ncq = st_cq0 + (c - st_c) * C::KG;
             st_c = c;
@@ -512,5 +532,52 @@ __global__ void __launch_bounds__(256) q4_to_nchw_kernel(const float *x, float *
         if (left > 1) dst[HW] = v.y;
         if (left > 2) dst[2 * (size_t)HW] = v.z;
         if (left > 3) dst[3 * (size_t)HW] = v.w;
+    }
+}
+
+// NCHW -> zero-padded NHWC rows for the row-packed gather: y[n][h + pt][w + pl][c], border = 0.
+// One pass: a thread produces 4 consecutive floats of y (one b128 store), i.e. 4 (pixel, channel)
+// elements gathered from up to 3 channel planes.
+__global__ void __launch_bounds__(256) nchw_to_rowpack_kernel(const float *x, float *y, unsigned total4, unsigned total,
+                                                              int C, int H, int W, int Hp, int Wp, int pt, int pl,
+                                                              FastDiv divC, FastDiv divWp, FastDiv divHp) {
+    const unsigned stride = gridDim.x * 256;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned f = i * 4 + e;                       // float index in y
+            unsigned pix, c, r, wp, n, hp;
+            divC.divmod(f, pix, c);
+            divWp.divmod(pix, r, wp);
+            divHp.divmod(r, n, hp);
+            const int h = (int)hp - pt, w = (int)wp - pl;
+            const bool in = f < total && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+            v[e] = in ? x[(((size_t)n * C + c) * H + h) * W + w] : 0.f;
+        }
+        reinterpret_cast<float4 *>(y)[i] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// OIHW -> wq[q = a*RQ + jq][co][4]: element e of quad jq is float 4*jq + e of filter row a's
+// (kw, cin) segment, i.e. tap kw = f / Cin, channel f % Cin (zero beyond kw*Cin and beyond Qtot)
+__global__ void __launch_bounds__(256) pack_filter_rowpack_kernel(const float *w, float *out, unsigned total, int Cout,
+                                                                  int Cin, int kh, int kw, int RQ, int Qtot,
+                                                                  FastDiv divCo, FastDiv divRQ) {
+    const unsigned stride = gridDim.x * 256;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {      // i = q*Cout + co
+        unsigned q, co;
+        divCo.divmod(i, q, co);
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if ((int)q < Qtot) {
+            unsigned a, jq;
+            divRQ.divmod(q, a, jq);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int f = (int)jq * 4 + e;
+                if (f < kw * Cin) v[e] = w[(((size_t)co * Cin + f % Cin) * kh + a) * kw + f / Cin];
+            }
+        }
+        reinterpret_cast<float4 *>(out)[i] = make_float4(v[0], v[1], v[2], v[3]);
     }
 }

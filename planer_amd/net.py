@@ -346,14 +346,18 @@ class Net:
                 group = int(entry[2].get("group", 1))
                 para = {k: v for k, v in entry[2].items() if k in ("group", "strides", "dilations", "pads")}
                 lay = 2
-                if (use_wino and _q4.w1d_q4_eligible(K.shape, **para)
+                if entry[2].get("rowpack") and _q4.rowpack_eligible(K.shape, **para):
+                    lay = 6
+                elif (use_wino and _q4.w1d_q4_eligible(K.shape, **para)
                         and shapes.get(srcs[0].split("@")[0]) is not None):
                     lay = self._pick_conv_algo(_q4.ConvQ4, K, srcs, entry[2], shapes, wmap, q4=True)
-                key = {2: "%s@q4g%d" % (srcs[1], group), 4: srcs[1] + "@winoq4", 5: srcs[1] + "@w1dq4"}[lay]
+                key = {2: "%s@q4g%d" % (srcs[1], group), 4: srcs[1] + "@winoq4", 5: srcs[1] + "@w1dq4",
+                       6: srcs[1] + "@rowpack"}[lay]
                 if key not in self._extra:
                     self._extra[key] = {2: lambda: _q4.prepare_q4_weights(K, group),
                                         4: lambda: _q4.prepare_winograd_q4_weights(K),
-                                        5: lambda: _q4.prepare_w1d_q4_weights(K)}[lay]()
+                                        5: lambda: _q4.prepare_w1d_q4_weights(K),
+                                        6: lambda: _q4.prepare_rowpack_weights(K)}[lay]()
                 srcs[1] = key
                 out_body[name] = [name, "conv_q4", dict(entry[2], w_layout=lay)]
             elif entry[1] in ("conv", "conv_fused") and len(srcs) >= 2 and srcs[1] in wmap:
@@ -506,7 +510,13 @@ class Net:
                 burst(10)
                 ms = (time.perf_counter() - t0) / 10 * 1e3
                 cand.ms = ms if cand.ms is None else min(cand.ms, ms)
-            if best is None or cand.ms < best.ms:
+            if os.environ.get("PLANER_PLAN_LOG"):
+                import sys
+                print("[planer_amd] plan candidate %s: %.4f ms/pass" % (cand.streams, cand.ms), file=sys.stderr)
+            # short bursts (fill + drain every 10 passes) under-represent a deeper pipeline's steady
+            # state: in long runs pipe3 is ~4 % ahead of pipe2 where the bursts show ~2 %
+            cand.score = cand.ms * (1.0 - 0.02 * (len(cand.replicas) - 2)) if how == "pipe" else cand.ms
+            if best is None or cand.score < best.score:
                 best = cand
         self.timer = timer
         self._plans[key] = best

@@ -11,6 +11,8 @@ intermediate tensor has exactly one reader and one writer, so nothing a user
 could observe disappears; the fused step sits where the LAST link of its
 chain was, so a residual operand produced after the conv is still available.
 """
+import os
+
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 ACT_RES_AFTER = 16      # OR-ed into `act`: the residual is added after the activation
 
@@ -225,8 +227,16 @@ def assign_layouts(body, flow, init_names, shapes, force=False):
             if res != "None" and (res in inits or not _is4d(shapes, res)):
                 as_q4 = False
             else:
-                args = [need(full[0], True)] + full[1:5] + [need(res, True)]
+                # 1..3 input channels arriving as NCHW (the stem): the row-packed kernel reads a padded
+                # NHWC copy it makes itself -- K without the 4th padding channel, no to_q4 step
+                k = shapes[srcs[1]]
+                rowpack = (os.environ.get("PLANER_HIP_ROWPACK", "1") != "0"
+                           and full[0] not in q4 and k[1] < 4 and int(para.get("group", 1)) == 1
+                           and list(para.get("dilations", (1, 1))) == [1, 1])
+                args = [need(full[0], not rowpack)] + full[1:5] + [need(res, True)]
                 new_kind = "conv_q4"
+                if rowpack:
+                    para = dict(para, rowpack=True)
                 if shapes.get(dst) is not None:
                     k = shapes[srcs[1]]
                     est["gain"] += 2.0 * (_nbytes(shapes[dst]) / 4) * k[1] * k[2] * k[3] * _Q4_CONV_GAIN_S_PER_FLOP

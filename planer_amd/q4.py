@@ -97,6 +97,26 @@ def prepare_winograd_q4_weights(K):
     return out
 
 
+def rowpack_eligible(k_shape, group=1, strides=(1, 1), dilations=(1, 1), pads=(0, 0, 0, 0), **_):
+    """Convs on 1..3 input channels (the stem): group 1, no dilation, symmetric pads."""
+    cout, cin_g, kh, kw = k_shape
+    pads = list(pads)
+    return (group == 1 and cin_g < 4 and list(dilations) == [1, 1] and len(pads) == 4
+            and pads[0] == pads[2] and pads[1] == pads[3])
+
+
+def prepare_rowpack_weights(K):
+    """OIHW filters with Cin < 4 -> row-packed [kh*ceil(kw*Cin/4)][Cout][4] (ConvQ4 w_layout=6)."""
+    _f32(K)
+    cout, cin, kh, kw = K.shape
+    n = ctypes.c_size_t()
+    _lib.call("pl_conv2d_rowpack_filter_elems", cout, cin, kh, kw, ctypes.byref(n))
+    out = empty((n.value,), ctx=K.ctx)
+    _lib.call("pl_conv2d_prepare_rowpack_f32", K.ctx.handle, K.ptr, cout, cin, kh, kw, out.ptr)
+    out.shape = K.shape
+    return out
+
+
 def prepare_w1d_q4_weights(K):
     """OIHW 3x3 filters -> 1-D Winograd filters [4][row*Cin/4 + cin/4][Cout][4] (ConvQ4 w_layout=5)."""
     _f32(K)
@@ -123,6 +143,24 @@ def ConvQ4(xq, Kq, B=None, scale=None, shift=None, resq=None, group=1, strides=(
     w_layout=2: Kq from prepare_q4_weights(); w_layout=4: Winograd filters from
     prepare_winograd_q4_weights()."""
     _f32(xq, Kq, B, scale, shift, resq)
+    if w_layout == 6:
+        # row-packed stem: the input is the reference's NCHW tensor, the output is Q4
+        if is_q4(xq) or (resq is not None and not is_q4(resq)):
+            raise TypeError("row-packed ConvQ4 takes an NCHW input (and a Q4 residual)")
+        if not rowpack_eligible(Kq.shape, group, strides, dilations, pads):
+            raise ValueError("row-packed filters serve group 1 / dilation 1 / Cin < 4 convs only")
+        n, cin, h, w = xq.shape
+        cout, cin_g, kh, kw = Kq.shape
+        if cin_g != cin:
+            raise ValueError("conv: weight %s does not match input %s" % (Kq.shape, xq.shape))
+        pads, strides = [int(p) for p in pads], [int(s) for s in strides]
+        ho, wo = conv_out_hw(h, w, kh, kw, strides, [1, 1], pads)
+        y = _new_q4(n, cout, ho, wo, xq.ctx)
+        if resq is not None and resq.shape != y.shape:
+            raise ValueError("fused residual shape %s != conv output %s" % (resq.shape, y.shape))
+        _lib.call("pl_conv2d_rowpack_q4_f32", xq.ctx.handle, xq.ptr, n, cin, h, w, Kq.ptr, cout, kh, kw, _ptr(B), y.ptr,
+                  strides[0], strides[1], pads[0], pads[1], _ptr(scale), _ptr(shift), _ptr(resq), int(act), float(alpha))
+        return y
     if not is_q4(xq) or (resq is not None and not is_q4(resq)):
         raise TypeError("ConvQ4 needs Q4 activations (planer_amd.q4.to_q4)")
     n, cin, h, w = logical_shape(xq)

@@ -218,3 +218,47 @@ def test_winograd_1d_fused_matches_oracle(pa):
         assert_close(y, ref, RTOL, "winograd-1d fused")
     with pytest.raises(ValueError):
         q4.ConvQ4(xq, U, pads=[0, 0, 0, 0], w_layout=5)
+
+
+def test_rowpack_stem_conv_matches_oracle(pa):
+    """Row-packed convolution for 1..3 input channels (pl_conv2d_rowpack_q4_f32): NCHW in, Q4 out;
+    K runs (filter row, quads of the kw*Cin row segment) over a zero-padded NHWC copy of the input."""
+    from planer_amd import q4
+    ctx = pa.hip.context()
+    names = _cfg_names(pa)
+    rng = np.random.default_rng(31)
+    shapes = [((2, 3, 33, 35), (20, 3, 7, 7), dict(strides=[2, 2], pads=[3, 3, 3, 3])),
+              ((1, 1, 20, 21), (6, 1, 3, 3), dict(strides=[1, 1], pads=[1, 1, 1, 1])),
+              ((2, 2, 15, 17), (9, 2, 5, 5), dict(strides=[2, 2], pads=[2, 2, 2, 2])),
+              ((2, 3, 16, 16), (64, 3, 3, 3), dict(strides=[1, 1], pads=[1, 1, 1, 1])),
+              ((1, 3, 12, 40), (8, 3, 3, 5), dict(strides=[1, 2], pads=[0, 2, 0, 2]))]
+    for xs, ks, p in shapes:
+        x = rng.standard_normal(xs).astype(np.float32)
+        k = (rng.standard_normal(ks) * 0.1).astype(np.float32)
+        b = rng.standard_normal(ks[0]).astype(np.float32)
+        sc = rng.uniform(0.5, 1.5, (1, ks[0], 1, 1)).astype(np.float32)
+        sh = rng.standard_normal((1, ks[0], 1, 1)).astype(np.float32)
+        dx, wq = pa.asarray(x), q4.prepare_rowpack_weights(pa.asarray(k))
+        ref = np.ascontiguousarray(onp.conv2d(x, k, b, **p))
+        yq = q4.ConvQ4(dx, wq, pa.asarray(b), w_layout=6, **p)
+        assert_close(q4.from_q4(yq).get(), ref, RTOL, "rowpack %s" % (xs,))
+        np.testing.assert_array_equal(yq.get(), q4_host(q4.from_q4(yq).get()))
+        ref2 = onp.relu(onp.batchnorm(np.ascontiguousarray(onp.conv2d(x, k, **p)), sc, sh))
+        y2 = q4.from_q4(q4.ConvQ4(dx, wq, None, pa.asarray(sc), pa.asarray(sh), None, act=1, w_layout=6, **p)).get()
+        assert_close(y2, ref2, RTOL, "rowpack fused %s" % (xs,))
+    # every channel-quad tile configuration and split-K on the stem-like shape
+    xs, ks, p = shapes[0]
+    x = rng.standard_normal(xs).astype(np.float32)
+    k = (rng.standard_normal(ks) * 0.1).astype(np.float32)
+    ref = np.ascontiguousarray(onp.conv2d(x, k, **p))
+    dx, wq = pa.asarray(x), q4.prepare_rowpack_weights(pa.asarray(k))
+    try:
+        for name in [n for n in names if n.startswith("q")]:
+            for split in (1, 2, 3):
+                ctx.set_conv_config(names.index(name), split)
+                y = q4.from_q4(q4.ConvQ4(dx, wq, w_layout=6, **p)).get()
+                assert_close(y, ref, RTOL, "rowpack cfg %s split %d" % (name, split))
+    finally:
+        ctx.set_conv_config(-1, 0)
+    with pytest.raises(ValueError):
+        q4.ConvQ4(dx, wq, w_layout=6, strides=[2, 2], pads=[3, 3, 3, 3], dilations=[2, 2])

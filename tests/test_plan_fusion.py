@@ -144,24 +144,28 @@ def _layout_program(mod, x):
     body, flow, _ = fuse_flow(g["layers"], g["flow"], inits, shapes)
     body, flow, nq4 = assign_layouts(body, flow, inits, shapes)
     kinds = {b_[0]: b_[1] for b_ in body}
-    return [(kinds[f[1][0]], f[0], f[2]) for f in flow], nq4
+    paras = {b_[0]: b_[2] for b_ in body}
+    return [(kinds[f[1][0]], f[0], f[2], paras[f[1][0]]) for f in flow], nq4
 
 
 def test_layouts_resnet18_one_conversion_in_none_out():
     steps, nq4 = _layout_program(resnet18, resnet18.make_input(1, size=64))
-    kinds = [k for k, _, _ in steps]
-    assert kinds.count("to_q4") == 1 and kinds[0] == "to_q4" and "from_q4" not in kinds
+    kinds = [k for k, _, _, _ in steps]
+    # the 3-channel stem reads the NCHW input itself (row-packed kernel): no conversion step at all
+    assert "to_q4" not in kinds and "from_q4" not in kinds
+    assert kinds[0] == "conv_q4" and steps[0][3].get("rowpack") and steps[0][1][0] == "x"
+    assert sum(1 for s_ in steps if s_[3].get("rowpack")) == 1
     assert kinds.count("conv_q4") == 20 and "conv_fused" not in kinds
     assert "maxpool_q4" in kinds and "gap_q4" in kinds          # gap hands NCHW to flatten/dense
     assert kinds[-3:] == ["flatten", "dense", "return"]
     # residual operands are read in Q4 directly (no conversions around them)
-    assert all(not s.endswith("@nchw") for _, srcs, _ in steps for s in srcs)
+    assert all(not s.endswith("@nchw") for _, srcs, _, _ in steps for s in srcs)
 
 
 def test_layouts_yolov3_outputs_are_converted_back():
     steps, _ = _layout_program(yolov3, yolov3.make_input(1, size=64))
-    kinds = [k for k, _, _ in steps]
-    assert kinds.count("to_q4") == 1
+    kinds = [k for k, _, _, _ in steps]
+    assert "to_q4" not in kinds and steps[0][3].get("rowpack")      # 3 -> 32 first conv: row-packed
     assert "upsample_q4" in kinds and "concat_q4" in kinds
     # the three detection heads (255 channels -> padded quads) come back as NCHW for `return`
     assert kinds.count("from_q4") == 3 and kinds[-1] == "return"
@@ -190,5 +194,5 @@ def test_layouts_lone_conv_with_a_large_output_stays_nchw():
     shp = {"x": (8, 3, 224, 224), "K": (64, 3, 3, 3), "B": (64,), "y": (8, 64, 224, 224)}
     body, out, nq4 = assign_layouts(layers, flow, ["K", "B"], shp)
     assert nq4 == 0 and [b_[1] for b_ in body] == ["conv"] and out == [[["x", "K", "B"], ["c"], "y"]]
-    _, out, nq4 = assign_layouts(layers, flow, ["K", "B"], shp, force=True)
-    assert nq4 == 1 and len(out) == 3
+    body, out, nq4 = assign_layouts(layers, flow, ["K", "B"], shp, force=True)
+    assert nq4 == 1 and len(out) == 2 and body[0][2].get("rowpack")           # conv (NCHW in) + from_q4

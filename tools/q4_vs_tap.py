@@ -77,6 +77,10 @@ if "--resnet" in sys.argv or len(sys.argv) == 1:
         t_q4 = timeit(lambda: q4.ConvQ4(xq, wq, None, sc, sh, resq, act=1, **kw))
         fl = 2.0 * xs[0] * ks[0] * ho * ho * ks[1] * ks[2] * ks[3]
         extra = ""
+        if q4.rowpack_eligible(ks, **kw):
+            wr = q4.prepare_rowpack_weights(k)
+            t_r = timeit(lambda: q4.ConvQ4(x, wr, None, sc, sh, resq, act=1, w_layout=6, **kw))
+            extra = " | row-packed (incl. input re-layout) %7.1f us %6.1f TF" % (t_r * 1e3, fl / t_r / 1e9)
         if q4.w1d_q4_eligible(ks, **kw):
             uq = q4.prepare_w1d_q4_weights(k)
             t_w = timeit(lambda: q4.ConvQ4(xq, uq, None, sc, sh, resq, act=1, w_layout=5, **kw))

@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(256) mix(const float *g, float *out, int chunk
                 bf[u][b] = V >= 1 ? *reinterpret_cast<const float4 *>(fb + (RS ? 1024 : 0) + (V >= 13 ? b * 128 + u * 1024 : b * 640 + u * 8) + (c & 1) * (RS ? 2560 : 2048))
                                   : make_float4(c - b, u, lane, 2.f);
         }
-        if (V == 13 || V == 14) {
+        if (V == 13 || V == 14 || V == 16) {
             // x: [32][32 quads][32][32][4]; w: [K/4][128][4]; one b128 per (pixel, channel quad)
             const int tap = (c >> 3) % 9, cq0 = (c & 7) * 4;
             const int dy = tap / 3 - 1, dx = tap % 3 - 1;
@@ -51,7 +51,9 @@ __global__ void __launch_bounds__(256) mix(const float *g, float *out, int chunk
 #pragma unroll
             for (int ps = 0; ps < 2; ++ps) {
                 const int soff = ((cq0 + (tid >> 7) + ps * 2) * 1024) << 4;
-                lb0[ps] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+                // V16: 16-byte loads at 4-byte alignment, 24 bytes between lanes (row-packed 3-channel stem)
+                const int vo = V == 16 ? (ok ? (((n & 31) * 32 * 1024 + (h + dy) * 32) << 4) + (w + dx) * 24 + 4 : (int)0x80000000) : voff;
+                lb0[ps] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, soff, 0));
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -275,7 +277,7 @@ int main() {
         run<5, 2, 2>(g, out, per, 72); run<6, 2, 2>(g, out, per, 72);
         run<7, 2, 2>(g, out, per, 72); run<8, 2, 2>(g, out, per, 72);
         run<9, 2, 2>(g, out, per, 72); run<10, 2, 2>(g, out, per, 72);
-        run<11, 2, 2>(g, out, per, 72); run<12, 2, 2>(g, out, per, 72); run<13, 2, 2>(g, out, per, 72); run<14, 2, 2>(g, out, per, 72); run_dma(g, out, per, 72);
+        run<11, 2, 2>(g, out, per, 72); run<12, 2, 2>(g, out, per, 72); run<13, 2, 2>(g, out, per, 72); run<14, 2, 2>(g, out, per, 72); run<16, 2, 2>(g, out, per, 72); run_dma(g, out, per, 72);
     }
     return 0;
     for (int ch : {72, 36, 16}) {
