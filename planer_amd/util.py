@@ -77,63 +77,74 @@ def _stack(arrays):
     return out
 
 
+class _Tiling:
+    """Geometry of one tiled run (host arithmetic only), following util.tile's rules
+    (util.py:300-316): the working size after `sample`, growth of images smaller than the window to
+    a multiple of `glob`, the window extents, the margin in pixels and the window grid."""
+
+    def __init__(self, height, width, sample, glob, window, margin):
+        self.src = [height, width]
+        work = list(sample) if isinstance(sample, tuple) else [int(height * sample), int(width * sample)]
+        extent = [window, window]
+        for axis in (0, 1):
+            if window > work[axis]:                      # smaller than one window: a single, glob-aligned one
+                extent[axis] = work[axis] = math.ceil(work[axis] / glob) * glob
+        self.work, self.win_h, self.win_w = work, extent[0], extent[1]
+        self.margin = int(window * margin) if isinstance(margin, float) else margin
+        self.windows = grid_slice(work[0], work[1], self.win_h, self.win_w, self.margin)
+        self.resampled = work != self.src
+
+    def back_size(self, k):
+        return int(self.src[0] * k), int(self.src[1] * k)
+
+
+_TILE_KEYS = ("sample", "window", "glob", "margin", "progress", "batched")
+
+
 def tile(sample=1, glob=1, window=1024, margin=0.1, astype="float32", progress=print, batched=False):
     """util.tile (util.py:291-348).  sample: float factor or (h, w) size; glob: images smaller than
     the window are grown to a multiple of it; window: tile size after resampling; margin: overlap
-    between windows (float = fraction of the window, int = pixels)."""
-    def wrapf(f):
-        def wrap(*p, **key):
-            ori = p[0]
-            on_host = isinstance(ori, numpy.ndarray)
-            img = hip.asarray(numpy.ascontiguousarray(ori, dtype=numpy.float32)) if on_host else ori
-            _f32(img)
-            h, w = img.shape[:2]
-            tps = {"sample", "window", "glob", "margin", "progress", "batched"}
-            fp = {k: v for k, v in key.items() if k not in tps}
-            tp = {k: v for k, v in key.items() if k in tps}
-            ssz = tp.get("sample", sample)
-            wsz = wsh = wsw = tp.get("window", window)
-            gsz = tp.get("glob", glob)
-            mar = tp.get("margin", margin)
-            info = tp.get("progress", progress)
-            stacked = tp.get("batched", batched)
-            ssz = list(ssz) if isinstance(ssz, tuple) else [int(h * ssz), int(w * ssz)]
-            if wsh > ssz[0]:
-                wsh = ssz[0] = math.ceil(ssz[0] / gsz) * gsz
-            if wsw > ssz[1]:
-                wsw = ssz[1] = math.ceil(ssz[1] / gsz) * gsz
-            if ssz != [h, w]:
-                img = resize(img, ssz)
-            if isinstance(mar, float):
-                mar = int(wsz * mar)
-            rcs = grid_slice(*ssz, wsh, wsw, mar)
-            if len(rcs) > 1:
-                info(1, len(rcs))
-            if stacked:
-                results = f(_stack([_window(img, rc) for rc in rcs]), *p[1:], **fp)
-                rst = results[0]
+    between windows (float = fraction of the window, int = pixels).  Every knob can be overridden
+    per call by keyword, as in the reference."""
+    defaults = dict(sample=sample, glob=glob, window=window, margin=margin, progress=progress, batched=batched)
+
+    def decorate(f):
+        def run(image, *rest, **kw):
+            opt = dict(defaults, **{k: kw.pop(k) for k in list(kw) if k in _TILE_KEYS})
+            host_in = isinstance(image, numpy.ndarray)
+            dev = hip.asarray(numpy.ascontiguousarray(image, dtype=numpy.float32)) if host_in else image
+            _f32(dev)
+            geo = _Tiling(dev.shape[0], dev.shape[1], opt["sample"], opt["glob"], opt["window"], opt["margin"])
+            if geo.resampled:
+                dev = resize(dev, geo.work)
+            n = len(geo.windows)
+            report = opt["progress"]
+            if n > 1:
+                report(1, n)
+            if opt["batched"]:                                 # all windows through f as ONE batch
+                outs = f(_stack([_window(dev, rc) for rc in geo.windows]), *rest, **kw)
+                produce = lambda i: outs[i]
             else:
-                results = None
-                rst = f(_window(img, rcs[0]), *p[1:], **fp)
-            k = rst.shape[0] / (rcs[0][0].stop - rcs[0][0].start)
-            if len(rcs) == 1:
-                if ssz != [h, w]:
-                    rst = resize(rst, (int(h * k), int(w * k)))
-                return rst.get() if on_host else rst
-            oh, ow = int(img.shape[0] * k), int(img.shape[1] * k)
-            ch = rst.size // (rst.shape[0] * rst.shape[1])
-            m = int(mar * k)
-            buf = hip.zeros((oh, ow) + tuple(rst.shape[2:]), ctx=img.ctx)
-            count = hip.zeros((oh, ow), ctx=img.ctx)
-            for i, rc in enumerate(rcs):
-                if i > 0:
-                    info(i + 1, len(rcs))
-                    rst = results[i] if stacked else f(_window(img, rc), *p[1:], **fp)
-                _lib.call("pl_tile_accumulate_f32", img.ctx.handle, rst.ptr, buf.ptr, count.ptr, rst.shape[0],
-                          rst.shape[1], ch, int(rc[0].start * k), int(rc[1].start * k), oh, ow, m)
-            _lib.call("pl_tile_normalise_f32", img.ctx.handle, buf.ptr, count.ptr, oh, ow, ch)
-            if ssz != [h, w]:
-                buf = resize(buf, (int(h * k), int(w * k)))
-            return buf.get() if on_host else buf
-        return wrap
-    return wrapf
+                produce = lambda i: f(_window(dev, geo.windows[i]), *rest, **kw)
+            first = produce(0)
+            k = first.shape[0] / geo.win_h                     # output pixels per input pixel
+            if n == 1:
+                result = resize(first, geo.back_size(k)) if geo.resampled else first
+                return result.get() if host_in else result
+            # blend buffers in HBM: weighted sum and weight total (util.py:327-344)
+            oh, ow = int(dev.shape[0] * k), int(dev.shape[1] * k)
+            chans = first.size // (first.shape[0] * first.shape[1])
+            total = hip.zeros((oh, ow) + tuple(first.shape[2:]), ctx=dev.ctx)
+            weight = hip.zeros((oh, ow), ctx=dev.ctx)
+            ramp = int(geo.margin * k)
+            for i, (rows, cols) in enumerate(geo.windows):
+                if i:
+                    report(i + 1, n)
+                piece = first if i == 0 else produce(i)
+                _lib.call("pl_tile_accumulate_f32", dev.ctx.handle, piece.ptr, total.ptr, weight.ptr, piece.shape[0],
+                          piece.shape[1], chans, int(rows.start * k), int(cols.start * k), oh, ow, ramp)
+            _lib.call("pl_tile_normalise_f32", dev.ctx.handle, total.ptr, weight.ptr, oh, ow, chans)
+            result = resize(total, geo.back_size(k)) if geo.resampled else total
+            return result.get() if host_in else result
+        return run
+    return decorate
