@@ -171,6 +171,17 @@ int pl_conv2d_rowpack_q4_f32(pl_ctx *ctx, const float *x, int N, int Cin, int H,
                              float *yq, int sh, int sw, int pt, int pl, const float *scale,
                              const float *shift, const float *resq, int act, double alpha);
 
+/* Winograd F(4x4,3x3) on Q4 tensors (same constraints as the F(2x2,3x3) entry points): 6x6 input
+ * tiles, 36 grouped GEMMs, 4x fewer multiplies than the direct conv and less transform traffic
+ * than F(2x2,3x3); larger transform constants, error a few 1e-6 of max|y| in fp32.
+ * uq = [36][k-quad][Cout][4]. */
+int pl_conv2d_winograd4_q4_filter_elems(int Cout, int Cin, size_t *elems);
+int pl_conv2d_prepare_winograd4_q4_f32(pl_ctx *ctx, const float *w, int Cout, int Cin, float *out);
+int pl_conv2d_winograd4_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W,
+                               const float *uq, int Cout, const float *bias, float *yq,
+                               const float *scale, const float *shift, const float *resq,
+                               int act, double alpha);
+
 /* Fused 1-D Winograd F(2,3) along W on Q4 tensors (3x3 / stride 1 / pad 1 / group 1, Cin %% 4 == 0):
  * 1.5x fewer multiplies than the direct conv with NO extra HBM traffic -- the input transform
  * happens between the global load and LDS, the output transform in registers (conv_w1d_kernel.h).

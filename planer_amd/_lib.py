@@ -61,6 +61,9 @@ SIGNATURES = {
     "pl_conv2d_winograd_q4_filter_elems": [_I, _I, POINTER(c_size_t)],
     "pl_conv2d_prepare_winograd_q4_f32": [_P, _P, _I, _I, _P],
     "pl_conv2d_winograd_q4_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, c_double],
+    "pl_conv2d_winograd4_q4_filter_elems": [_I, _I, POINTER(c_size_t)],
+    "pl_conv2d_prepare_winograd4_q4_f32": [_P, _P, _I, _I, _P],
+    "pl_conv2d_winograd4_q4_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, c_double],
     "pl_conv2d_rowpack_filter_elems": [_I, _I, _I, _I, POINTER(c_size_t)],
     "pl_conv2d_prepare_rowpack_f32": [_P, _P, _I, _I, _I, _I, _P],
     "pl_conv2d_rowpack_q4_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, c_double],

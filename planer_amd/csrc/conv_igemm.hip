@@ -1430,6 +1430,180 @@ int winograd_q4_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int 
     return rc;
 }
 
+// ---- Winograd F(4x4,3x3) on channel-quad tensors ----------------------------------------------------
+// Same pipeline as F(2x2,3x3) above (filter transform once, input transform, ONE grouped 1x1 conv on
+// conv_q4_kernel -- here 36 groups --, output transform with the fused tail) with 6x6 input tiles that
+// yield 4x4 outputs: 36 products per 16 outputs = 4x fewer multiplies than the direct conv (2.25x for
+// F(2,3)) and LESS transform traffic (V holds 36 values per 16 pixels instead of 16 per 4).  The
+// transforms use the standard interpolation points 0, +-1, +-2, inf:
+//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//   G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+//   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+// Larger constants than F(2,3): the fp32 error is a few 1e-6 of max|y| (measured in the tests, bar
+// 1e-4).  Threads work on single floats of the Q4 arrays (thread = (channel quad, tile, lane)), so
+// 36 values fit in registers; four neighbouring lanes form the 16-byte accesses.
+__device__ __forceinline__ void w4_bt(const float (&d)[6], float (&o)[6]) {      // o = B^T d
+    o[0] = 4.f * d[0] - 5.f * d[2] + d[4];
+    o[1] = -4.f * (d[1] + d[2]) + d[3] + d[4];
+    o[2] = 4.f * (d[1] - d[2]) - d[3] + d[4];
+    o[3] = 2.f * (d[3] - d[1]) - d[2] + d[4];
+    o[4] = 2.f * (d[1] - d[3]) - d[2] + d[4];
+    o[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+}
+__device__ __forceinline__ void w4_at(const float (&m)[6], float (&o)[4]) {      // o = A^T m
+    const float p = m[1] + m[2], q = m[1] - m[2], r = m[3] + m[4], t = m[3] - m[4];
+    o[0] = m[0] + p + r;
+    o[1] = q + 2.f * t;
+    o[2] = p + 4.f * r;
+    o[3] = q + 8.f * t + m[5];
+}
+
+// uq[f = 6a+b][q = cin/4][co][cin%4] = (G g G^T)[a][b], zero padded to Qpad k-quads
+__global__ void __launch_bounds__(256) wino4_filter_q4_kernel(const float *w, float *Uq, unsigned total, int Cin, int Cout,
+                                                              int Qpad) {
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;   // (co, c) pair
+    if (i >= total) return;
+    const int co = (int)(i / (unsigned)Cin), c = (int)(i - (unsigned)co * Cin);
+    const float *g = w + (size_t)i * 9;
+    float t[6][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float g0 = g[j], g1 = g[3 + j], g2 = g[6 + j];
+        t[0][j] = g0 * 0.25f;
+        t[1][j] = -(g0 + g1 + g2) * (1.f / 6.f);
+        t[2][j] = (-g0 + g1 - g2) * (1.f / 6.f);
+        t[3][j] = g0 * (1.f / 24.f) + g1 * (1.f / 12.f) + g2 * (1.f / 6.f);
+        t[4][j] = g0 * (1.f / 24.f) - g1 * (1.f / 12.f) + g2 * (1.f / 6.f);
+        t[5][j] = g2;
+    }
+    const size_t plane = (size_t)Qpad * Cout * 4;
+    float *up = Uq + ((size_t)(c >> 2) * Cout + co) * 4 + (c & 3);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        const float g0 = t[a][0], g1 = t[a][1], g2 = t[a][2];
+        up[(size_t)(a * 6 + 0) * plane] = g0 * 0.25f;
+        up[(size_t)(a * 6 + 1) * plane] = -(g0 + g1 + g2) * (1.f / 6.f);
+        up[(size_t)(a * 6 + 2) * plane] = (-g0 + g1 - g2) * (1.f / 6.f);
+        up[(size_t)(a * 6 + 3) * plane] = g0 * (1.f / 24.f) + g1 * (1.f / 12.f) + g2 * (1.f / 6.f);
+        up[(size_t)(a * 6 + 4) * plane] = g0 * (1.f / 24.f) - g1 * (1.f / 12.f) + g2 * (1.f / 6.f);
+        up[(size_t)(a * 6 + 5) * plane] = g2;
+    }
+}
+
+// V[f][cq][t][e] = (B^T d B)[f];  thread i = ((cq*T + t)*4 + e)
+__global__ void __launch_bounds__(256) wino4_input_q4_kernel(const float *x, float *V, const WinoArgs p, int Cq,
+                                                             unsigned total) {
+    const unsigned stride = gridDim.x * 256;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        const unsigned e = i & 3, it = i >> 2;
+        unsigned cq, t, n, r, ty, tx;
+        p.divT.divmod(it, cq, t);
+        p.divTw.divmod(t, r, tx);
+        p.divTh.divmod(r, n, ty);
+        const int h0 = (int)ty * 4 - 1, w0 = (int)tx * 4 - 1;
+        const float *xp = x + (((size_t)n * Cq + cq) * p.H * p.W) * 4 + e;
+        float m[6][6];
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {                     // columns first: m[.][b] = B^T d[.][b]
+            float d[6], o[6];
+            const int wi = w0 + b;
+            const bool wok = (unsigned)wi < (unsigned)p.W;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                const int hi = h0 + a;
+                d[a] = (wok && (unsigned)hi < (unsigned)p.H) ? xp[((size_t)hi * p.W + wi) * 4] : 0.f;
+            }
+            w4_bt(d, o);
+#pragma unroll
+            for (int a = 0; a < 6; ++a) m[a][b] = o[a];
+        }
+        const size_t plane = (size_t)Cq * p.T * 4;
+        float *vp = V + (size_t)it * 4 + e;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {                     // then rows: V[a][.] = B^T m[a][.]
+            float o[6];
+            w4_bt(m[a], o);
+#pragma unroll
+            for (int b = 0; b < 6; ++b) vp[(size_t)(a * 6 + b) * plane] = o[b];
+        }
+    }
+}
+
+// y = epilogue(A^T m A);  thread i = ((coq*T + t)*4 + e)
+__global__ void __launch_bounds__(256) wino4_output_q4_kernel(const float *M, float *y, const WinoArgs p, int Coq,
+                                                              unsigned total) {
+    const unsigned stride = gridDim.x * 256;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        const unsigned e = i & 3, it = i >> 2;
+        unsigned coq, t, n, r, ty, tx;
+        p.divT.divmod(it, coq, t);
+        p.divTw.divmod(t, r, tx);
+        p.divTh.divmod(r, n, ty);
+        const size_t plane = (size_t)Coq * p.T * 4;
+        const float *mp = M + (size_t)it * 4 + e;
+        float s[4][6];
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {                     // columns: s[.][b] = A^T m[.][b]
+            float m[6], o[4];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) m[a] = mp[(size_t)(a * 6 + b) * plane];
+            w4_at(m, o);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) s[a][b] = o[a];
+        }
+        const int c = (int)coq * 4 + (int)e;              // Cout % 4 == 0: every lane is a real channel
+        const int ho = (int)ty * 4, wo = (int)tx * 4;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            if (ho + a >= p.Ho) continue;
+            float o[4];
+            w4_at(s[a], o);
+            const size_t row = ((((size_t)n * Coq + coq) * p.Ho + ho + a) * p.Wo + wo) * 4 + e;
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                if (wo + b < p.Wo) y[row + (size_t)b * 4] = apply_epilogue(p.ep, o[b], c, row + (size_t)b * 4);
+        }
+    }
+}
+
+int winograd4_q4_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const float *Uq, int Cout,
+                        const float *bias, float *yq, const float *scale, const float *shift, const float *resq,
+                        int act, double alpha) {
+    WinoArgs p;
+    p.N = N; p.C = Cin; p.H = H; p.W = W; p.Cout = Cout; p.Ho = H; p.Wo = W;
+    p.th = (H + 3) / 4; p.tw = (W + 3) / 4; p.T = N * p.th * p.tw;
+    const int Cq = Cin / 4, Coq = Cout / 4;
+    const size_t vin = (size_t)36 * Cin * p.T, vout = (size_t)36 * Cout * p.T;
+    PL_REQUIRE(vin < (1ull << 29) && vout < (1ull << 31) && (size_t)Cin * p.T < (1ull << 32) &&
+                   (size_t)Cout * p.T < (1ull << 32), PL_EUNSUPPORTED, "winograd F(4,3): tensor too large");
+    p.divT = FastDiv(p.T); p.divTw = FastDiv(p.tw); p.divTh = FastDiv(p.th);
+    p.ep = make_epilogue(bias, scale, shift, resq, act, alpha);
+    float *V = nullptr, *M = nullptr;
+    int rc = pl_alloc(ctx, vin * sizeof(float), (void **)&V);
+    if (rc != PL_OK) return rc;
+    rc = pl_alloc(ctx, vout * sizeof(float), (void **)&M);
+    if (rc != PL_OK) {
+        pl_free(ctx, V);
+        return rc;
+    }
+    const unsigned cap = (unsigned)(ctx->cu_count > 0 ? ctx->cu_count : 256) * 8;
+    const unsigned tin = (unsigned)((size_t)Cin * p.T), tout = (unsigned)((size_t)Cout * p.T);
+    wino4_input_q4_kernel<<<std::min(cap, (tin + 255) / 256), 256, 0, ctx->stream>>>(xq, V, p, Cq, tin);
+    rc = conv_launch(ctx, V, 1, 36 * Cin, N * p.th, p.tw, Uq, 36 * Cout, 1, 1, nullptr, M, 1, 1, 1, 1, 0, 0, 0, 0, 36,
+                     nullptr, nullptr, nullptr, PL_ACT_NONE, 0.0, 2);
+    if (rc == PL_OK) {
+        wino4_output_q4_kernel<<<std::min(cap, (tout + 255) / 256), 256, 0, ctx->stream>>>(M, yq, p, Coq, tout);
+        hipError_t le = hipGetLastError();
+        if (le != hipSuccess) {
+            pl_set_error("winograd F(4,3) transform launch: %s", hipGetErrorString(le));
+            rc = PL_EHIP;
+        }
+    }
+    pl_free(ctx, M);
+    pl_free(ctx, V);
+    return rc;
+}
+
 #include "conv_w1d_kernel.h"
 
 int w1d_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const float *uq, int Cout, const float *bias,
@@ -1594,6 +1768,42 @@ int pl_conv2d_w1d_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int H, in
     if (N == 0) return PL_OK;
     CtxGuard guard(ctx);
     return w1d_launch(ctx, xq, N, Cin, H, W, uq, Cout, bias, yq, scale, shift, resq, act, alpha);
+}
+
+int pl_conv2d_winograd4_q4_filter_elems(int Cout, int Cin, size_t *elems) {
+    PL_REQUIRE(elems && Cout > 0 && Cin > 0, PL_EINVAL, "pl_conv2d_winograd4_q4_filter_elems: bad argument");
+    *elems = (size_t)36 * (((size_t)Cin / 4 + 7) / 8 * 8) * Cout * 4;
+    return PL_OK;
+}
+
+int pl_conv2d_prepare_winograd4_q4_f32(pl_ctx *ctx, const float *w, int Cout, int Cin, float *out) {
+    PL_REQUIRE(ctx && w && out, PL_EINVAL, "pl_conv2d_prepare_winograd4_q4_f32: null pointer");
+    PL_REQUIRE(Cout > 0 && Cin > 0 && Cin % 4 == 0 && Cout % 4 == 0, PL_EINVAL,
+               "winograd F(4,3) Q4 filters need Cin %% 4 == 0 and Cout %% 4 == 0");
+    const size_t pairs = (size_t)Cout * Cin;
+    size_t elems = 0;
+    pl_conv2d_winograd4_q4_filter_elems(Cout, Cin, &elems);
+    PL_REQUIRE(elems < (1ull << 29), PL_EUNSUPPORTED, "filter too large");
+    CtxGuard g(ctx);
+    PL_HIP(hipMemsetAsync(out, 0, elems * sizeof(float), ctx->stream));       // k-quad padding
+    wino4_filter_q4_kernel<<<(unsigned)((pairs + 255) / 256), 256, 0, ctx->stream>>>(w, out, (unsigned)pairs, Cin, Cout,
+                                                                                    (Cin / 4 + 7) / 8 * 8);
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
+
+int pl_conv2d_winograd4_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const float *uq, int Cout,
+                               const float *bias, float *yq, const float *scale, const float *shift,
+                               const float *resq, int act, double alpha) {
+    PL_REQUIRE(ctx && xq && uq && yq, PL_EINVAL, "pl_conv2d_winograd4_q4_f32: null pointer");
+    PL_REQUIRE(N >= 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0 && Cin % 4 == 0 && Cout % 4 == 0, PL_EINVAL,
+               "pl_conv2d_winograd4_q4_f32: bad shape (Cin, Cout must be multiples of 4)");
+    PL_REQUIRE(act >= 0 && (act & 15) <= 2 && (act & ~31) == 0, PL_EINVAL, "pl_conv2d_winograd4_q4_f32: bad activation code");
+    PL_REQUIRE(((reinterpret_cast<uintptr_t>(xq) | reinterpret_cast<uintptr_t>(yq) | reinterpret_cast<uintptr_t>(uq) |
+                 reinterpret_cast<uintptr_t>(resq)) & 15u) == 0, PL_EINVAL, "Q4 tensors must be 16-byte aligned");
+    if (N == 0) return PL_OK;
+    CtxGuard guard(ctx);
+    return winograd4_q4_launch(ctx, xq, N, Cin, H, W, uq, Cout, bias, yq, scale, shift, resq, act, alpha);
 }
 
 int pl_conv2d_winograd_q4_filter_elems(int Cout, int Cin, size_t *elems) {

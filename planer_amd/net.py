@@ -352,12 +352,13 @@ class Net:
                         and shapes.get(srcs[0].split("@")[0]) is not None):
                     lay = self._pick_conv_algo(_q4.ConvQ4, K, srcs, entry[2], shapes, wmap, q4=True)
                 key = {2: "%s@q4g%d" % (srcs[1], group), 4: srcs[1] + "@winoq4", 5: srcs[1] + "@w1dq4",
-                       6: srcs[1] + "@rowpack"}[lay]
+                       6: srcs[1] + "@rowpack", 7: srcs[1] + "@wino4q4"}[lay]
                 if key not in self._extra:
                     self._extra[key] = {2: lambda: _q4.prepare_q4_weights(K, group),
                                         4: lambda: _q4.prepare_winograd_q4_weights(K),
                                         5: lambda: _q4.prepare_w1d_q4_weights(K),
-                                        6: lambda: _q4.prepare_rowpack_weights(K)}[lay]()
+                                        6: lambda: _q4.prepare_rowpack_weights(K),
+                                        7: lambda: _q4.prepare_winograd4_q4_weights(K)}[lay]()
                 srcs[1] = key
                 out_body[name] = [name, "conv_q4", dict(entry[2], w_layout=lay)]
             elif entry[1] in ("conv", "conv_fused") and len(srcs) >= 2 and srcs[1] in wmap:
@@ -398,6 +399,8 @@ class Net:
             if _q4.winograd_q4_eligible(K.shape, **{k: v for k, v in para.items()
                                                    if k in ("group", "strides", "dilations", "pads")}):
                 cands.append((4, _q4.prepare_winograd_q4_weights))
+                if os.environ.get("PLANER_HIP_WINOGRAD4", "1") != "0":
+                    cands.append((7, _q4.prepare_winograd4_q4_weights))      # F(4x4,3x3)
         args = [hip.zeros((cout,), numpy.float32, ctx) if has[0] else None, chan if has[1] else None,
                 chan if has[2] else None, res]
         kw = {k: v for k, v in para.items() if k != "w_layout"}

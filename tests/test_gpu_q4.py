@@ -262,3 +262,32 @@ def test_rowpack_stem_conv_matches_oracle(pa):
         ctx.set_conv_config(-1, 0)
     with pytest.raises(ValueError):
         q4.ConvQ4(dx, wq, w_layout=6, strides=[2, 2], pads=[3, 3, 3, 3], dilations=[2, 2])
+
+
+def test_winograd_f43_matches_oracle(pa):
+    """Winograd F(4x4,3x3) on Q4 tensors: map sizes that are / are not multiples of 4, with and
+    without the fused tail, and the real ResNet layer3/4 shapes (where its larger transform
+    constants matter most: K = 2304 / 4608).  Same 1e-4 * max|ref| bar; the measured error is printed."""
+    from planer_amd import q4
+    rng = np.random.default_rng(37)
+    worst = 0.0
+    for (n, cin, h, w, cout) in [(2, 16, 7, 7, 24), (3, 20, 14, 13, 44), (1, 64, 9, 12, 64), (2, 48, 28, 28, 32),
+                                 (4, 256, 14, 14, 256), (4, 512, 7, 7, 512)]:
+        x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+        k = (rng.standard_normal((cout, cin, 3, 3)) * (2.0 / (9 * cin)) ** 0.5).astype(np.float32)
+        b = rng.standard_normal(cout).astype(np.float32)
+        sc = rng.uniform(0.5, 1.5, (1, cout, 1, 1)).astype(np.float32)
+        sh = rng.standard_normal((1, cout, 1, 1)).astype(np.float32)
+        res = rng.standard_normal((n, cout, h, w)).astype(np.float32)
+        xq = q4.to_q4(pa.asarray(x))
+        U = q4.prepare_winograd4_q4_weights(pa.asarray(k))
+        y = q4.from_q4(q4.ConvQ4(xq, U, pa.asarray(b), pads=[1, 1, 1, 1], w_layout=7)).get()
+        ref = np.ascontiguousarray(onp.conv2d(x, k, b, pads=[1, 1, 1, 1]))
+        worst = max(worst, float(np.abs(y - ref).max() / np.abs(ref).max()))
+        assert_close(y, ref, RTOL, "winograd F(4,3) %s" % ((n, cin, h, w, cout),))
+        y = q4.from_q4(q4.ConvQ4(xq, U, None, pa.asarray(sc), pa.asarray(sh), q4.to_q4(pa.asarray(res)),
+                                 pads=[1, 1, 1, 1], act=1, w_layout=7)).get()
+        ref = onp.relu(onp.batchnorm(np.ascontiguousarray(onp.conv2d(x, k, pads=[1, 1, 1, 1])), sc, sh) + res)
+        assert_close(y, ref, RTOL, "winograd F(4,3) fused")
+    print("winograd F(4,3): worst error %.2e of max|ref|" % worst)
+    assert worst < 3e-5                       # keep a 3x margin to the 1e-4 bar

@@ -89,5 +89,9 @@ if "--resnet" in sys.argv or len(sys.argv) == 1:
                 u2 = q4.prepare_winograd_q4_weights(k)
                 t_2 = timeit(lambda: q4.ConvQ4(xq, u2, None, sc, sh, resq, act=1, w_layout=4, **kw))
                 extra += " | winograd-2d %7.1f us" % (t_2 * 1e3)
+            if ks[0] % 4 == 0:
+                u4 = q4.prepare_winograd4_q4_weights(k)
+                t_4 = timeit(lambda: q4.ConvQ4(xq, u4, None, sc, sh, resq, act=1, w_layout=7, **kw))
+                extra += " | F(4,3) %7.1f us" % (t_4 * 1e3)
         print("%-11s nchw %7.1f us %6.1f TF | q4 %7.1f us %6.1f TF | x%.2f%s" %
               (label, t_old * 1e3, fl / t_old / 1e9, t_q4 * 1e3, fl / t_q4 / 1e9, t_old / t_q4, extra), flush=True)
