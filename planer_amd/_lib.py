@@ -70,6 +70,9 @@ SIGNATURES = {
     "pl_conv2d_w1d_q4_filter_elems": [_I, _I, POINTER(c_size_t)],
     "pl_conv2d_prepare_w1d_q4_f32": [_P, _P, _I, _I, _P],
     "pl_conv2d_w1d_q4_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, c_double],
+    "pl_conv2d_w1d4_q4_filter_elems": [_I, _I, POINTER(c_size_t)],
+    "pl_conv2d_prepare_w1d4_q4_f32": [_P, _P, _I, _I, _P],
+    "pl_conv2d_w1d4_q4_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, c_double],
     "pl_pool2d_q4_f32": [_P, _P, _P] + [_I] * 13,
     "pl_upsample_nearest_q4_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I],
     "pl_gap_q4_f32": [_P, _P, _P, _I, _I, _I],

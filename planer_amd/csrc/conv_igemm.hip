@@ -1607,10 +1607,10 @@ int winograd4_q4_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int
 #include "conv_w1d_kernel.h"
 
 int w1d_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const float *uq, int Cout, const float *bias,
-               float *yq, const float *scale, const float *shift, const float *resq, int act, double alpha) {
+               float *yq, const float *scale, const float *shift, const float *resq, int act, double alpha, bool f43) {
     ConvArgs a;
     memset(&a, 0, sizeof a);
-    const int Tw = (W + 1) / 2;
+    const int Tw = f43 ? (W + 3) / 4 : (W + 1) / 2;          // output pixels per tile: 4 (F(4,3)) or 2 (F(2,3))
     a.x = xq; a.w = uq; a.y = yq;
     a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.Ho = H; a.Wo = W;
     a.kh = 3; a.kw = 3; a.sh = a.sw = a.dh = a.dw = 1; a.pt = a.pl = 1;
@@ -1621,7 +1621,7 @@ int w1d_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const
     a.cols = N * H * Tw;
     a.HoWo = H * W; a.HW = H * W;
     const size_t in_elems = (size_t)N * Cin * H * W, out_elems = (size_t)N * a.Coq * 4 * H * W;
-    const size_t w_elems = (size_t)4 * a.Qpad * Cout * 4;
+    const size_t w_elems = (size_t)(f43 ? 6 : 4) * a.Qpad * Cout * 4;
     PL_REQUIRE(in_elems < (1ull << 29) && out_elems < (1ull << 31) && w_elems < (1ull << 29) &&
                    (size_t)N * H * Tw < (1ull << 31), PL_EUNSUPPORTED, "winograd-1d: tensor too large");
     a.x_bytes = (int)(in_elems * 4); a.w_bytes = (int)(w_elems * 4);
@@ -1633,9 +1633,15 @@ int w1d_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const
     a.divMt = FastDiv(a.mtiles);
     a.tile_offset = 0; a.tile_count = a.tiles; a.splits = 1;
     a.ep = make_epilogue(bias, scale, shift, resq, act, alpha);
-    int rc = ensure_lds_attr((const void *)conv_w1d_kernel, W1dCfg::LDS_BYTES);
-    if (rc != PL_OK) return rc;
-    hipLaunchKernelGGL(conv_w1d_kernel, dim3((unsigned)a.tiles), dim3(256), W1dCfg::LDS_BYTES, ctx->stream, a);
+    if (f43) {
+        int rc = ensure_lds_attr((const void *)conv_w1d4_kernel, W1d4Cfg::LDS_BYTES);
+        if (rc != PL_OK) return rc;
+        hipLaunchKernelGGL(conv_w1d4_kernel, dim3((unsigned)a.tiles), dim3(256), W1d4Cfg::LDS_BYTES, ctx->stream, a);
+    } else {
+        int rc = ensure_lds_attr((const void *)conv_w1d_kernel, W1dCfg::LDS_BYTES);
+        if (rc != PL_OK) return rc;
+        hipLaunchKernelGGL(conv_w1d_kernel, dim3((unsigned)a.tiles), dim3(256), W1dCfg::LDS_BYTES, ctx->stream, a);
+    }
     PL_LAUNCH_CHECK();
     return PL_OK;
 }
@@ -1733,13 +1739,26 @@ int pl_conv2d_rowpack_q4_f32(pl_ctx *ctx, const float *x, int N, int Cin, int H,
     return rc;
 }
 
-int pl_conv2d_w1d_q4_filter_elems(int Cout, int Cin, size_t *elems) {
-    PL_REQUIRE(elems && Cout > 0 && Cin > 0, PL_EINVAL, "pl_conv2d_w1d_q4_filter_elems: bad argument");
-    *elems = (size_t)4 * (((size_t)3 * (Cin / 4) + 7) / 8 * 8) * Cout * 4;
+static int w1d_filter_elems(int Cout, int Cin, int freqs, size_t *elems) {
+    PL_REQUIRE(elems && Cout > 0 && Cin > 0, PL_EINVAL, "winograd-1d filter size: bad argument");
+    *elems = (size_t)freqs * (((size_t)3 * (Cin / 4) + 7) / 8 * 8) * Cout * 4;
     return PL_OK;
 }
 
+int pl_conv2d_w1d_q4_filter_elems(int Cout, int Cin, size_t *elems) { return w1d_filter_elems(Cout, Cin, 4, elems); }
+int pl_conv2d_w1d4_q4_filter_elems(int Cout, int Cin, size_t *elems) { return w1d_filter_elems(Cout, Cin, 6, elems); }
+
+static int w1d_prepare(pl_ctx *ctx, const float *w, int Cout, int Cin, float *out, bool f43);
+
 int pl_conv2d_prepare_w1d_q4_f32(pl_ctx *ctx, const float *w, int Cout, int Cin, float *out) {
+    return w1d_prepare(ctx, w, Cout, Cin, out, false);
+}
+
+int pl_conv2d_prepare_w1d4_q4_f32(pl_ctx *ctx, const float *w, int Cout, int Cin, float *out) {
+    return w1d_prepare(ctx, w, Cout, Cin, out, true);
+}
+
+static int w1d_prepare(pl_ctx *ctx, const float *w, int Cout, int Cin, float *out, bool f43) {
     PL_REQUIRE(ctx && w && out, PL_EINVAL, "pl_conv2d_prepare_w1d_q4_f32: null pointer");
     PL_REQUIRE(Cout > 0 && Cin > 0 && Cin % 4 == 0, PL_EINVAL, "winograd-1d filters need Cin %% 4 == 0");
     PL_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15u) == 0, PL_EINVAL, "pl_conv2d_prepare_w1d_q4_f32: unaligned output");
@@ -1749,15 +1768,35 @@ int pl_conv2d_prepare_w1d_q4_f32(pl_ctx *ctx, const float *w, int Cout, int Cin,
     CtxGuard g(ctx);
     unsigned blocks = (unsigned)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    pack_filter_w1d_kernel<<<blocks, 256, 0, ctx->stream>>>(w, out, (unsigned)total, Cout, Cin, cqg, q_tot, q_pad,
-                                                           FastDiv(Cout), FastDiv(cqg));
+    if (f43)
+        pack_filter_w1d4_kernel<<<blocks, 256, 0, ctx->stream>>>(w, out, (unsigned)total, Cout, Cin, cqg, q_tot, q_pad,
+                                                                FastDiv(Cout), FastDiv(cqg));
+    else
+        pack_filter_w1d_kernel<<<blocks, 256, 0, ctx->stream>>>(w, out, (unsigned)total, Cout, Cin, cqg, q_tot, q_pad,
+                                                               FastDiv(Cout), FastDiv(cqg));
     PL_LAUNCH_CHECK();
     return PL_OK;
 }
 
+static int w1d_entry(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const float *uq, int Cout,
+                     const float *bias, float *yq, const float *scale, const float *shift, const float *resq, int act,
+                     double alpha, bool f43);
+
 int pl_conv2d_w1d_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const float *uq, int Cout,
                          const float *bias, float *yq, const float *scale, const float *shift, const float *resq,
                          int act, double alpha) {
+    return w1d_entry(ctx, xq, N, Cin, H, W, uq, Cout, bias, yq, scale, shift, resq, act, alpha, false);
+}
+
+int pl_conv2d_w1d4_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const float *uq, int Cout,
+                          const float *bias, float *yq, const float *scale, const float *shift, const float *resq,
+                          int act, double alpha) {
+    return w1d_entry(ctx, xq, N, Cin, H, W, uq, Cout, bias, yq, scale, shift, resq, act, alpha, true);
+}
+
+static int w1d_entry(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const float *uq, int Cout,
+                     const float *bias, float *yq, const float *scale, const float *shift, const float *resq, int act,
+                     double alpha, bool f43) {
     PL_REQUIRE(ctx && xq && uq && yq, PL_EINVAL, "pl_conv2d_w1d_q4_f32: null pointer");
     PL_REQUIRE(N >= 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0 && Cin % 4 == 0, PL_EINVAL,
                "pl_conv2d_w1d_q4_f32: bad shape (Cin must be a multiple of 4)");
@@ -1767,7 +1806,7 @@ int pl_conv2d_w1d_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int H, in
                  reinterpret_cast<uintptr_t>(resq)) & 15u) == 0, PL_EINVAL, "Q4 tensors must be 16-byte aligned");
     if (N == 0) return PL_OK;
     CtxGuard guard(ctx);
-    return w1d_launch(ctx, xq, N, Cin, H, W, uq, Cout, bias, yq, scale, shift, resq, act, alpha);
+    return w1d_launch(ctx, xq, N, Cin, H, W, uq, Cout, bias, yq, scale, shift, resq, act, alpha, f43);
 }
 
 int pl_conv2d_winograd4_q4_filter_elems(int Cout, int Cin, size_t *elems) {

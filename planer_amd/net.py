@@ -352,13 +352,14 @@ class Net:
                         and shapes.get(srcs[0].split("@")[0]) is not None):
                     lay = self._pick_conv_algo(_q4.ConvQ4, K, srcs, entry[2], shapes, wmap, q4=True)
                 key = {2: "%s@q4g%d" % (srcs[1], group), 4: srcs[1] + "@winoq4", 5: srcs[1] + "@w1dq4",
-                       6: srcs[1] + "@rowpack", 7: srcs[1] + "@wino4q4"}[lay]
+                       6: srcs[1] + "@rowpack", 7: srcs[1] + "@wino4q4", 8: srcs[1] + "@w1d4q4"}[lay]
                 if key not in self._extra:
                     self._extra[key] = {2: lambda: _q4.prepare_q4_weights(K, group),
                                         4: lambda: _q4.prepare_winograd_q4_weights(K),
                                         5: lambda: _q4.prepare_w1d_q4_weights(K),
                                         6: lambda: _q4.prepare_rowpack_weights(K),
-                                        7: lambda: _q4.prepare_winograd4_q4_weights(K)}[lay]()
+                                        7: lambda: _q4.prepare_winograd4_q4_weights(K),
+                                        8: lambda: _q4.prepare_w1d4_q4_weights(K)}[lay]()
                 srcs[1] = key
                 out_body[name] = [name, "conv_q4", dict(entry[2], w_layout=lay)]
             elif entry[1] in ("conv", "conv_fused") and len(srcs) >= 2 and srcs[1] in wmap:
@@ -394,8 +395,8 @@ class Net:
         cands = ((1, prepare_conv_weights), (3, prepare_winograd_weights))
         if q4:
             x, res = _q4.to_q4(x), (_q4.to_q4(res) if res is not None else None)
-            # direct, fused 1-D Winograd along W, 2-D Winograd with separate transform kernels
-            cands = [(2, _q4.prepare_q4_weights), (5, _q4.prepare_w1d_q4_weights)]
+            # direct, fused 1-D Winograd along W (F(2,3) and F(4,3)), 2-D Winograd pipelines with separate transform kernels
+            cands = [(2, _q4.prepare_q4_weights), (5, _q4.prepare_w1d_q4_weights), (8, _q4.prepare_w1d4_q4_weights)]
             if _q4.winograd_q4_eligible(K.shape, **{k: v for k, v in para.items()
                                                    if k in ("group", "strides", "dilations", "pads")}):
                 cands.append((4, _q4.prepare_winograd_q4_weights))

@@ -145,6 +145,20 @@ def prepare_w1d_q4_weights(K):
     return out
 
 
+def prepare_w1d4_q4_weights(K):
+    """OIHW 3x3 filters -> fused 1-D Winograd F(4,3) filters [6][row*Cin/4 + cin/4][Cout][4] (w_layout=8)."""
+    _f32(K)
+    cout, cin, kh, kw = K.shape
+    if (kh, kw) != (3, 3) or cin % 4:
+        raise ValueError("1-D winograd filters need 3x3 kernels and Cin % 4 == 0")
+    n = ctypes.c_size_t()
+    _lib.call("pl_conv2d_w1d4_q4_filter_elems", cout, cin, ctypes.byref(n))
+    out = empty((n.value,), ctx=K.ctx)
+    _lib.call("pl_conv2d_prepare_w1d4_q4_f32", K.ctx.handle, K.ptr, cout, cin, out.ptr)
+    out.shape = K.shape
+    return out
+
+
 def w1d_q4_eligible(k_shape, group=1, strides=(1, 1), dilations=(1, 1), pads=(0, 0, 0, 0), **_):
     cout, cin_g, kh, kw = k_shape
     return (kh == 3 and kw == 3 and group == 1 and cin_g % 4 == 0 and list(strides) == [1, 1]
@@ -188,10 +202,10 @@ def ConvQ4(xq, Kq, B=None, scale=None, shift=None, resq=None, group=1, strides=(
     y = _new_q4(n, cout, ho, wo, xq.ctx)
     if resq is not None and resq.shape != y.shape:
         raise ValueError("fused residual shape %s != conv output %s" % (resq.shape, y.shape))
-    if w_layout == 5:
+    if w_layout in (5, 8):
         if not w1d_q4_eligible(Kq.shape, group, strides, dilations, pads):
             raise ValueError("1-D winograd filters serve 3x3 / stride 1 / pad 1 / group 1 convs only")
-        _lib.call("pl_conv2d_w1d_q4_f32", xq.ctx.handle, xq.ptr, n, cin, h, w, Kq.ptr, cout, _ptr(B), y.ptr,
+        _lib.call("pl_conv2d_w1d_q4_f32" if w_layout == 5 else "pl_conv2d_w1d4_q4_f32", xq.ctx.handle, xq.ptr, n, cin, h, w, Kq.ptr, cout, _ptr(B), y.ptr,
                   _ptr(scale), _ptr(shift), _ptr(resq), int(act), float(alpha))
         return y
     if w_layout in (4, 7):

@@ -291,3 +291,33 @@ def test_winograd_f43_matches_oracle(pa):
         assert_close(y, ref, RTOL, "winograd F(4,3) fused")
     print("winograd F(4,3): worst error %.2e of max|ref|" % worst)
     assert worst < 3e-5                       # keep a 3x margin to the 1e-4 bar
+
+
+def test_winograd_1d_f43_fused_matches_oracle(pa):
+    """Fused 1-D Winograd F(4,3) along W (conv_w1d4_kernel): widths that are / are not multiples of 4,
+    Cout not a multiple of 64 or 4, K tails, fused tail; error bar as for the 2-D F(4,3)."""
+    from planer_amd import q4
+    rng = np.random.default_rng(41)
+    worst = 0.0
+    for (n, cin, h, w, cout) in [(2, 16, 7, 7, 24), (3, 20, 14, 13, 44), (1, 64, 9, 12, 64), (2, 48, 28, 28, 130),
+                                 (1, 8, 5, 1, 6), (2, 4, 6, 3, 3), (2, 64, 56, 56, 64)]:
+        x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+        k = (rng.standard_normal((cout, cin, 3, 3)) * (2.0 / (9 * cin)) ** 0.5).astype(np.float32)
+        b = rng.standard_normal(cout).astype(np.float32)
+        sc = rng.uniform(0.5, 1.5, (1, cout, 1, 1)).astype(np.float32)
+        sh = rng.standard_normal((1, cout, 1, 1)).astype(np.float32)
+        res = rng.standard_normal((n, cout, h, w)).astype(np.float32)
+        xq = q4.to_q4(pa.asarray(x))
+        U = q4.prepare_w1d4_q4_weights(pa.asarray(k))
+        yq = q4.ConvQ4(xq, U, pa.asarray(b), pads=[1, 1, 1, 1], w_layout=8)
+        y = q4.from_q4(yq).get()
+        ref = np.ascontiguousarray(onp.conv2d(x, k, b, pads=[1, 1, 1, 1]))
+        worst = max(worst, float(np.abs(y - ref).max() / np.abs(ref).max()))
+        assert_close(y, ref, RTOL, "winograd-1d F(4,3) %s" % ((n, cin, h, w, cout),))
+        np.testing.assert_array_equal(yq.get(), q4_host(y))
+        y = q4.from_q4(q4.ConvQ4(xq, U, None, pa.asarray(sc), pa.asarray(sh), q4.to_q4(pa.asarray(res)),
+                                 pads=[1, 1, 1, 1], act=1, w_layout=8)).get()
+        ref = onp.relu(onp.batchnorm(np.ascontiguousarray(onp.conv2d(x, k, pads=[1, 1, 1, 1])), sc, sh) + res)
+        assert_close(y, ref, RTOL, "winograd-1d F(4,3) fused")
+    print("winograd-1d F(4,3): worst error %.2e of max|ref|" % worst)
+    assert worst < 3e-5
