@@ -213,7 +213,7 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
     if os.path.exists(tpath):
         fam = [r for r in json.load(open(tpath))
-               if any(t in r["kernel"] for t in ("conv_q4_kernel", "conv_w1d_kernel", "conv_tap_kernel", "conv_igemm_kernel",
+               if any(t in r["kernel"] for t in ("conv_q4_kernel", "conv_w1d_kernel", "conv_w1d4_kernel", "conv_tap_kernel", "conv_igemm_kernel",
                                                  "reduce_tiles", "wino_"))]
         launches = sum(r["launches"] for r in fam)
         if launches:
@@ -221,8 +221,8 @@ def main():
                                 * r["launches"] for r in fam) / launches)
             traffic_src = "profiles/r01_hbm_traffic.json: HBM bytes per conv-family kernel launch (PMC run of this command)"
     roofline = {"bound": "mfma", "kernel": "the 16 conv3x3 layers of one forward on channel-quad tensors, each on the fastest of "
-                                          "conv_q4_kernel (direct implicit GEMM, stride-2 layers), conv_w1d_kernel (fused 1-D "
-                                          "Winograd, layer1) and the 2-D Winograd pipelines F(2x2,3x3) / F(4x4,3x3) (transforms + one grouped "
+                                          "conv_q4_kernel (direct implicit GEMM, stride-2 layers), conv_w1d4_kernel (fused 1-D "
+                                          "Winograd F(4,3), layer1) and the 2-D Winograd pipelines F(2x2,3x3) / F(4x4,3x3) (transforms + one grouped "
                                           "1x1 conv_q4_kernel, layer2-4), incl. split-K tile-reduce and transform launches; "
                                           "achieved = algorithmic FLOPs / time",
                 "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -231,7 +231,7 @@ def main():
                 "flops_per_launch": c3["flops"] / c3["launches"],
                 "whole_forward_mfma_frac": round(value / world * (total_flops / n) / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
                 "whole_forward_note": "ALGORITHMIC FLOPs of the timed (pipelined) run / peak; the Winograd paths execute "
-                                      "1.5x (1-D F(2,3)), 2.25x (F(2x2,3x3)) or 4x (F(4x4,3x3)) fewer multiplies than that",
+                                      "1.5x / 2x (fused 1-D F(2,3) / F(4,3)), 2.25x (F(2x2,3x3)) or 4x (F(4x4,3x3)) fewer multiplies than that",
                 "by_class_ms": {k: round(v["ms"], 4) for k, v in sorted(classes.items())}}
 
     out = {"metric": "images/sec ResNet-18 fp32 forward", "value": round(value, 1), "unit": "images/sec",
