@@ -1529,39 +1529,55 @@ __global__ void __launch_bounds__(256) wino4_input_q4_kernel(const float *x, flo
     }
 }
 
-// y = epilogue(A^T m A);  thread i = ((coq*T + t)*4 + e)
-__global__ void __launch_bounds__(256) wino4_output_q4_kernel(const float *M, float *y, const WinoArgs p, int Coq,
+// y = epilogue(A^T m A);  thread i = coq*T + t works on float4s (the 4 channels of a quad): 36 b128
+// loads, column pass into 24 float4 registers, row pass, fused tail, one b128 store per output pixel
+__device__ __forceinline__ void w4_at4(const float4 (&m)[6], float4 (&o)[4]) {
+    const float4 p = f4sum(m[1], m[2]), q = f4sub(m[1], m[2]), r = f4sum(m[3], m[4]), t = f4sub(m[3], m[4]);
+    o[0] = f4sum(f4sum(m[0], p), r);
+    o[1] = make_float4(q.x + 2.f * t.x, q.y + 2.f * t.y, q.z + 2.f * t.z, q.w + 2.f * t.w);
+    o[2] = make_float4(p.x + 4.f * r.x, p.y + 4.f * r.y, p.z + 4.f * r.z, p.w + 4.f * r.w);
+    o[3] = make_float4(q.x + 8.f * t.x + m[5].x, q.y + 8.f * t.y + m[5].y, q.z + 8.f * t.z + m[5].z,
+                       q.w + 8.f * t.w + m[5].w);
+}
+
+__global__ void __launch_bounds__(256) wino4_output_q4_kernel(const float4 *M, float4 *y, const WinoArgs p, int Coq,
                                                               unsigned total) {
     const unsigned stride = gridDim.x * 256;
+    const float4 *res4 = reinterpret_cast<const float4 *>(p.ep.res);
     for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
-        const unsigned e = i & 3, it = i >> 2;
         unsigned coq, t, n, r, ty, tx;
-        p.divT.divmod(it, coq, t);
+        p.divT.divmod(i, coq, t);
         p.divTw.divmod(t, r, tx);
         p.divTh.divmod(r, n, ty);
-        const size_t plane = (size_t)Coq * p.T * 4;
-        const float *mp = M + (size_t)it * 4 + e;
-        float s[4][6];
+        const size_t plane = (size_t)Coq * p.T;
+        const float4 *mp = M + i;
+        float4 s[4][6];
 #pragma unroll
         for (int b = 0; b < 6; ++b) {                     // columns: s[.][b] = A^T m[.][b]
-            float m[6], o[4];
+            float4 m[6], o[4];
 #pragma unroll
             for (int a = 0; a < 6; ++a) m[a] = mp[(size_t)(a * 6 + b) * plane];
-            w4_at(m, o);
+            w4_at4(m, o);
 #pragma unroll
             for (int a = 0; a < 4; ++a) s[a][b] = o[a];
         }
-        const int c = (int)coq * 4 + (int)e;              // Cout % 4 == 0: every lane is a real channel
+        float bs[4], sc[4], sh[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) load_chan_params(p.ep, (int)coq * 4 + e, bs[e], sc[e], sh[e]);   // Cout % 4 == 0
+        const float4 bias = make_float4(bs[0], bs[1], bs[2], bs[3]), scale = make_float4(sc[0], sc[1], sc[2], sc[3]);
+        const float4 shift = make_float4(sh[0], sh[1], sh[2], sh[3]);
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         const int ho = (int)ty * 4, wo = (int)tx * 4;
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             if (ho + a >= p.Ho) continue;
-            float o[4];
-            w4_at(s[a], o);
-            const size_t row = ((((size_t)n * Coq + coq) * p.Ho + ho + a) * p.Wo + wo) * 4 + e;
+            float4 o[4];
+            w4_at4(s[a], o);
+            const size_t row = (((size_t)n * Coq + coq) * p.Ho + ho + a) * p.Wo + wo;
 #pragma unroll
             for (int b = 0; b < 4; ++b)
-                if (wo + b < p.Wo) y[row + (size_t)b * 4] = apply_epilogue(p.ep, o[b], c, row + (size_t)b * 4);
+                if (wo + b < p.Wo)
+                    y[row + b] = apply_epilogue4(p.ep, bias, scale, shift, res4 ? res4[row + b] : z, 4, o[b]);
         }
     }
 }
@@ -1587,12 +1603,13 @@ int winograd4_q4_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int
         return rc;
     }
     const unsigned cap = (unsigned)(ctx->cu_count > 0 ? ctx->cu_count : 256) * 8;
-    const unsigned tin = (unsigned)((size_t)Cin * p.T), tout = (unsigned)((size_t)Cout * p.T);
+    const unsigned tin = (unsigned)((size_t)Cin * p.T), tout = (unsigned)((size_t)Coq * p.T);
     wino4_input_q4_kernel<<<std::min(cap, (tin + 255) / 256), 256, 0, ctx->stream>>>(xq, V, p, Cq, tin);
     rc = conv_launch(ctx, V, 1, 36 * Cin, N * p.th, p.tw, Uq, 36 * Cout, 1, 1, nullptr, M, 1, 1, 1, 1, 0, 0, 0, 0, 36,
                      nullptr, nullptr, nullptr, PL_ACT_NONE, 0.0, 2);
     if (rc == PL_OK) {
-        wino4_output_q4_kernel<<<std::min(cap, (tout + 255) / 256), 256, 0, ctx->stream>>>(M, yq, p, Coq, tout);
+        wino4_output_q4_kernel<<<std::min(cap, (tout + 255) / 256), 256, 0, ctx->stream>>>((const float4 *)M, (float4 *)yq, p,
+                                                                                           Coq, tout);
         hipError_t le = hipGetLastError();
         if (le != hipSuccess) {
             pl_set_error("winograd F(4,3) transform launch: %s", hipGetErrorString(le));
