@@ -48,7 +48,11 @@ def timed(fn, reps=3):
 quiet = lambda *a: None
 t_one, o1 = timed(lambda: util.tile(window=WINDOW, margin=0.1, progress=quiet)(f_one)(dimg))
 t_all, o2 = timed(lambda: util.tile(window=WINDOW, margin=0.1, progress=quiet, batched=True)(f_all)(dimg))
-assert np.array_equal(o1.get(), o2.get())
+# per-window (batch 1) and batched (batch = #windows) calls may pick different conv algorithms
+# (direct / Winograd variants are chosen per shape by timing): equal to rounding, not bit for bit
+a1, a2 = o1.get(), o2.get()
+mode_diff = float(np.abs(a1 - a2).max() / np.abs(a1).max())
+assert mode_diff < 1e-4, mode_diff
 
 # CPU: the oracle's tile around the oracle's net on a 1024 x 1024 corner (bounded sample)
 from oracle import planer_np as onp
@@ -63,4 +67,5 @@ nwin = len(util.grid_slice(SIZE, SIZE, WINDOW, WINDOW, int(WINDOW * 0.1)))
 print(json.dumps({"metric": "tiled inference, input megapixels/sec", "image": [SIZE, SIZE], "window": WINDOW, "windows": nwin,
                   "per_window_mpix_s": round(SIZE * SIZE / t_one / 1e6, 1), "batched_mpix_s": round(SIZE * SIZE / t_all / 1e6, 1),
                   "cpu_oracle_mpix_s": round(1024 * 1024 / t_cpu / 1e6, 2), "cpu_sample": "1024x1024 corner, %d threads" % len(os.sched_getaffinity(0)),
-                  "max_rel_err_vs_oracle": err}))
+                  "max_rel_err_vs_oracle": err,
+                  "per_window_vs_batched_rel_diff": mode_diff}))
