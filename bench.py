@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Headline benchmark: images/sec of the ResNet-18 fp32 forward pass on
 MI355X, next to the numpy-CPU baseline, with the roofline of the dominant
-kernel (the 3x3 implicit-GEMM convolutions).
+kernel and a parity check of exactly what was timed.
 
     python bench.py --gpus N --steps K --warmup W
 
@@ -12,10 +12,24 @@ weight blob through ONE RCCL broadcast over xGMI; the forward pass itself has
 no collective (batch shards are independent), so scaling is weak: 32 images
 per GPU.  A step = one captured forward pass over one resident batch.
 Rank 0 prints one JSON line.
+
+What the line's numbers mean:
+  value               images/sec of the timed, pipelined run (inputs resident in HBM)
+  parity_rel_err      max|logits - oracle| / max|oracle| of the plan that was just timed
+  config.algos        which kernel family + launch plan every conv layer ran
+  roofline.frac       EXECUTED MFMA FLOPs of the dominant kernel / its device time / 157.3 TFLOP/s
+                      (= matrix-core utilisation; Winograd kernels execute 1.5-4x fewer FLOPs
+                      than the direct algorithm, padding included)
+  roofline.effective_frac  the same with ALGORITHMIC (direct-conv) FLOPs
+  roofline_hbm        the HBM-bound single-kernel layers: algorithmic bytes / time / 8 TB/s
+  cpu_baseline        the numpy oracle on the host cores of this box (all cores at batch 32 and
+                      batch 1, and OPENBLAS_NUM_THREADS=1 per-core), with library versions
 """
 import argparse
 import json
 import os
+import re
+import subprocess
 import sys
 import time
 
@@ -27,10 +41,15 @@ import numpy as np  # noqa: E402
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0
 PER_GPU_BATCH = 32                 # BASELINE.json configs[2] / configs[3]: 32 images per GPU
+PROFILE_TAG = "r02"                # profiles/<tag>_* files this build's numbers are cross-checked against
 
 
-def conv_flops(g, shapes):
-    """Algorithmic FLOPs (2*MAC) of every conv layer of the graph, by layer name."""
+def cdiv(a, b):
+    return -(-a // b)
+
+
+def conv_table(g, shapes):
+    """Every conv / dense layer of the graph: algorithmic FLOPs (2*MAC) and geometry, by layer name."""
     kinds = {n: (k, p) for n, k, p in g["layers"]}
     out = {}
     for src, names, dst in g["flow"]:
@@ -38,39 +57,121 @@ def conv_flops(g, shapes):
         if kind == "conv":
             n, cout, ho, wo = shapes[dst]
             _, cin_g, kh, kw = shapes[src[1]]
-            out[names[0]] = (2.0 * n * cout * ho * wo * cin_g * kh * kw, (kh, kw))
+            _, cin, h, w = shapes[src[0]]
+            out[names[0]] = {"flops": 2.0 * n * cout * ho * wo * cin_g * kh * kw, "k": (kh, kw), "n": n, "cin": cin,
+                             "cout": cout, "h": h, "w": w, "ho": ho, "wo": wo, "group": int(para.get("group", 1)),
+                             "cls": "conv%dx%d" % (kh, kw)}
+        elif kind == "dense":
+            n, cout = shapes[dst]
+            out[names[0]] = {"flops": 2.0 * n * cout * shapes[src[0]][1], "k": (1, 1), "n": n, "cin": shapes[src[0]][1],
+                             "cout": cout, "h": 1, "w": 1, "ho": 1, "wo": 1, "group": 1, "cls": "dense"}
     return out
 
 
-def cpu_baseline(g, b, x, iters):
-    """The numpy restatement of the reference (oracle/planer_np.py: im2col +
-    OpenBLAS sgemm, all host cores) timed on a bounded sample: `iters`
-    forwards of the same batch-32 workload after one warm-up."""
+def executed_flops(rec, c):
+    """MFMA FLOPs the chosen kernel really issues for conv `c` (tile, K-chunk and Winograd-tile padding
+    included), from the launch plan the library reported (`rec["plan"]`, e.g. "wino4[q64x64x16 tiles=..]").
+    None when the plan string is not understood."""
+    m = re.search(r"[qt]?(\d+)x(\d+)(?:x(\d+))?", rec["plan"])
+    if not m:
+        return None
+    bm, bn, bk = int(m.group(1)), int(m.group(2)), int(m.group(3) or 16)
+    n, cin, cout, h, w, ho, wo = c["n"], c["cin"], c["cout"], c["h"], c["w"], c["ho"], c["wo"]
+    kh, kw = c["k"]
+    lay = rec["w_layout"]
+
+    def gemm(rows, cols, kquads, groups=1):
+        return 2.0 * groups * cdiv(rows, bm) * bm * cdiv(cols, bn) * bn * cdiv(kquads * 4, bk) * bk
+    if lay == 2:
+        grp = c["group"]
+        return gemm(cout // grp, n * ho * wo, kh * kw * cdiv(cin // grp, 4), grp)
+    if lay == 6:
+        return gemm(cout, n * ho * wo, kh * cdiv(kw * cin, 4))
+    if lay == 5:
+        return 4 * gemm(cout, n * h * cdiv(w, 2), 3 * cin // 4)
+    if lay == 8:
+        return 6 * gemm(cout, n * h * cdiv(w, 4), 3 * cin // 4)
+    if lay == 4:
+        return gemm(cout, n * cdiv(h, 2) * cdiv(w, 2), cin // 4, 16)
+    if lay == 7:
+        return gemm(cout, n * cdiv(h, 4) * cdiv(w, 4), cin // 4, 36)
+    if lay in (0, 1) and rec["kind"] in ("dense", "conv", "conv_fused"):
+        return 2.0 * cdiv(cout, bm) * bm * cdiv(n * ho * wo, bn) * bn * cdiv(cin // c["group"] * kh * kw, bk) * bk
+    return None
+
+
+def oracle_net(g, b):
     from oracle import planer_np as onp
     net = onp.OracleNet()
     net.load_json(g["input"], g["inits"], g["layers"], g["flow"])
     net.load_weights(b)
+    return net
+
+
+def _median_rate(net, x, iters):
     net(x.copy())
     ts = []
     for _ in range(iters):
         t0 = time.perf_counter()
         net(x.copy())
         ts.append(time.perf_counter() - t0)
-    threads = len(os.sched_getaffinity(0))
+    return x.shape[0] / float(np.median(ts)), x.shape[0] / min(ts)
+
+
+def cpu_worker(batch, iters):
+    """`bench.py --cpu-worker B I`: the oracle alone in a fresh process (so OPENBLAS_NUM_THREADS set
+    by the parent takes effect); prints images/sec."""
+    from planer_amd.irgen import resnet18
+    g, b = resnet18.build()
+    x = np.random.default_rng(1).standard_normal((batch, 3, 224, 224)).astype(np.float32)
+    med, best = _median_rate(oracle_net(g, b), x, iters)
+    print(json.dumps({"images_per_sec": med, "best": best}))
+
+
+def cpu_baseline(g, b, x, iters):
+    """The numpy restatement of the reference (oracle/planer_np.py: im2col + OpenBLAS sgemm) timed
+    on the host cores of this box on a bounded sample.  Returns the
+    report and the oracle logits of `x` (for the parity check)."""
+    net = oracle_net(g, b)
+    logits = net(x.copy())
+    med, best = _median_rate(net, x, iters)
+    n1, _ = _median_rate(net, x[:1], 3)
+    threads, blas = len(os.sched_getaffinity(0)), "unknown"
     try:
         import threadpoolctl
         info = [i for i in threadpoolctl.threadpool_info() if i.get("user_api") == "blas"]
         if info:
             threads = int(info[0]["num_threads"])
+            blas = "%s %s (%s)" % (info[0].get("internal_api"), info[0].get("version"), info[0].get("threading_layer"))
     except Exception:
         pass
-    med = float(np.median(ts))
-    return {"value": x.shape[0] / med, "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": "%d forwards of ResNet-18 batch %d after 1 warm-up, median; best %.1f img/s; "
-                      "host has %d logical CPUs" % (iters, x.shape[0], x.shape[0] / min(ts), os.cpu_count())}
+    cpu = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu = [ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")][0]
+    except Exception:
+        pass
+    per_core = None
+    try:            # one BLAS thread, fresh process: the per-core figure BASELINE.md asks for
+        env = dict(os.environ, OPENBLAS_NUM_THREADS="1", OMP_NUM_THREADS="1")
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", "4", "2"], env=env,
+                           capture_output=True, text=True, timeout=300)
+        per_core = json.loads(r.stdout.strip().splitlines()[-1])["images_per_sec"]
+    except Exception:
+        pass
+    rep = {"value": med, "unit": "images/sec", "cores": threads, "kind": "port",
+           "sample": "%d forwards of ResNet-18 batch %d after 1 warm-up, median (best %.1f img/s); batch 1: 3 forwards; "
+                     "per_core: 2 forwards of batch 4 with OPENBLAS_NUM_THREADS=1 in a fresh process"
+                     % (iters, x.shape[0], best),
+           "batch1_images_per_sec": round(n1, 2), "per_core_images_per_sec": None if per_core is None else round(per_core, 3),
+           "logical_cpus": os.cpu_count(), "affinity_cpus": len(os.sched_getaffinity(0)), "blas": blas,
+           "numpy": np.__version__, "cpu_model": cpu}
+    return rep, logits
 
 
 def main():
+    if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-worker":
+        return cpu_worker(int(sys.argv[2]), int(sys.argv[3]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -82,7 +183,8 @@ def main():
     ap.add_argument("--workload", default="resnet18", choices=["resnet18", "yolov3", "conv2"],
                     help="resnet18 = the headline (BASELINE configs[2]); yolov3 = config 5 at batch 1; "
                          "conv2 = config 2's single Conv2d 3->64 on (8,3,224,224)")
-    ap.add_argument("--e2e", action="store_true", help="also time net(x_host): H2D + forward + D2H (PCIe-inclusive)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive net(x_host) leg")
+    ap.add_argument("--per-layer-csv", help="write the per-layer table (HIP events) to this file")
     args = ap.parse_args()
 
     import planer_amd
@@ -96,7 +198,9 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with one process per GPU "
                      "(python -m torch.distributed.run --nproc-per-node %d bench.py ...)" % (args.gpus, args.gpus))
     ctx = planer_amd.hip.context()
-    comm = dist.init(ctx, fallback=True)      # RCCL; same-node file fallback if it cannot come up
+    # RCCL or nothing: the same-node file transport is only used when asked for by name, so a
+    # fallback run can never be mistaken for the RCCL path
+    comm = dist.init(ctx, fallback=False)
 
     # ---- model: graph on every rank, weights from rank 0 by RCCL broadcast -------
     if args.workload == "yolov3":
@@ -112,8 +216,8 @@ def main():
         in_shape, args.batch = (3, 224, 224), (args.batch if args.batch != PER_GPU_BATCH else 8)
     else:
         build, in_shape = resnet18.build, (3, 224, 224)
-    # weights come from rank 0 by ONE RCCL broadcast; only the file fallback regenerates the
-    # (seeded) blob on every rank
+    # weights come from rank 0 by ONE RCCL broadcast; only the (explicit) file transport
+    # regenerates the seeded blob on every rank
     g, blob = build() if (rank == 0 or not comm.device_transport) else (build()[0], None)
     net = planer_amd.Net(ctx)
     net.load_json(g["input"], g["inits"], g["layers"], g["flow"])
@@ -129,14 +233,14 @@ def main():
     xs_host = [np.random.default_rng(1 + 1000 * i + rank).standard_normal((hi - lo,) + in_shape).astype(np.float32)
                for i in range(2)]
     xs = [planer_amd.asarray(a, ctx=ctx) for a in xs_host]
-    # fuse + tune + warm the pool + capture the hipGraph(s); "throughput": sub-batch streams free-run
+    # fuse + pick algorithms + tune + warm the pool + capture the hipGraph(s)
     plan = net.compile(xs[0], mode="throughput")
     ctx.save_tune_cache()                       # no-op unless PLANER_HIP_TUNE_CACHE is set
+    net.save_algo_cache()
     state = {"i": 0}
 
     def step():
-        if not os.environ.get("PLANER_BENCH_NOFEED"):
-            plan.feed([xs[state["i"] & 1]])        # rotate two distinct resident batches
+        plan.feed([xs[state["i"] & 1]])        # rotate two distinct resident batches
         plan.launch(join=False)
         state["i"] += 1
 
@@ -148,96 +252,172 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = global_batch * args.steps / elapsed
 
-    # ---- correctness guard on what was just timed (cheap: logits of 2 images) ----
+    # ---- parity of what was just timed: every replica of the plan on batch 0 vs the oracle ----
     sync()
-    logits = plan.outputs[0].get() if isinstance(plan.outputs, tuple) else plan.outputs.get()
-    assert np.isfinite(logits).all()
+    got = []
+    for _ in range(len(getattr(plan, "replicas", [0]))):
+        plan.feed([xs[0]])
+        plan.launch(join=False)
+        sync()
+        o = plan.outputs
+        got.append([t.get() for t in (o if isinstance(o, tuple) else (o,))])
+    for other in got[1:]:
+        for a, c in zip(got[0], other):
+            assert np.array_equal(a, c), "replicas of one plan disagree"
+    assert all(np.isfinite(t).all() for t in got[0])
 
     if rank != 0:
         return
 
-    # ---- roofline of the dominant kernel: HIP events around every layer of the
-    #      same fused program, launched eagerly on the same stream, K steps ----------
+    cpu_rep, want = None, None
+    if args.workload == "resnet18" and world == 1 and not args.no_cpu_baseline:
+        cpu_rep, want = cpu_baseline(g, blob, xs_host[0], args.cpu_iters)
+        want, checked = [want], xs_host[0].shape[0]
+    else:                                      # bounded: the first images of the batch only
+        checked = min(2, xs_host[0].shape[0])
+        w = oracle_net(g, blob)(xs_host[0][:checked].copy())
+        want = list(w) if isinstance(w, tuple) else [w]
+    parity = 0.0
+    for a, r in zip(got[0], want):
+        r = np.asarray(r)
+        parity = max(parity, float(np.abs(a[:r.shape[0]].astype(np.float64) - r).max() / max(np.abs(r).max(), 1e-30)))
+    if not parity <= 1e-4:
+        sys.exit("PARITY FAILURE: the timed plan differs from the oracle by %.3e of max|ref| (> 1e-4)" % parity)
+
+    # ---- per-layer device time: HIP events around every layer of the same fused program,
+    #      launched eagerly on the main stream (no trial launches: algorithms and launch plans are
+    #      cached by now) ----------------------------------------------------------------------
     shapes = {k: a.shape for k, a in zip(net.inits, net.weights)}
     shapes[g["input"][0]] = xs[0].shape
     net._interpret(net._program, [xs[0].copy()], shapes=shapes)
-    flops = conv_flops(g, shapes)
+    convs = conv_table(g, shapes)
     prog, _ = net._fuse(shapes)
     per_layer = {}
-    prof_steps = min(args.steps, 20)
+    prof_steps = min(max(args.steps, 5), 20)
     for it in range(prof_steps + 2):
         net._interpret(prog, [xs[it & 1].copy()], profile=True)
         if it >= 2:
             for name, kind, ms in net.last_events:
                 per_layer.setdefault((name, kind), []).append(ms)
-    classes = {}
+    algos = {a["layer"].rstrip("+"): a for a in plan.algos}
+    rows, classes, families = [], {}, {}
     for (name, kind), v in per_layer.items():
         ms = float(np.mean(v))
-        base = name[:-1] if name.endswith("+") else name
-        if base in flops:
-            f, (kh, kw) = flops[base]
-            cls = "conv%dx%d" % (kh, kw)
-        else:
-            f, cls = 0.0, kind
-        c = classes.setdefault(cls, {"ms": 0.0, "flops": 0.0, "launches": 0})
-        c["ms"] += ms
-        c["flops"] += f
-        c["launches"] += 1
+        base = name.rstrip("+")
+        c, rec = convs.get(base), algos.get(base)
+        alg = c["flops"] if c else 0.0
+        exe = executed_flops(rec, c) if (c and rec) else None
+        cls = c["cls"] if c else kind
+        fam = (rec["algo"] if rec else kind)
+        rows.append({"layer": name, "class": cls, "kernel": fam, "plan": rec["plan"] if rec else "", "ms": ms,
+                     "algorithmic_flops": alg, "executed_flops": exe})
+        for key, table in ((cls, classes), (fam, families)):
+            t = table.setdefault(key, {"ms": 0.0, "flops": 0.0, "executed": 0.0, "launches": 0})
+            t["ms"] += ms
+            t["flops"] += alg
+            t["executed"] += exe or 0.0
+            t["launches"] += 1
         if args.detail:
-            print("%-14s %-10s %8.3f ms %8.2f TFLOP/s" % (name, cls, ms, f / ms / 1e9 if ms else 0), file=sys.stderr)
+            print("%-14s %-10s %8.3f ms  %7.2f TFLOP/s algorithmic  %7.2f executed  %s"
+                  % (name, cls, ms, alg / ms / 1e9 if ms else 0, (exe or 0) / ms / 1e9 if ms else 0, fam), file=sys.stderr)
+    if args.per_layer_csv:
+        with open(args.per_layer_csv, "w") as f:
+            f.write("layer,class,kernel,plan,us_hip_events,algorithmic_flops,executed_flops,algorithmic_tflops,executed_tflops\n")
+            for r in rows:
+                f.write("%s,%s,\"%s\",\"%s\",%.2f,%.0f,%.0f,%.2f,%.2f\n"
+                        % (r["layer"], r["class"], r["kernel"], r["plan"], r["ms"] * 1e3, r["algorithmic_flops"],
+                           r["executed_flops"] or 0, r["algorithmic_flops"] / r["ms"] / 1e9,
+                           (r["executed_flops"] or 0) / r["ms"] / 1e9))
+
     e2e = None
-    if args.e2e:
+    if not args.no_e2e:                        # PCIe-inclusive: host batch in, host logits out
+        net.streams = "1x1"                    # one full-batch graph: the same kernels as the timed plan
         net(xs_host[0])
         t0 = time.perf_counter()
         for i in range(10):
             net(xs_host[i & 1])
         e2e = n * 10 / (time.perf_counter() - t0)
+    algo_list = [{"layer": a["layer"], "algo": a["algo"], "plan": a["plan"]} for a in plan.algos]
+
     if args.workload != "resnet18":
-        tot = sum(f for f, _ in flops.values())
+        tot = sum(c["flops"] for c in convs.values())
         print(json.dumps({"metric": "images/sec %s fp32 forward" % args.workload, "value": round(value, 1),
                           "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "dtype": "f32",
+                          "parity_rel_err": parity, "parity_checked_images": checked,
                           "config": {"workload": args.workload, "per_gpu_batch": n, "fused_steps": plan.fused_steps,
-                                     "streams": plan.streams},
+                                     "streams": plan.streams, "algos": algo_list},
                           "conv_tflops_whole_step": round(tot / (ms_per_step * 1e-3) / 1e12, 2),
                           "by_class_ms": {k: round(v["ms"], 4) for k, v in sorted(classes.items())},
                           "pcie_inclusive_images_per_sec": e2e}))
         return
+
+    def tf(flops, ms):
+        return flops / (ms * 1e-3) / 1e12 if ms else 0.0
+    conv_fams = {k: v for k, v in families.items() if v["flops"] > 0 and k != "igemm-nchw"}
+    dom_name = max(conv_fams, key=lambda k: conv_fams[k]["ms"])
+    dom = conv_fams[dom_name]
     c3 = classes["conv3x3"]
-    achieved = c3["flops"] / (c3["ms"] * 1e-3) / 1e12
-    total_flops = sum(f for f, _ in flops.values()) + 2.0 * n * 512 * 1000   # + the 512->1000 dense layer
-    # HBM traffic cannot be counted from inside this process: it comes from the committed rocprofv3
-    # PMC digest of this same command (tools/profile_bench.sh -> profiles/r01_hbm_traffic.json),
-    # FETCH_SIZE doubled as the MI355X guide prescribes for gfx950, averaged per conv-family launch.
+    total_alg = sum(c["flops"] for c in convs.values())
+    total_exe = sum(r["executed_flops"] or 0.0 for r in rows)
+    # HBM traffic of the dominant kernel comes from the committed rocprofv3 PMC passes of this same
+    # command (tools/profile_bench.sh; FETCH_SIZE doubled per the MI355X guide) -- it cannot be counted
+    # from inside the process, so it describes the profiled run of this build, not this very run
     traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", PROFILE_TAG + "_hbm_traffic.json")
     if os.path.exists(tpath):
-        fam = [r for r in json.load(open(tpath))
-               if any(t in r["kernel"] for t in ("conv_q4_kernel", "conv_w1d_kernel", "conv_w1d4_kernel", "conv_tap_kernel", "conv_igemm_kernel",
-                                                 "reduce_tiles", "wino_"))]
-        launches = sum(r["launches"] for r in fam)
-        if launches:
-            traffic = round(sum((r["read_mb_per_launch_corrected"] * 1e6 + r["write_kb_per_launch"] * 1e3)
-                                * r["launches"] for r in fam) / launches)
-            traffic_src = "profiles/r01_hbm_traffic.json: HBM bytes per conv-family kernel launch (PMC run of this command)"
-    roofline = {"bound": "mfma", "kernel": "the 16 conv3x3 layers of one forward on channel-quad tensors, each on the fastest of "
-                                          "conv_q4_kernel (direct implicit GEMM, stride-2 layers), conv_w1d4_kernel (fused 1-D "
-                                          "Winograd F(4,3), layer1) and the 2-D Winograd pipelines F(2x2,3x3) / F(4x4,3x3) (transforms + one grouped "
-                                          "1x1 conv_q4_kernel, layer2-4), incl. split-K tile-reduce and transform launches; "
-                                          "achieved = algorithmic FLOPs / time",
-                "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "avg_launch_ms": round(c3["ms"] / c3["launches"], 4),
-                "flops_per_launch": c3["flops"] / c3["launches"],
-                "whole_forward_mfma_frac": round(value / world * (total_flops / n) / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
-                "whole_forward_note": "ALGORITHMIC FLOPs of the timed (pipelined) run / peak; the Winograd paths execute "
-                                      "1.5x / 2x (fused 1-D F(2,3) / F(4,3)), 2.25x (F(2x2,3x3)) or 4x (F(4x4,3x3)) fewer multiplies than that",
-                "by_class_ms": {k: round(v["ms"], 4) for k, v in sorted(classes.items())}}
+        try:
+            want_k = re.search(r"\((\w+)\)", dom_name)
+            for r in json.load(open(tpath)):
+                if want_k and want_k.group(1) in r["kernel"] and "reduce" not in r["kernel"]:
+                    traffic = round(r["read_mb_per_launch_corrected"] * 1e6 + r["write_kb_per_launch"] * 1e3)
+                    traffic_src = "profiles/%s_hbm_traffic.json (%s, %d launches)" % (PROFILE_TAG, r["kernel"][:60], r["launches"])
+                    break
+        except Exception:
+            pass
+    roofline = {
+        "bound": "mfma",
+        "kernel": dom_name,
+        "definition": "dominant = the conv kernel family with the largest summed device time in one forward (HIP events, "
+                      "single stream, %d passes); achieved/frac count the MFMA FLOPs the kernel EXECUTES (tile, K-chunk and "
+                      "Winograd-tile padding included), effective_* count the direct algorithm's FLOPs" % prof_steps,
+        "launches_per_forward": dom["launches"],
+        "avg_launch_ms": round(dom["ms"] / dom["launches"], 5),
+        "executed_flops_per_launch": dom["executed"] / dom["launches"],
+        "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
+        "achieved": round(tf(dom["executed"], dom["ms"]), 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(tf(dom["executed"], dom["ms"]) / PEAK_FP32_MFMA_TFLOPS, 4),
+        "effective_achieved": round(tf(dom["flops"], dom["ms"]), 2),
+        "effective_frac": round(tf(dom["flops"], dom["ms"]) / PEAK_FP32_MFMA_TFLOPS, 4),
+        "traffic": traffic, "traffic_source": traffic_src,
+        "conv3x3": {"ms": round(c3["ms"], 4), "launches": c3["launches"],
+                    "mfma_util": round(tf(c3["executed"], c3["ms"]) / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "effective_frac": round(tf(c3["flops"], c3["ms"]) / PEAK_FP32_MFMA_TFLOPS, 4)},
+        "whole_forward_timed_run": {
+            "mfma_util": round(value / world * (total_exe / n) / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
+            "effective_frac": round(value / world * ((total_alg) / n) / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
+            "note": "executed / algorithmic conv+dense FLOPs of one forward x images/sec of the timed pipelined run / peak"},
+        "by_kernel": {k: {"ms": round(v["ms"], 4), "launches": v["launches"],
+                          "mfma_util": round(tf(v["executed"], v["ms"]) / PEAK_FP32_MFMA_TFLOPS, 4),
+                          "effective_frac": round(tf(v["flops"], v["ms"]) / PEAK_FP32_MFMA_TFLOPS, 4)}
+                      for k, v in sorted(conv_fams.items())},
+        "by_class_ms": {k: round(v["ms"], 4) for k, v in sorted(classes.items())}}
+    # HBM-bound single-kernel layers: algorithmic bytes = input read once + output written once
+    hbm = []
+    for (name, kind), v in per_layer.items():
+        if kind in ("maxpool_q4", "maxpool", "gap_q4", "gap"):
+            src = [f for f in g["flow"] if f[1][0] == name][0]
+            nbytes = 4.0 * (np.prod(shapes[src[0] if isinstance(src[0], str) else src[0][0]]) + np.prod(shapes[src[2]]))
+            ms = float(np.mean(v))
+            hbm.append({"layer": name, "kernel": kind, "bytes": nbytes, "ms": round(ms, 5),
+                        "achieved": round(nbytes / (ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)})
 
     out = {"metric": "images/sec ResNet-18 fp32 forward", "value": round(value, 1), "unit": "images/sec",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
            "data": "synthetic: standard-normal (N,3,224,224) fp32, seeded He-normal weights (planer_amd.irgen.resnet18)",
+           "parity_rel_err": parity, "parity_checked_images": checked,
            "config": {"workload": "ResNet-18 planer IR (70 layers), forward, batch %d per GPU, 224x224, fp32, "
                                   "channel-quad activations, fused conv epilogues, hipGraph replay" % n,
                       "global_batch": global_batch, "per_gpu_batch": n, "parallelism": "batch-shard x%d" % world,
@@ -247,11 +427,13 @@ def main():
                       "fused_steps": plan.fused_steps,
                       "streams": plan.streams,
                       "pcie_inclusive_images_per_sec": None if e2e is None else round(e2e, 1),
-                      "device": ctx.arch, "cu_count": ctx.cu_count},
-           "roofline": roofline}
-    if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(g, blob, xs_host[0], args.cpu_iters)
-        out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+                      "device": ctx.arch, "cu_count": ctx.cu_count,
+                      "tune_cache": os.environ.get("PLANER_HIP_TUNE_CACHE"),
+                      "algos": algo_list},
+           "roofline": roofline, "roofline_hbm": hbm}
+    if cpu_rep is not None:
+        out["cpu_baseline"] = cpu_rep
+        out["gpu_over_cpu"] = round(value / cpu_rep["value"], 1)
     print(json.dumps(out))
 
 

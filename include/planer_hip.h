@@ -230,6 +230,10 @@ int pl_conv2d_set_config(pl_ctx *ctx, int cfg, int split_k);
  * the rest as split_k slices + tile reduce; occupancy>0 pins workgroups per CU. */
 int pl_conv2d_set_plan(pl_ctx *ctx, int cfg, int dp_tiles, int split_k, int occupancy);
 int pl_conv2d_num_configs(void);
+/* How the last convolution enqueued on this context was launched -- kernel family, tile
+ * configuration, data-parallel tiles / split-K slices / occupancy pin, e.g.
+ * "wino4[q64x64x16 dp=1800 split=1 occ=0]".  For run reports (bench.py config.algos). */
+int pl_conv2d_last_plan(pl_ctx *ctx, char *buf, size_t len);
 int pl_conv2d_config_name(int cfg, char *buf, size_t len);
 
 /* layer.Dense (layer.py:15-18): y[M,N] = x[M,K] @ w[N,K]^T + bias[N]  (trans_b=1)

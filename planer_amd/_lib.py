@@ -84,6 +84,7 @@ SIGNATURES = {
     "pl_conv2d_set_plan": [_P, _I, _I, _I, _I],
     "pl_conv2d_num_configs": [],
     "pl_conv2d_config_name": [_I, c_char_p, _Z],
+    "pl_conv2d_last_plan": [_P, c_char_p, _Z],
     "pl_gemm_f32": [_P, _P, _I, _I, _P, _I, _I, _P, _P],
     "pl_scale_shift_f32": [_P, _P, _P, _P, _P, _I, _I, _I],
     "pl_relu_f32": [_P, _P, _P, _Z],

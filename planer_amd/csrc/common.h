@@ -73,6 +73,7 @@ struct pl_ctx {
     bool autotune = true;
     int conv_t1 = 0, conv_occ = 0;
     void *sync_event = nullptr;      // hipEvent_t used by pl_stream_wait
+    std::string last_plan;           // how the last conv on this context was launched (pl_conv2d_last_plan)
 
     // RCCL (dlopen'ed on first use)
     void *comm = nullptr;

@@ -811,6 +811,11 @@ int run_plan(pl_ctx *ctx, const ConvArgs &a0, const Plan &pl, bool avec, float *
     const int T = a.tiles * a.groups;
     const int s2 = effective_splits(ci, a.K, pl.s2);
     const int t1 = s2 <= 1 ? T : (pl.t1 < 0 ? 0 : (pl.t1 > T ? T : pl.t1));
+    {
+        char buf[96];
+        snprintf(buf, sizeof buf, "%s tiles=%d dp=%d split=%d occ=%d", ci.name, T, t1, s2, pl.occ);
+        ctx->last_plan = buf;
+    }
     int used = 0;
     int rc = launch_pass(ctx, a, ci, avec, 0, t1, 1, pl.occ, y, &used);
     if (rc != PL_OK) return rc;
@@ -1268,6 +1273,7 @@ int winograd_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, c
     }
     pl_free(ctx, M);
     pl_free(ctx, V);
+    ctx->last_plan = "wino2[" + ctx->last_plan + "]";
     return rc;
 }
 
@@ -1427,6 +1433,7 @@ int winograd_q4_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int 
     }
     pl_free(ctx, M);
     pl_free(ctx, V);
+    ctx->last_plan = "wino2[" + ctx->last_plan + "]";
     return rc;
 }
 
@@ -1618,6 +1625,7 @@ int winograd4_q4_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int
     }
     pl_free(ctx, M);
     pl_free(ctx, V);
+    ctx->last_plan = "wino4[" + ctx->last_plan + "]";
     return rc;
 }
 
@@ -1660,6 +1668,11 @@ int w1d_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const
         hipLaunchKernelGGL(conv_w1d_kernel, dim3((unsigned)a.tiles), dim3(256), W1dCfg::LDS_BYTES, ctx->stream, a);
     }
     PL_LAUNCH_CHECK();
+    {
+        char buf[96];
+        snprintf(buf, sizeof buf, "%s tiles=%d", f43 ? "w1d4 64x64x8" : "w1d 64x64x16", a.tiles);
+        ctx->last_plan = buf;
+    }
     return PL_OK;
 }
 
@@ -2028,6 +2041,12 @@ int pl_conv2d_set_plan(pl_ctx *ctx, int cfg, int dp_tiles, int split_k, int occu
 }
 
 int pl_conv2d_num_configs(void) { return kNumCfgs; }
+
+int pl_conv2d_last_plan(pl_ctx *ctx, char *buf, size_t len) {
+    PL_REQUIRE(ctx && buf && len, PL_EINVAL, "pl_conv2d_last_plan: bad argument");
+    snprintf(buf, len, "%s", ctx->last_plan.c_str());
+    return PL_OK;
+}
 
 int pl_conv2d_config_name(int cfg, char *buf, size_t len) {
     PL_REQUIRE(cfg >= 0 && cfg < kNumCfgs && buf && len, PL_EINVAL, "pl_conv2d_config_name: bad argument");

@@ -200,6 +200,58 @@ class FileCommunicator(Communicator):
         self.barrier()
 
 
+class VirtualWorld:
+    """SURVEY 8(e) "virtual ranks on one device": `world` ranks inside ONE process on ONE GPU, for
+    checking the sharded path (BASELINE config 4: batch 256 = 8 x 32) where only one device is
+    visible.  Every rank is its own context (stream + memory pool) with its own `Net` and its own
+    full copy of the weight blob -- rank `root` uploads it, the others receive a device-to-device
+    copy (what `ncclBroadcast` does between real ranks) -- and runs the forward pass of its
+    `shard_range` slice independently; no rank ever reads another rank's activations."""
+
+    def __init__(self, world, device=None):
+        from . import hip
+        base = hip.context()
+        dev = base.device if device is None else int(device)
+        self.world = int(world)
+        self.ctxs = [base if (r == 0 and dev == base.device) else hip.Context(dev) for r in range(self.world)]
+
+    def load(self, graph, blob, root=0):
+        """-> one Net per rank; only `root` touches the host blob."""
+        from .net import Net
+        nets = []
+        for r, ctx in enumerate(self.ctxs):
+            net = Net(ctx)
+            net.load_json(graph["input"], graph["inits"], graph["layers"], graph["flow"])
+            nets.append(net)
+        nets[root].load_weights(blob)
+        self.ctxs[root].synchronize()
+        src = nets[root].weight_blob()
+        for r, net in enumerate(nets):
+            if r != root:
+                dst = net.weight_blob()
+                _lib.call("pl_d2d", net.ctx.handle, dst.ptr, src.ptr, dst.nbytes)      # the "broadcast"
+                net.ctx.synchronize()
+                net.refresh_host_mirror()
+        return nets
+
+    def forward(self, nets, x):
+        """Host batch in -> assembled host result out: rank r computes rows shard_range(N, world, r)
+        on its own stream (all ranks are enqueued before any is read back)."""
+        from . import hip
+        n = x.shape[0]
+        outs = []
+        for r, net in enumerate(nets):
+            lo, hi = shard_range(n, self.world, r)
+            outs.append(None if hi == lo else net(hip.asarray(numpy.ascontiguousarray(x[lo:hi]), ctx=net.ctx)))
+        host = []
+        for o in outs:
+            if o is not None:
+                host.append(tuple(t.get() for t in o) if isinstance(o, tuple) else o.get())
+        if host and isinstance(host[0], tuple):
+            return tuple(numpy.concatenate([h[i] for h in host], axis=0) for i in range(len(host[0])))
+        return numpy.concatenate(host, axis=0)
+
+
 def init(ctx=None, fallback=False):
     """Communicator for this process from the launcher's environment.  With `fallback`, a failure
     to bring RCCL up yields a FileCommunicator (its `.why` says what went wrong) instead of raising."""

@@ -70,6 +70,12 @@ class Context:
         """Force a full launch plan: `dp_tiles` data-parallel tiles + the rest split `split_k` ways."""
         _lib.call("pl_conv2d_set_plan", self.handle, int(cfg), int(dp_tiles), int(split_k), int(occupancy))
 
+    def last_conv_plan(self):
+        """How the last convolution on this context was launched (kernel family, tile plan)."""
+        buf = ctypes.create_string_buffer(160)
+        _lib.call("pl_conv2d_last_plan", self.handle, buf, 160)
+        return buf.value.decode()
+
     def close(self):
         if self.handle is not None:
             _lib.load().pl_ctx_destroy(self.handle)

@@ -34,6 +34,12 @@ _q4.register(layer_map)
 
 _ALIGN = 256
 
+# ConvQ4 / ConvFused w_layout codes -> what runs (for run reports)
+W_LAYOUT_NAMES = {0: "igemm-nchw", 1: "tap-nchw", 2: "direct-q4 (conv_q4_kernel)", 3: "wino2x2-nchw",
+                  4: "wino2x2-q4 (transforms + grouped conv_q4_kernel)", 5: "w1d F(2,3) (conv_w1d_kernel)",
+                  6: "rowpack-q4 (nchw_to_rowpack + conv_q4_kernel)",
+                  7: "wino4x4-q4 (transforms + grouped conv_q4_kernel)", 8: "w1d4 F(4,3) (conv_w1d4_kernel)"}
+
 
 def _as_list(v):
     return list(v) if isinstance(v, (list, tuple)) else [v]
@@ -61,6 +67,7 @@ class _Plan:
     def __init__(self, inputs, outputs, graph, ctx, fused_steps):
         self.inputs, self.outputs, self.graph, self.ctx = inputs, outputs, graph, ctx
         self.fused_steps, self.ms, self.streams = fused_steps, None, "1x1"
+        self.algos = []              # per conv step: kernel family + launch plan (filled by Net._capture)
 
     def feed(self, xs):
         """Copy new inputs into the plan's static input buffers (on the plan's stream)."""
@@ -96,6 +103,7 @@ class _MultiPlan:
         self.inputs, self.outputs, self.subs, self.ctx = inputs, outputs, subs, ctx
         self.fused_steps, self.ms = fused_steps, None
         self.streams = "%dx%d" % (len(subs), len(subs))
+        self.algos = subs[0].algos
 
     def feed(self, xs):
         """Per-stream input copy: stream i copies ITS rows, ordered behind its own previous
@@ -138,6 +146,7 @@ class _PipelinePlan:
     def __init__(self, replicas, ctx, fused_steps):
         self.replicas, self.ctx, self.fused_steps, self.ms = replicas, ctx, fused_steps, None
         self.streams = "pipe%d" % len(replicas)
+        self.algos = replicas[0].algos
         self.turn, self.last = 0, replicas[0]
 
     @property
@@ -191,6 +200,14 @@ class Net:
         self._plans = {}
         self._extra = {}             # derived constant tensors (tap-major / Winograd filters)
         self._algo = {}              # conv shape signature -> chosen w_layout
+        # force_algo: w_layout (int) every eligible 3x3/s1/p1 conv must use, or None = pick by timing
+        fa = os.environ.get("PLANER_HIP_CONV_ALGO")
+        self.force_algo = int(fa) if fa else None
+        # choices persist next to the C library's launch-plan cache, so a second run (profiling!)
+        # launches no trial kernels and reproduces the first run's kernels exactly
+        tc = os.environ.get("PLANER_HIP_TUNE_CACHE")
+        self.algo_cache = tc + ".algo.json" if tc else None
+        self._algo_loaded = False
 
     # ---- loading ----------------------------------------------------------------
     def load_json(self, inputs, inits, body, flow, debug=False):
@@ -252,8 +269,9 @@ class Net:
         return obj.shape if hasattr(obj, "shape") else obj
 
     # ---- eager interpreter ---------------------------------------------------------
-    def _interpret(self, prog, xs, debug=False, shapes=None, profile=False):
-        """net.py:37-72: one kernel launch (or view) per layer, in flow order."""
+    def _interpret(self, prog, xs, debug=False, shapes=None, profile=False, record=None):
+        """net.py:37-72: one kernel launch (or view) per layer, in flow order.  `record` (a list)
+        receives one dict per convolution / dense step: which kernel family and launch plan ran."""
         env = {"None": None}
         env.update(zip(self.inits, self.weights))
         env.update(self._extra)
@@ -276,6 +294,12 @@ class Net:
                 val = obj(*args)
                 if profile:
                     events.append((name, obj.name, e0, hip.Event(self.ctx).record()))
+                if record is not None and obj.name in ("conv", "conv_fused", "conv_q4", "dense", "matmul"):
+                    lay = obj.para().get("w_layout", 0) if obj.name != "conv" else 0
+                    ctx_ = args[0].ctx if isinstance(args[0], DeviceArray) else self.ctx
+                    record.append({"layer": name, "kind": obj.name, "w_layout": lay,
+                                   "algo": W_LAYOUT_NAMES.get(lay, str(lay)), "plan": ctx_.last_conv_plan(),
+                                   "x": list(_q4.logical_shape(args[0]) if _q4.is_q4(args[0]) else args[0].shape)})
                 del args
                 if isinstance(dst, str):
                     env[dst] = val
@@ -378,23 +402,15 @@ class Net:
         return [out_body[b[0]] for b in body], out_flow
 
     def _pick_conv_algo(self, ConvFused, K, srcs, para, shapes, wmap, q4=False):
-        """Time the direct implicit GEMM and the Winograd pipeline for this conv's real shape and
-        epilogue; -> w_layout 1 or 3 (NCHW), 2 or 4 (channel-quad).  Cached per shape signature."""
+        """Time the direct implicit GEMM and the Winograd variants for this conv's real shape and
+        epilogue; -> w_layout 1 or 3 (NCHW), 2 / 5 / 8 / 4 / 7 (channel-quad).  Cached per shape
+        signature (and persisted, see `algo_cache`); `force_algo` bypasses the measurement."""
         from .layer import prepare_conv_weights, prepare_winograd_weights
         xs = tuple(shapes[srcs[0].split("@")[0]])
         has = [i < len(srcs) and srcs[i] != "None" for i in range(2, 6)]       # B, scale, shift, res
         sig = (q4, xs, tuple(K.shape), tuple(has), para.get("act", 0))
-        if sig in self._algo:
-            return self._algo[sig]
-        ctx = self.ctx
-        x = hip.zeros(xs, numpy.float32, ctx)
-        cout = K.shape[0]
-        chan = hip.zeros((1, cout, 1, 1), numpy.float32, ctx)
-        out_shape = (xs[0], cout, xs[2], xs[3])
-        res = hip.zeros(out_shape, numpy.float32, ctx) if has[3] else None
-        cands = ((1, prepare_conv_weights), (3, prepare_winograd_weights))
+        cands = [(1, prepare_conv_weights), (3, prepare_winograd_weights)]
         if q4:
-            x, res = _q4.to_q4(x), (_q4.to_q4(res) if res is not None else None)
             # direct, fused 1-D Winograd along W (F(2,3) and F(4,3)), 2-D Winograd pipelines with separate transform kernels
             cands = [(2, _q4.prepare_q4_weights), (5, _q4.prepare_w1d_q4_weights), (8, _q4.prepare_w1d4_q4_weights)]
             if _q4.winograd_q4_eligible(K.shape, **{k: v for k, v in para.items()
@@ -402,6 +418,24 @@ class Net:
                 cands.append((4, _q4.prepare_winograd_q4_weights))
                 if os.environ.get("PLANER_HIP_WINOGRAD4", "1") != "0":
                     cands.append((7, _q4.prepare_winograd4_q4_weights))      # F(4x4,3x3)
+        if self.force_algo is not None:
+            if self.force_algo not in [c[0] for c in cands]:
+                raise ValueError("force_algo=%r does not apply to conv %s k%s" % (self.force_algo, xs, tuple(K.shape)))
+            return self.force_algo
+        self._load_algo_cache()
+        if sig in self._algo:
+            return self._algo[sig]
+        ctx = self.ctx
+        # random operands: zero tensors clock ~19 % higher (DVFS) and would bias the pick towards
+        # the MFMA-heavy candidates (MI355X guide, "DVFS give-back")
+        rng = numpy.random.default_rng(1234)
+        x = hip.asarray(rng.standard_normal(xs).astype(numpy.float32), ctx=ctx)
+        cout = K.shape[0]
+        chan = hip.asarray(rng.uniform(0.5, 1.5, (1, cout, 1, 1)).astype(numpy.float32), ctx=ctx)
+        out_shape = (xs[0], cout, xs[2], xs[3])
+        res = hip.asarray(rng.standard_normal(out_shape).astype(numpy.float32), ctx=ctx) if has[3] else None
+        if q4:
+            x, res = _q4.to_q4(x), (_q4.to_q4(res) if res is not None else None)
         args = [hip.zeros((cout,), numpy.float32, ctx) if has[0] else None, chan if has[1] else None,
                 chan if has[2] else None, res]
         kw = {k: v for k, v in para.items() if k != "w_layout"}
@@ -412,11 +446,14 @@ class Net:
                 run = lambda: ConvFused(x, Kp, *args, w_layout=lay, **kw)
                 for _ in range(3):
                     run()                              # first call autotunes the MFMA plan(s)
-                e0 = hip.Event(ctx).record()
-                for _ in range(8):
-                    run()
-                e1 = hip.Event(ctx).record()
-                ms = e0.elapsed_ms(e1) / 8
+                ms = None
+                for _ in range(3):                     # best of three bursts of 8
+                    e0 = hip.Event(ctx).record()
+                    for _ in range(8):
+                        run()
+                    e1 = hip.Event(ctx).record()
+                    t = e0.elapsed_ms(e1) / 8
+                    ms = t if ms is None else min(ms, t)
             except (NotImplementedError, ValueError, MemoryError):
                 continue
             if os.environ.get("PLANER_CONV_TUNE_LOG"):
@@ -426,7 +463,38 @@ class Net:
             if best_ms is None or ms < best_ms:
                 best, best_ms = lay, ms
         self._algo[sig] = best
+        self._algo_dirty = True
         return best
+
+    @staticmethod
+    def _sig_key(sig):
+        return repr(sig)
+
+    def _load_algo_cache(self):
+        if self._algo_loaded or not self.algo_cache:
+            return
+        self._algo_loaded = True
+        try:
+            import json
+            with open(self.algo_cache) as f:
+                stored = json.load(f)
+        except (OSError, ValueError):
+            return
+        import ast
+        for k, v in stored.items():
+            try:
+                self._algo.setdefault(ast.literal_eval(k), int(v))
+            except (ValueError, SyntaxError):
+                pass
+
+    def save_algo_cache(self, path=None):
+        """Persist the per-shape conv algorithm choices (next to PLANER_HIP_TUNE_CACHE by default)."""
+        path = path or self.algo_cache
+        if not path:
+            return
+        import json
+        with open(path, "w") as f:
+            json.dump({self._sig_key(k): v for k, v in sorted(self._algo.items(), key=repr)}, f, indent=1)
 
     def compile(self, *xs, mode="latency"):
         """Build (or fetch) the captured plan for these device inputs.  `mode` only affects how
@@ -524,6 +592,9 @@ class Net:
                 best = cand
         self.timer = timer
         self._plans[key] = best
+        if getattr(self, "_algo_dirty", False):
+            self.save_algo_cache()
+            self._algo_dirty = False
         return best
 
     def _side_context(self, i):
@@ -578,7 +649,8 @@ class Net:
                 for s_, v in zip(statics, srcs):
                     _lib.call("pl_d2d", ctx.handle, s_.ptr, v.ptr, s_.nbytes)
         fill()
-        warm = self._interpret(prog, [s_.copy() for s_ in statics])
+        algos = []
+        warm = self._interpret(prog, [s_.copy() for s_ in statics], record=algos)
         dsts = make_dsts(warm) if make_dsts else None
         del warm
         ctx.synchronize()
@@ -609,7 +681,9 @@ class Net:
             raise
         g = _lib.c_void_p()
         _lib.call("pl_capture_end", ctx.handle, _lib.byref(g))
-        return _Plan(statics, out, g, ctx, nfused)
+        plan = _Plan(statics, out, g, ctx, nfused)
+        plan.algos = algos
+        return plan
 
     def _replay(self, xs):
         plan = self.compile(*xs)
