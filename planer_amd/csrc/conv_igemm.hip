@@ -633,6 +633,7 @@ __global__ void __launch_bounds__(256) permute_weights_kernel(const float *w, fl
 }
 
 #include "conv_q4_kernel.h"
+#include "conv_pcg_kernel.h"
 
 // ---- configurations ---------------------------------------------------------
 typedef Cfg<128, 128, 16, 2, 2> C128x128;
@@ -680,6 +681,7 @@ struct CfgInfo {
     void (*scl)(const ConvArgs);
     void (*reduce)(const ConvArgs, const float *, float *);
     void (*reduce4)(const ConvArgs, const float *, float *);
+    bool pc;     // persistent producer/consumer kernel (conv_pcg_kernel.h): 512 threads, one workgroup per CU
 };
 
 #define CFG_ENTRY(T, nm)                                                                                 \
@@ -693,7 +695,12 @@ struct CfgInfo {
 
 #define Q4_ENTRY(T, nm) \
     { nm, 2, T::BM, T::BN, T::BK, T::LDS_BYTES, conv_q4_kernel<T>, conv_q4_kernel<T>, \
-      reduce_tiles_q4_kernel<T::BM, T::BN>, reduce_tiles_q4_kernel<T::BM, T::BN> }
+      reduce_tiles_q4_kernel<T::BM, T::BN>, reduce_tiles_q4_kernel<T::BM, T::BN>, false }
+#define PC_ENTRY(T, nm) \
+    { nm, 2, T::BM, T::BN, T::BK, T::LDS_BYTES, conv_pc_kernel<T>, conv_pc_kernel<T>, nullptr, nullptr, true }
+typedef PcCfg<128, 128> P128x128;
+typedef PcCfg<64, 256> P64x256;
+typedef PcCfg<256, 64> P256x64;
 
 const CfgInfo kCfgs[] = {
     CFG_ENTRY(C128x128, "128x128"), CFG_ENTRY(C64x128, "64x128"), CFG_ENTRY(C128x64, "128x64"),
@@ -711,12 +718,21 @@ const CfgInfo kCfgs[] = {
     Q4_ENTRY(Q64x64x16, "q64x64x16"),      Q4_ENTRY(Q64x64x32, "q64x64x32"),
     Q4_ENTRY(Q128x32x32, "q128x32x32"),    Q4_ENTRY(Q32x128x32, "q32x128x32"),
     Q4_ENTRY(Q256x64x16, "q256x64x16"),    Q4_ENTRY(Q64x256x16, "q64x256x16"),
+    PC_ENTRY(P128x128, "p128x128x16"),     PC_ENTRY(P64x256, "p64x256x16"),     PC_ENTRY(P256x64, "p256x64x16"),
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 constexpr int kLdsPerCu = 160 * 1024;
 
 // weight layouts: 0 OIHW (generic kernel), 1 tap-major, 2 Q4 (activations AND filter in quad form)
-bool cfg_applies(const CfgInfo &ci, int layout, int cin_g) {
+bool pc_enabled() {
+    static const bool on = !getenv("PLANER_HIP_PC") || atoi(getenv("PLANER_HIP_PC")) != 0;
+    return on;
+}
+
+bool cfg_applies(const CfgInfo &ci, int layout, int cin_g, int q_pad = 1 << 20) {
+    // the persistent kernel: plain channel-quad gather only, and at least 4 chunks per tile (its
+    // per-tile parameter hand-off is three tiles deep)
+    if (ci.pc && (layout != 2 || q_pad / 4 < 4 || !pc_enabled())) return false;
     if (layout == 6) layout = 2;            // row-packed input: the channel-quad kernel with another gather
     if (ci.tap != layout) return false;
     return ci.tap != 1 || cin_g % ci.bk == 0;
@@ -781,6 +797,24 @@ int launch_pass(pl_ctx *ctx, ConvArgs a, const CfgInfo &ci, bool avec, int tile_
     a.tile_offset = tile_offset;
     a.tile_count = tile_count;
     a.y = out;
+    if (ci.pc) {
+        // persistent: every workgroup walks tiles blockIdx.x, +grid, ...; no split-K, whole conv in one launch
+        if (splits != 1 || tile_offset != 0 || tile_count != a.tiles * a.groups) {
+            pl_set_error("conv: the persistent kernel runs whole, unsplit convolutions only");
+            return PL_EINVAL;
+        }
+        int rc = ensure_lds_attr((const void *)ci.vec, ci.lds);
+        if (rc != PL_OK) return rc;
+        const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
+        hipLaunchKernelGGL(ci.vec, dim3((unsigned)std::min(tile_count, cus)), dim3(512), ci.lds, ctx->stream, a);
+        hipError_t le = hipGetLastError();
+        if (le != hipSuccess) {
+            pl_set_error("conv launch (%s): %s", ci.name, hipGetErrorString(le));
+            return PL_EHIP;
+        }
+        *used_splits = 1;
+        return PL_OK;
+    }
     int lds = ci.lds;
     if (occ > 0) {
         const int want = (kLdsPerCu / occ) & ~255;          // occ blocks fit, occ+1 do not
@@ -856,7 +890,7 @@ Plan choose_plan(pl_ctx *ctx, int layout, const ConvArgs &a) {
     Plan pl{-1, 0, 1, 0};
     for (int c = 0; c < kNumCfgs; ++c) {
         const CfgInfo &ci = kCfgs[c];
-        if (!cfg_applies(ci, layout, a.cin_g)) continue;
+        if (ci.pc || !cfg_applies(ci, layout, a.cin_g)) continue;
         const double mt = (a.cout_g + ci.bm - 1) / ci.bm, nt = (a.cols + ci.bn - 1) / ci.bn;
         const double tiles = mt * nt * a.groups;
         const double kch = std::ceil((double)a.K / ci.bk);
@@ -925,11 +959,12 @@ Plan tune_plan(pl_ctx *ctx, int layout, const ConvArgs &a, bool avec, float *y, 
     const int splits[] = {2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14, 16};
     for (int c = 0; c < kNumCfgs; ++c) {
         const CfgInfo &ci = kCfgs[c];
-        if (!cfg_applies(ci, layout, a.cin_g)) continue;
+        if (!cfg_applies(ci, layout, a.cin_g, a.Qpad)) continue;
         const int T = ((a.cout_g + ci.bm - 1) / ci.bm) * ((a.cols + ci.bn - 1) / ci.bn) * a.groups;
         if ((double)T * ci.bm * ci.bn > 2.5 * work + 1e5) continue;               // mostly padding
         Plan dp{c, T, 1, 0};
         stage1.push_back({time_plan(ctx, a, dp, avec, y, e0, e1, 2), dp});
+        if (ci.pc) continue;                                                      // persistent: no split-K variants
         const int chunks = (a.K + ci.bk - 1) / ci.bk;
         const char *ms_env = getenv("PLANER_CONV_MAX_SPLIT");     // experiments: cap split-K
         const int max_split = ms_env ? atoi(ms_env) : 1 << 20;
@@ -955,6 +990,7 @@ Plan tune_plan(pl_ctx *ctx, int layout, const ConvArgs &a, bool avec, float *y, 
         if (std::find(tried.begin(), tried.end(), c) != tried.end()) continue;
         tried.push_back(c);
         const CfgInfo &ci = kCfgs[c];
+        if (ci.pc) continue;
         const int T = ((a.cout_g + ci.bm - 1) / ci.bm) * ((a.cols + ci.bn - 1) / ci.bn) * a.groups;
         const int chunks = (a.K + ci.bk - 1) / ci.bk;
         const int maxocc = std::min(8, kLdsPerCu / ci.lds);
@@ -1080,7 +1116,7 @@ int conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const
     const bool avec = (a.K % 4 == 0) && ((reinterpret_cast<uintptr_t>(w) & 15u) == 0);
 
     // forced configuration (tests / tuning tools): split > 1 means split-K over all tiles
-    if (ctx->conv_cfg >= 0 && ctx->conv_cfg < kNumCfgs && cfg_applies(kCfgs[ctx->conv_cfg], layout, a.cin_g)) {
+    if (ctx->conv_cfg >= 0 && ctx->conv_cfg < kNumCfgs && cfg_applies(kCfgs[ctx->conv_cfg], layout, a.cin_g, a.Qpad)) {
         const int s = ctx->conv_split_k > 0 ? ctx->conv_split_k : 1;
         Plan pl{ctx->conv_cfg, s > 1 ? ctx->conv_t1 : (1 << 30), s, ctx->conv_occ};
         return run_plan(ctx, a, pl, avec, y);
@@ -1630,6 +1666,7 @@ int winograd4_q4_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int
 }
 
 #include "conv_w1d_kernel.h"
+#include "conv_pc_kernel.h"
 
 int w1d_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const float *uq, int Cout, const float *bias,
                float *yq, const float *scale, const float *shift, const float *resq, int act, double alpha, bool f43) {
@@ -1658,7 +1695,19 @@ int w1d_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const
     a.divMt = FastDiv(a.mtiles);
     a.tile_offset = 0; a.tile_count = a.tiles; a.splits = 1;
     a.ep = make_epilogue(bias, scale, shift, resq, act, alpha);
-    if (f43) {
+    // persistent producer/consumer variant (conv_pc_kernel.h): whole chunks only, and enough of them
+    // per tile that the parameter hand-off is race free
+    // (measured slower than conv_w1d4_kernel at batch 32 -- one 512-thread workgroup per CU quantises 392 tiles
+    //  into two rounds -- so it is opt-in: PLANER_HIP_W1D4_PC=1)
+    const bool pc_env = getenv("PLANER_HIP_W1D4_PC") && atoi(getenv("PLANER_HIP_W1D4_PC")) != 0;
+    const bool pc = f43 && pc_env && Cin % 16 == 0 && a.Qtot / W1d4PcCfg::KG >= 6;
+    int pc_grid = 0;
+    if (pc) {
+        int rc = ensure_lds_attr((const void *)conv_w1d4_pc_kernel, W1d4PcCfg::LDS_BYTES);
+        if (rc != PL_OK) return rc;
+        pc_grid = std::min(a.tiles, ctx->cu_count > 0 ? ctx->cu_count : 256);
+        hipLaunchKernelGGL(conv_w1d4_pc_kernel, dim3((unsigned)pc_grid), dim3(512), W1d4PcCfg::LDS_BYTES, ctx->stream, a);
+    } else if (f43) {
         int rc = ensure_lds_attr((const void *)conv_w1d4_kernel, W1d4Cfg::LDS_BYTES);
         if (rc != PL_OK) return rc;
         hipLaunchKernelGGL(conv_w1d4_kernel, dim3((unsigned)a.tiles), dim3(256), W1d4Cfg::LDS_BYTES, ctx->stream, a);
@@ -1670,7 +1719,8 @@ int w1d_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const
     PL_LAUNCH_CHECK();
     {
         char buf[96];
-        snprintf(buf, sizeof buf, "%s tiles=%d", f43 ? "w1d4 64x64x8" : "w1d 64x64x16", a.tiles);
+        if (pc) snprintf(buf, sizeof buf, "w1d4pc 64x64x8 tiles=%d grid=%d", a.tiles, pc_grid);
+        else snprintf(buf, sizeof buf, "%s tiles=%d", f43 ? "w1d4 64x64x8" : "w1d 64x64x16", a.tiles);
         ctx->last_plan = buf;
     }
     return PL_OK;

@@ -245,6 +245,11 @@ struct W1d4Cfg {
 __device__ __forceinline__ float4 f4s(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
 __device__ __forceinline__ float4 f4a(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4m(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+// s*a + b as ONE v_fma_f32 per lane: fp32 VALU work beside fp32 MFMAs is not free on gfx950 (both use the
+// SIMD's FMA lanes, tools/ubench/pc_interference.hip), so the input transform is written in as few ops as it takes
+__device__ __forceinline__ float4 f4fma(float s, float4 a, float4 b) {
+    return make_float4(__builtin_fmaf(s, a.x, b.x), __builtin_fmaf(s, a.y, b.y), __builtin_fmaf(s, a.z, b.z), __builtin_fmaf(s, a.w, b.w));
+}
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 conv_w1d4_kernel(const ConvArgs p) {
@@ -314,15 +319,15 @@ conv_w1d4_kernel(const ConvArgs p) {
     auto store_chunk = [&](int buf, const float4 (&st)[C::F]) {
         if (b_role) {                                        // V = B^T d
             const float4 d0 = st[0], d1 = st[1], d2 = st[2], d3 = st[3], d4 = st[4], d5 = st[5];
-            const float4 a = f4m(d4, f4s(d2, 4.f)), b = f4m(d3, f4s(d1, 4.f));
-            const float4 c2 = f4m(d4, d2), e2 = f4s(f4m(d3, d1), 2.f);
+            const float4 a = f4fma(-4.f, d2, d4), b = f4fma(-4.f, d1, d3);
+            const float4 c2 = f4m(d4, d2), e1 = f4m(d3, d1);
             float4 *bp = reinterpret_cast<float4 *>(Bs + buf * C::B_ELEMS) + kq * C::BN + lane;
-            bp[0 * (C::B_PLANE / 4)] = f4a(f4m(f4s(d0, 4.f), f4s(d2, 5.f)), d4);
+            bp[0 * (C::B_PLANE / 4)] = f4fma(4.f, d0, f4fma(-5.f, d2, d4));
             bp[1 * (C::B_PLANE / 4)] = f4a(a, b);
             bp[2 * (C::B_PLANE / 4)] = f4m(a, b);
-            bp[3 * (C::B_PLANE / 4)] = f4a(c2, e2);
-            bp[4 * (C::B_PLANE / 4)] = f4m(c2, e2);
-            bp[5 * (C::B_PLANE / 4)] = f4a(f4m(f4s(d1, 4.f), f4s(d3, 5.f)), d5);
+            bp[3 * (C::B_PLANE / 4)] = f4fma(2.f, e1, c2);
+            bp[4 * (C::B_PLANE / 4)] = f4fma(-2.f, e1, c2);
+            bp[5 * (C::B_PLANE / 4)] = f4fma(4.f, d1, f4fma(-5.f, d3, d5));
         } else {
             float4 *ap = reinterpret_cast<float4 *>(As + buf * C::A_ELEMS) + kq * C::BM + lane;
 #pragma unroll
@@ -408,9 +413,9 @@ conv_w1d4_kernel(const ConvArgs p) {
             const float m0_ = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r], m4 = acc[4][r], m5 = acc[5][r];
             const float ps = m1 + m2, qs = m1 - m2, rr = m3 + m4, tt = m3 - m4;
             o[0][e] = m0_ + ps + rr;
-            o[1][e] = qs + 2.f * tt;
-            o[2][e] = ps + 4.f * rr;
-            o[3][e] = qs + 8.f * tt + m5;
+            o[1][e] = __builtin_fmaf(2.f, tt, qs);
+            o[2][e] = __builtin_fmaf(4.f, rr, ps);
+            o[3][e] = __builtin_fmaf(8.f, tt, qs) + m5;
         }
 #pragma unroll
         for (int b = 0; b < 4; ++b)

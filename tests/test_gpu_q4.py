@@ -321,3 +321,71 @@ def test_winograd_1d_f43_fused_matches_oracle(pa):
         assert_close(y, ref, RTOL, "winograd-1d F(4,3) fused")
     print("winograd-1d F(4,3): worst error %.2e of max|ref|" % worst)
     assert worst < 3e-5
+
+
+def test_persistent_producer_consumer_configs_match_oracle(pa):
+    """conv_pc_kernel (512-thread persistent workgroups, LDS-DMA producers, MFMA-only consumers): every
+    p* tile configuration on ragged shapes, groups, strides, dilation, several tiles per workgroup, and
+    the fused tail with a residual -- same tolerance as the 256-thread kernels."""
+    from planer_amd import q4
+    ctx = pa.hip.context()
+    names = _cfg_names(pa)
+    pnames = [n for n in names if n.startswith("p")]
+    assert len(pnames) >= 3
+    rng = np.random.default_rng(31)
+    shapes = [((2, 20, 13, 11), (70, 20, 3, 3), dict(strides=[2, 2], pads=[1, 1, 1, 1])),
+              ((3, 32, 14, 14), (40, 32, 3, 3), dict(strides=[1, 1], pads=[1, 1, 1, 1])),
+              ((2, 64, 7, 7), (130, 64, 1, 1), dict()),
+              ((2, 64, 9, 9), (48, 32, 3, 3), dict(pads=[2, 2, 2, 2], dilations=[2, 2], group=2)),
+              ((5, 24, 17, 19), (300, 24, 3, 3), dict(pads=[1, 1, 1, 1])),
+              ((40, 16, 40, 40), (64, 16, 3, 3), dict(pads=[1, 1, 1, 1]))]       # 1000 tiles of 64x64: many per workgroup
+    try:
+        for xs, ks, p in shapes:
+            x = rng.standard_normal(xs).astype(np.float32)
+            k = (rng.standard_normal(ks) * 0.1).astype(np.float32)
+            cout = ks[0]
+            sc = rng.uniform(0.5, 1.5, (1, cout, 1, 1)).astype(np.float32)
+            sh = rng.standard_normal((1, cout, 1, 1)).astype(np.float32)
+            conv = np.ascontiguousarray(onp.conv2d(x, k, **p))
+            res = rng.standard_normal(conv.shape).astype(np.float32)
+            ref = onp.relu(onp.batchnorm(conv, sc, sh) + res)
+            xq, rq = q4.to_q4(pa.asarray(x)), q4.to_q4(pa.asarray(res))
+            kq = q4.prepare_q4_weights(pa.asarray(k), p.get("group", 1))
+            dsc, dsh = pa.asarray(sc), pa.asarray(sh)
+            for name in pnames:
+                ctx.set_conv_config(names.index(name), 1)
+                yq = q4.ConvQ4(xq, kq, None, dsc, dsh, rq, act=1, **p)
+                assert ctx.last_conv_plan().startswith(name), ctx.last_conv_plan()
+                y = q4.from_q4(yq).get()
+                assert_close(y, ref, RTOL, "cfg %s %s" % (name, xs))
+                np.testing.assert_array_equal(yq.get(), q4_host(y))          # padding lanes stay zero
+                y2 = q4.from_q4(q4.ConvQ4(xq, kq, None, dsc, dsh, rq, act=1, **p)).get()
+                np.testing.assert_array_equal(y, y2)                         # deterministic
+        # K too short for the persistent kernel's parameter hand-off: it must step aside, not misbehave
+        ctx.set_conv_config(names.index(pnames[0]), 1)
+        x = rng.standard_normal((2, 8, 6, 6)).astype(np.float32)
+        k = rng.standard_normal((8, 8, 1, 1)).astype(np.float32)
+        y = q4.from_q4(q4.ConvQ4(q4.to_q4(pa.asarray(x)), q4.prepare_q4_weights(pa.asarray(k)), None)).get()
+        assert not ctx.last_conv_plan().startswith("p")
+        assert_close(y, np.ascontiguousarray(onp.conv2d(x, k)), RTOL)
+    finally:
+        ctx.set_conv_config(-1, 0)
+
+
+def test_w1d4_persistent_variant_matches_oracle(pa, monkeypatch):
+    """conv_w1d4_pc_kernel (opt-in, PLANER_HIP_W1D4_PC=1): same arithmetic as conv_w1d4_kernel."""
+    from planer_amd import q4
+    ctx = pa.hip.context()
+    monkeypatch.setenv("PLANER_HIP_W1D4_PC", "1")
+    rng = np.random.default_rng(41)
+    for n, c, h, w, co in [(2, 16, 9, 11, 24), (3, 32, 13, 17, 70), (8, 64, 28, 28, 64), (40, 16, 20, 36, 130)]:
+        x = rng.standard_normal((n, c, h, w)).astype(np.float32)
+        k = (rng.standard_normal((co, c, 3, 3)) * 0.1).astype(np.float32)
+        sc = rng.uniform(0.5, 1.5, (1, co, 1, 1)).astype(np.float32)
+        sh = rng.standard_normal((1, co, 1, 1)).astype(np.float32)
+        res = rng.standard_normal((n, co, h, w)).astype(np.float32)
+        ref = onp.relu(onp.batchnorm(np.ascontiguousarray(onp.conv2d(x, k, pads=[1, 1, 1, 1])), sc, sh) + res)
+        yq = q4.ConvQ4(q4.to_q4(pa.asarray(x)), q4.prepare_w1d4_q4_weights(pa.asarray(k)), None, pa.asarray(sc),
+                       pa.asarray(sh), q4.to_q4(pa.asarray(res)), pads=[1, 1, 1, 1], act=1, w_layout=8)
+        assert ctx.last_conv_plan().startswith("w1d4pc"), ctx.last_conv_plan()
+        assert_close(q4.from_q4(yq).get(), ref, RTOL, "w1d4pc %s" % ((n, c, h, w, co),))
