@@ -302,7 +302,7 @@ def main():
     algos = {a["layer"].rstrip("+"): a for a in plan.algos}
     rows, classes, families = [], {}, {}
     for (name, kind), v in per_layer.items():
-        ms = float(np.mean(v))
+        ms = float(np.median(v))                 # median: one pool-growth hiccup must not skew a layer
         base = name.rstrip("+")
         c, rec = convs.get(base), algos.get(base)
         alg = c["flops"] if c else 0.0
@@ -430,7 +430,9 @@ def main():
                       "device": ctx.arch, "cu_count": ctx.cu_count,
                       "tune_cache": os.environ.get("PLANER_HIP_TUNE_CACHE"),
                       "algos": algo_list},
-           "roofline": roofline, "roofline_hbm": hbm}
+           "roofline": roofline, "roofline_hbm": hbm,
+           "per_layer": [{"layer": r["layer"], "kernel": r["kernel"].split(" ")[0], "us": round(r["ms"] * 1e3, 2),
+                          "algorithmic_flops": r["algorithmic_flops"], "executed_flops": r["executed_flops"]} for r in rows]}
     if cpu_rep is not None:
         out["cpu_baseline"] = cpu_rep
         out["gpu_over_cpu"] = round(value / cpu_rep["value"], 1)
