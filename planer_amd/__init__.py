@@ -14,6 +14,7 @@ from . import hip
 from . import util  # noqa: F401  (tile / resize: tiled large-image inference, util.py:253-348)
 from .hip import DeviceArray
 from .io import from_graph, read_net
+from .onnx_import import onnx2pla, read_onnx  # noqa: F401  (io.py:53-299; need the `onnx` package at call time)
 from .layer import *  # noqa: F401,F403  (Conv2d, Dense, ..., layer_map, wrap)
 from .layer import layer_map, prepare_conv_weights, prepare_winograd_weights, wrap
 from .net import Net

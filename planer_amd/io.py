@@ -3,9 +3,8 @@
 Formats are the reference's own: a `.pla` zip holding `<base>.json` +
 `<base>.npy`, or the two files side by side.  The json carries `input`,
 `inits`, `layers`, `flow`; the npy is a 1-D uint8 array with every init's raw
-bytes back to back (io.py:286, net.py:83-88).  `.onnx` import needs the `onnx`
-package (io.py:53-54), which this image does not have; graphs are produced by
-planer_amd.irgen or by the reference's own onnx2pla elsewhere.
+bytes back to back (io.py:286, net.py:83-88).  A lone `.onnx` file goes through
+planer_amd.onnx_import.read_onnx (io.py:24-27), which needs the `onnx` package.
 """
 import json
 import os
@@ -41,10 +40,12 @@ def read_net(path, debug=False, ctx=None, comm=None):
     """
     path = path.replace(".onnx", "")
     graph, blob = _load_pair(path)
+    if graph is None and os.path.exists(path + ".onnx"):           # io.py:24-27
+        from .onnx_import import read_onnx
+        graph, blob = read_onnx(path + ".onnx")
+        if graph == "lost":
+            return blob                                             # the node nobody knows (io.py:26)
     if graph is None:
-        if os.path.exists(path + ".onnx"):
-            raise NotImplementedError("reading .onnx needs the `onnx` package (io.py:53-54); "
-                                      "convert with onnx2pla first")
         return print("model %s not found!" % path)
     net = Net(ctx)
     net.load_json(graph["input"], graph["inits"], graph["layers"], graph["flow"], debug)

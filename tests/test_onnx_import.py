@@ -1,0 +1,120 @@
+"""the ONNX importer restatement (planer_amd/onnx_import.py) against what the REFERENCE's
+io.read_onnx (io.py:53-287) produced for the very same protobuf stand-ins (tests/golden/onnx_ir.json,
+made by tools/capture_onnx_golden.py in the build container).  Integer / byte work: exact equality."""
+import hashlib
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+
+from planer_amd import onnx_import
+from tests import onnx_standin as st
+from tests.conftest import GOLDEN, RTOL, assert_close
+
+GOLD = json.load(open(os.path.join(GOLDEN, "onnx_ir.json")))
+
+
+def norm(graph):
+    return json.loads(json.dumps(graph))
+
+
+@pytest.mark.parametrize("name", ["mini_resnet", "every_op"])
+def test_ir_and_blob_equal_the_reference_importer(name):
+    graph, blob = onnx_import.graph_to_ir(st.MODELS[name]().graph, st.to_array)
+    want = GOLD[name]
+    g = norm(graph)
+    assert g["input"] == want["graph"]["input"]
+    assert g["inits"] == want["graph"]["inits"]
+    for mine, ref in zip(g["layers"], want["graph"]["layers"]):
+        assert mine == ref
+    assert len(g["layers"]) == len(want["graph"]["layers"])
+    assert g["flow"] == want["graph"]["flow"]
+    assert blob.dtype == np.uint8 and blob.size == want["blob_len"]
+    assert hashlib.sha256(blob.tobytes()).hexdigest() == want["blob_sha256"]
+
+
+def test_reference_quirks_are_kept():
+    graph, _ = onnx_import.graph_to_ir(st.every_op().graph, st.to_array)
+    layers = {l[0]: l for l in graph["layers"]}
+    assert layers["clip_k14"][2] == {"max": 6.0}                     # min == 0.0 fails the truth test (io.py:273-278)
+    assert layers["reciprocal_u7"][1] == "erf"                       # io.py:269-270
+    assert layers["conv_t0"][2] == {"group": 1, "strides": None, "dilations": None, "pads": None}
+    assert layers["batchnormalization_t3"][1] == "batchnorm"
+    bn_flow = [f for f in graph["flow"] if f[1] == ["batchnormalization_t3"]][0]
+    assert bn_flow[0] == ["t0", "g_invK", "g_invB"]
+    assert [i for i in graph["inits"] if i[0] == "c0"][0][1] in ((), [])       # 0-d Constant keeps its () shape
+    assert graph["layers"][-1] == ["return", "return", {}] and graph["flow"][-1][2] == "plrst"
+    assert not any(l[1] == "const" for l in graph["layers"])
+
+
+def test_batchnorm_fold_uses_the_hard_coded_epsilon():
+    m = st.mini_resnet()
+    graph, blob = onnx_import.graph_to_ir(m.graph, st.to_array)
+    arrs, off = {}, 0
+    for name, shape, dt in graph["inits"]:
+        n = int(np.prod(shape, dtype=np.int64)) * np.dtype(dt).itemsize
+        arrs[name] = blob[off:off + n].view(dt).reshape(shape)
+        off += n
+    g, b, mu, var = [arrs[k] for k in ("g1", "be1", "m1", "v1")]
+    np.testing.assert_array_equal(arrs["g1_invK"].ravel(), g * (1 / np.sqrt(var + 1e-5)))      # not the node's 1e-3
+    np.testing.assert_array_equal(arrs["g1_invB"].ravel(), -g * mu * (1 / np.sqrt(var + 1e-5)) + b)
+    assert arrs["g1_invK"].shape == (1, 8, 1, 1)
+
+
+def test_unknown_op_is_reported_like_the_reference(capsys):
+    status, node = onnx_import.graph_to_ir(st.unknown_op().graph, st.to_array)
+    assert status == "lost" and node.op_type == GOLD["unknown_op"]["lost"] == "Einsum"
+    assert capsys.readouterr().out == GOLD["unknown_op"]["printed"]
+
+
+def test_read_onnx_needs_the_onnx_package(tmp_path):
+    try:
+        import onnx  # noqa: F401
+        pytest.skip("onnx is installed here")
+    except ImportError:
+        pass
+    with pytest.raises(ImportError, match="onnx"):
+        onnx_import.read_onnx(str(tmp_path / "m.onnx"))
+
+
+def test_onnx2pla_and_read_net_round_trip(tmp_path, monkeypatch):
+    """With an `onnx` module present (here: a fake one serving the stand-in), onnx2pla writes the files
+    the reference's reader takes, and read_net('<model>.onnx') routes through the importer."""
+    import sys
+    fake = types.ModuleType("onnx")
+    fake.numpy_helper = types.ModuleType("onnx.numpy_helper")
+    fake.numpy_helper.to_array = st.to_array
+    fake.load = lambda path: st.mini_resnet()
+    monkeypatch.setitem(sys.modules, "onnx", fake)
+    monkeypatch.setitem(sys.modules, "onnx.numpy_helper", fake.numpy_helper)
+    path = str(tmp_path / "mini.onnx")
+    open(path, "wb").close()
+    onnx_import.onnx2pla(path, zip=True)
+    assert os.path.exists(str(tmp_path / "mini.pla")) and not os.path.exists(str(tmp_path / "mini.json"))
+    from oracle import planer_np as onp
+    net = onp.read_net(str(tmp_path / "mini"))                      # the oracle reads .pla like io.read_net
+    x = np.random.default_rng(0).standard_normal((2, 3, 8, 8)).astype(np.float32)
+    y = net(x)
+    assert y.shape == (2, 5) and np.isfinite(y).all()
+    onnx_import.onnx2pla(path, zip=False)
+    g = json.load(open(str(tmp_path / "mini.json")))
+    assert g == GOLD["mini_resnet"]["graph"]
+    assert np.load(str(tmp_path / "mini.npy")).tolist() == GOLD["mini_resnet"]["blob"]
+
+
+@pytest.mark.gpu
+def test_imported_graph_runs_on_the_gpu_like_the_oracle():
+    import planer_amd
+    from oracle import planer_np as onp
+    graph, blob = onnx_import.graph_to_ir(st.mini_resnet().graph, st.to_array)
+    graph = norm(graph)
+    x = np.random.default_rng(5).standard_normal((4, 3, 16, 16)).astype(np.float32)
+    ref = onp.OracleNet()
+    ref.load_json(graph["input"], graph["inits"], graph["layers"], graph["flow"])
+    ref.load_weights(blob)
+    want = ref(x.copy())
+    net = planer_amd.from_graph(graph, blob)
+    for _ in range(2):
+        assert_close(net(x), want, RTOL)
