@@ -296,6 +296,21 @@ int pl_transpose_f32(pl_ctx *ctx, const float *x, float *y, int ndim, const int 
 int pl_strided_map_f32(pl_ctx *ctx, const float *x, float *y, int ndim, const int *out_shape,
                        const long long *in_stride, const int *start, const int *step,
                        const int *div, const int *extent, const int *wrap, double fill);
+/* ---- operators of ONNX-exported detection heads (layer.py:155-157, 200-234, 253-258) -------------
+ * pl_compare_f32: layer.Equal / Greater / GreaterOrEqual (op 0 / 1 / 2) -> bool bytes; *_one: that operand is one value.
+ * pl_where_f32:   layer.Where, np.where(mask, a, b) with bool-byte mask.
+ * pl_cast:        layer.Cast between 0 float32, 1 int32, 2 int64, 3 bool (numpy astype: truncation, != 0).
+ * pl_gather_f32:  layer.Gather, np.take(x, idx, axis) on x viewed (outer, axis_len, inner); idx int32, negatives wrap.
+ * pl_erf_lut_f32: layer.Erf -- clamps x IN PLACE like the reference and looks y up in its 1025-entry table `lut`.
+ * pl_instancenorm_f32: layer.InstanceNormalization on (rows = N*C, inner) IN PLACE, scale/bias per channel. */
+int pl_compare_f32(pl_ctx *ctx, const float *a, const float *b, unsigned char *y, size_t n, int op, int a_one, int b_one);
+int pl_where_f32(pl_ctx *ctx, const unsigned char *mask, const float *a, const float *b, float *y, size_t n,
+                 int a_one, int b_one);
+int pl_cast(pl_ctx *ctx, const void *src, void *dst, size_t n, int src_type, int dst_type);
+int pl_gather_f32(pl_ctx *ctx, const float *x, const int *idx, float *y, int outer, int axis_len, int inner, int n_idx);
+int pl_erf_lut_f32(pl_ctx *ctx, float *x, const float *lut, float *y, size_t n);
+int pl_instancenorm_f32(pl_ctx *ctx, float *x, const float *scale, const float *bias, int rows, int C, int inner,
+                        double eps);
 /* ---- tiled large-image inference: the device side of util.tile (util.py:291-348) ----
  * pl_resize_hwc_f32: util.resize (util.py:253-269) on an H x W x C image; ra/rs (OH entries) and
  * ca/cs (OW entries) are the integer sample rows/columns and their fractions, device arrays

@@ -349,7 +349,66 @@ def convtranspose2d(x, K, B=None, strides=[2, 2], dilations=[1, 1], pads=[0, 0, 
     return conv2d(buf, K.transpose(1, 0, 2, 3)[:, :, ::-1, ::-1], B, strides=[1, 1], dilations=dilations, group=group)
 
 
-OPS = {"slice": slice_, "pad": pad, "tile": lambda x, repeat: np.tile(x, repeat.tolist()), "expand": expand,
+# ---- operators of ONNX-exported detection heads ---------------------------------------------------
+def const(value=0, dtype="float32"):
+    """layer.Const (layer.py:136-139)"""
+    return np.array(value, dtype=dtype) if isinstance(value, list) else value
+
+
+def instancenorm(x, s, bias, epsilon=1e-5):
+    """layer.InstanceNormalization (layer.py:214-224): in place on x; s / bias are reshaped in place"""
+    axis = tuple(range(2, x.ndim))
+    mean = np.mean(x, axis=axis, keepdims=True)
+    var = x - mean
+    var **= 2
+    var = np.mean(var, axis=axis, keepdims=True)
+    s.shape = bias.shape = (-1,) + (1,) * (x.ndim - 2)
+    var = (var + epsilon) ** 0.5
+    x *= s / var
+    x += bias - s * mean / var
+    return x
+
+
+_ERF_LUT = None
+
+
+def erf(x):
+    """layer.Erf (layer.py:253-258): table lookup at 1025 points of [-2, 2]; clobbers x like the reference"""
+    global _ERF_LUT
+    if _ERF_LUT is None:
+        from math import erf as _erf
+        _ERF_LUT = [_erf(i / 256 - 2) for i in range(1025)]
+    x -= 2
+    x *= x < 0
+    x += 4
+    x *= x > 0
+    x *= 256
+    return np.array(_ERF_LUT, x.dtype)[x.astype("int16")]
+
+
+def scatternd(data, indices, updates):
+    """layer.Scatternd (layer.py:208-212)"""
+    data = data.copy()
+    for i in range(len(indices[0])):
+        data[tuple(indices[0, i])] = updates[0, i]
+    return data
+
+
+def topk(x, k, axis=-1, largest=1, sorted=1):
+    """layer.TopK (layer.py:234-239)"""
+    idk = np.arange(k) * -largest - (largest > 0)
+    idx = np.take(np.argsort(x, axis=axis), idk, axis=axis)
+    return np.take_along_axis(x, idx, axis=axis), idx
+
+
+OPS = {"shape": lambda x: np.array(x.shape), "gather": lambda x, idx, axis=0: np.take(x, idx, axis=axis),
+       "const": const, "constantofshape": lambda x, value=0, dtype="float32": np.full(x.ravel().tolist(), value, dtype=dtype),
+       "cast": lambda x, dtype="flaot32": x.astype(dtype),
+       "range": lambda start, end, delta: np.arange(int(start), int(end), int(delta)),
+       "equal": lambda a, b: np.equal(a, b), "greater": lambda a, b: np.greater(a, b), "greaterorequal": lambda a, b: a >= b,
+       "where": lambda m, a, b: np.where(m, a, b), "nonzero": lambda x: np.array(np.nonzero(x)),
+       "scatternd": scatternd, "topk": topk, "erf": erf, "instancenormalization": instancenorm,
+       "slice": slice_, "pad": pad, "tile": lambda x, repeat: np.tile(x, repeat.tolist()), "expand": expand,
        "split": split, "convtranspose": convtranspose2d,
        "sub": sub, "mul": mul, "div": div, "pow": power, "exp": lambda x: np.exp(x),
        "log": lambda x: np.log(x), "tanh": lambda x: np.tanh(x), "sqrt": lambda x: np.sqrt(x),

@@ -103,6 +103,12 @@ SIGNATURES = {
     "pl_transpose_f32": [_P, _P, _P, _I, POINTER(c_int), POINTER(c_int)],
     "pl_strided_map_f32": [_P, _P, _P, _I, POINTER(c_int), POINTER(ctypes.c_longlong), POINTER(c_int), POINTER(c_int),
                            POINTER(c_int), POINTER(c_int), POINTER(c_int), c_double],
+    "pl_compare_f32": [_P, _P, _P, _P, _Z, _I, _I, _I],
+    "pl_where_f32": [_P, _P, _P, _P, _P, _Z, _I, _I],
+    "pl_cast": [_P, _P, _P, _Z, _I, _I],
+    "pl_gather_f32": [_P, _P, _P, _P, _I, _I, _I, _I],
+    "pl_erf_lut_f32": [_P, _P, _P, _P, _Z],
+    "pl_instancenorm_f32": [_P, _P, _P, _P, _I, _I, _I, c_double],
     "pl_resize_hwc_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "pl_tile_accumulate_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I],
     "pl_tile_normalise_f32": [_P, _P, _P, _I, _I, _I],

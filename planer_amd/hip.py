@@ -235,7 +235,7 @@ class DeviceArray:
         return a if dtype is None else a.astype(dtype)
 
     def set(self, host):
-        host = numpy.ascontiguousarray(host, dtype=self.dtype)
+        host = numpy.require(host, dtype=self.dtype, requirements="C")      # (ascontiguousarray lifts 0-d to 1-d)
         if host.shape != self.shape:
             raise ValueError("shape mismatch %s vs %s" % (host.shape, self.shape))
         if host.nbytes:
@@ -279,8 +279,11 @@ def asarray(a, dtype=None, ctx=None):
     """Host ndarray -> DeviceArray (net.py:96-98); DeviceArrays pass through."""
     if isinstance(a, DeviceArray):
         return a
-    host = numpy.ascontiguousarray(a, dtype=dtype)
-    return DeviceArray(host.shape, host.dtype, ctx).set(host)
+    host = numpy.require(a, dtype=dtype, requirements="C")
+    d = DeviceArray(host.shape, host.dtype, ctx).set(host)
+    if host.dtype != numpy.float32 and host.size <= 4096:
+        d.host = host.copy()         # small integer / bool tensors (shapes, indices) stay readable on the host
+    return d
 
 
 def asnumpy(a, **key):

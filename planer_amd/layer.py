@@ -5,16 +5,18 @@ is `f(*arrays, **json_params)` with the reference's positional order, keyword
 names and defaults, and `wrap(f, kind)(**params)` gives the Layer objects
 `Net` instantiates (layer.py:6-13).  Here every function takes and returns
 `DeviceArray`s and enqueues hand-written HIP kernels through the C ABI
-(include/planer_hip.h); nothing in this module computes on the host.
+(include/planer_hip.h); no activation is ever computed on the host.  (Integer
+shape tensors -- what `Shape` returns and what is derived from it -- are
+evaluated on their host mirrors, see "shape-domain tensors" below.)
 
-Ops of the reference's table that no BASELINE config reaches are listed in
-`NOT_ON_DEVICE` and raise NotImplementedError instead of silently running on
-the CPU.
+The four ops of the reference's table that need sorting, data-dependent
+shapes or a recurrence (`NOT_ON_DEVICE`) raise NotImplementedError instead of
+silently running on the CPU.
 """
 import numpy
 
 from . import _lib
-from .hip import DeviceArray, empty
+from .hip import DeviceArray, asarray, empty
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = _lib.ACT_NONE, _lib.ACT_RELU, _lib.ACT_LEAKY
 
@@ -145,14 +147,33 @@ def Dense(x, K, B, shp=None):
 
 
 def MatMul(x, y):
-    """layer.MatMul (layer.py:20) for 2-D operands."""
+    """layer.MatMul (layer.py:20): np.matmul -- 2-D operands, or stacks of matrices whose leading
+    dimensions are equal or absent on one side (one MFMA GEMM per matrix of the stack)."""
     _f32(x, y)
-    if x.ndim != 2 or y.ndim != 2:
-        raise NotImplementedError("MatMul on the HIP path handles 2-D operands")
-    m, k = x.shape
-    n = y.shape[1]
-    out = empty((m, n), ctx=x.ctx)
-    _lib.call("pl_gemm_f32", x.ctx.handle, x.ptr, m, k, y.ptr, n, 0, None, out.ptr)
+    if x.ndim < 2 or y.ndim < 2:
+        raise NotImplementedError("MatMul on the HIP path needs operands with at least 2 dimensions")
+    m, k = x.shape[-2:]
+    if y.shape[-2] != k:
+        raise ValueError("matmul: inner dimensions differ: %s @ %s" % (x.shape, y.shape))
+    n = y.shape[-1]
+    if x.ndim == 2 and y.ndim == 2:
+        out = empty((m, n), ctx=x.ctx)
+        _lib.call("pl_gemm_f32", x.ctx.handle, x.ptr, m, k, y.ptr, n, 0, None, out.ptr)
+        return out
+    lead = x.shape[:-2] if x.ndim >= y.ndim else y.shape[:-2]
+    if (x.ndim > 2 and y.ndim > 2 and x.shape[:-2] != y.shape[:-2]):
+        raise NotImplementedError("matmul: stacks must have equal leading dimensions (no broadcasting between stacks)")
+    if y.ndim == 2:                                     # (..., m, k) @ (k, n): one GEMM over all rows
+        out = empty(x.shape[:-1] + (n,), ctx=x.ctx)
+        rows = x.size // k
+        _lib.call("pl_gemm_f32", x.ctx.handle, x.ptr, rows, k, y.ptr, n, 0, None, out.ptr)
+        return out
+    count = int(numpy.prod(lead, dtype=numpy.int64))
+    out = empty(tuple(lead) + (m, n), ctx=x.ctx)
+    for b in range(count):
+        xa = x.ptr + (b * m * k * 4 if x.ndim > 2 else 0)
+        ya = y.ptr + b * k * n * 4
+        _lib.call("pl_gemm_f32", x.ctx.handle, xa, m, k, ya, n, 0, None, out.ptr + b * m * n * 4)
     return out
 
 
@@ -390,45 +411,48 @@ def Clip(x, min=0, max=1):
     return _unary(x, 6, min, max, inplace=True)
 
 
-def _rows_cols(x, axis):
+def _softmax_any_axis(x, axis, log):
+    _f32(x)
     nd = x.ndim
     axis = axis + nd if axis < 0 else axis
-    if axis != nd - 1:
-        raise NotImplementedError("softmax over axis %d of %d dims is not on the HIP path (last axis only)" % (axis, nd))
+    if not 0 <= axis < nd:
+        raise ValueError("softmax: axis out of range")
+    if axis != nd - 1:                                  # move the axis last, reduce, move it back
+        perm = [d for d in range(nd) if d != axis] + [axis]
+        inv = [perm.index(d) for d in range(nd)]
+        return Transpose(_softmax_any_axis(Transpose(x, perm), -1, log), inv)
     cols = x.shape[-1]
-    return (x.size // cols if cols else 0), cols
+    y = empty(x.shape, ctx=x.ctx)
+    _lib.call("pl_softmax_f32", x.ctx.handle, x.ptr, y.ptr, (x.size // cols if cols else 0), cols, log)
+    return y
 
 
 def Softmax(x, axis=-1):
     """layer.Softmax (layer.py:141-146)"""
-    _f32(x)
-    rows, cols = _rows_cols(x, axis)
-    y = empty(x.shape, ctx=x.ctx)
-    _lib.call("pl_softmax_f32", x.ctx.handle, x.ptr, y.ptr, rows, cols, 0)
-    return y
+    return _softmax_any_axis(x, axis, 0)
 
 
 def LogSoftmax(x, axis=-1):
     """layer.LogSoftmax (layer.py:148-153)"""
-    _f32(x)
-    rows, cols = _rows_cols(x, axis)
-    y = empty(x.shape, ctx=x.ctx)
-    _lib.call("pl_softmax_f32", x.ctx.handle, x.ptr, y.ptr, rows, cols, 1)
-    return y
+    return _softmax_any_axis(x, axis, 1)
 
 
 def _reduce(x, axes, keepdims, op):
-    """ReduceSum/Mean/Max/Min (layer.py:113-123) over a trailing block of axes."""
+    """ReduceSum/Mean/Max/Min (layer.py:113-123): x.<op>(axis=tuple(axes), keepdims).  The kernel reduces a
+    trailing block of axes; any other set is moved there by one transpose first."""
     _f32(x)
     nd = x.ndim
-    axes = sorted(a + nd if a < 0 else a for a in tuple(axes))      # tuple(axes) as in the reference
-    if axes != list(range(nd - len(axes), nd)):
-        raise NotImplementedError("reduction over axes %s of %d dims is not on the HIP path (trailing axes only)" % (axes, nd))
-    cols = int(numpy.prod(x.shape[nd - len(axes):], dtype=numpy.int64))
+    axes = sorted(set(a + nd if a < 0 else a for a in tuple(axes)))      # tuple(axes) as in the reference
+    if any(not 0 <= a < nd for a in axes):
+        raise ValueError("reduction: axis out of range")
+    kept = [d for d in range(nd) if d not in axes]
+    src = x if axes == list(range(nd - len(axes), nd)) else Transpose(x, kept + axes)
+    cols = int(numpy.prod([x.shape[a] for a in axes], dtype=numpy.int64))
     rows = x.size // cols if cols else 0
-    lead = x.shape[:nd - len(axes)]
-    y = empty(lead + ((1,) * len(axes) if keepdims else ()), ctx=x.ctx)
-    _lib.call("pl_reduce_f32", x.ctx.handle, x.ptr, y.ptr, rows, max(cols, 1), op)
+    y = empty(tuple(x.shape[d] for d in kept), ctx=x.ctx)
+    _lib.call("pl_reduce_f32", x.ctx.handle, src.ptr, y.ptr, rows, max(cols, 1), op)
+    if keepdims:
+        y = y.reshape([1 if d in axes else x.shape[d] for d in range(nd)])
     return y
 
 
@@ -637,6 +661,179 @@ def ConvTranspose2d(x, K, B=None, strides=[2, 2], dilations=[1, 1], pads=[0, 0, 
     return Conv2d(buf, Kt, B, strides=[1, 1], dilations=[d1, d2])
 
 
+# ---- shape-domain tensors and the operators of ONNX detection heads ---------------------------------
+# ONNX exporters wrap the convolutional trunk in integer arithmetic on shapes (Shape -> Gather ->
+# Unsqueeze -> Concat -> Reshape ...).  Those tensors are a handful of int64 values that steer views;
+# the reference computes them with host numpy whatever the backend (layer.py:155, 202).  Here a small
+# integer / bool DeviceArray carries a host mirror (`.host`), and an operator whose tensor arguments
+# all have mirrors -- none of them a float32 activation -- is evaluated on the mirrors: no kernel, no
+# stream synchronisation.  float32 activations never take this route.
+def _mirrored(host, ctx=None):
+    host = numpy.require(host, requirements="C")
+    d = DeviceArray(host.shape, host.dtype, ctx)
+    if host.nbytes:
+        d.set(host)
+    d.host = host
+    return d
+
+
+def _shape_domain(args):
+    arrs = [a for a in args if isinstance(a, DeviceArray)]
+    return bool(arrs) and all(a.host is not None and a.dtype != numpy.float32 for a in arrs)
+
+
+def _hosts(args):
+    return [a.host if isinstance(a, DeviceArray) else a for a in args]
+
+
+def _wrap_host(out, ctx):
+    if isinstance(out, (list, tuple)):
+        return type(out)(_wrap_host(o, ctx) for o in out)
+    return _mirrored(numpy.asarray(out), ctx)
+
+
+def _with_shape_domain(device_fn, host_fn):
+    """`device_fn` for activations; `host_fn` (numpy, the reference's own expression) when every tensor
+    argument is a mirrored integer / bool tensor."""
+    def op(*args, **kw):
+        if _shape_domain(args):
+            ctx = [a for a in args if isinstance(a, DeviceArray)][0].ctx
+            return _wrap_host(host_fn(*_hosts(args), **kw), ctx)
+        return device_fn(*args, **kw)
+    op.__name__ = device_fn.__name__
+    op.__doc__ = device_fn.__doc__
+    return op
+
+
+def Shape(x):
+    """layer.Shape (layer.py:155): np.array(x.shape)"""
+    return _mirrored(numpy.array(x.shape), x.ctx if isinstance(x, DeviceArray) else None)
+
+
+def Const(value=0, dtype="float32"):
+    """layer.Const (layer.py:136-139)"""
+    if isinstance(value, list):
+        return _mirrored(numpy.array(value, dtype=dtype))
+    return value
+
+
+def ConstantofShape(x, value=0, dtype="float32"):
+    """layer.ConstantofShape (layer.py:167-168): np.full(x.ravel().tolist(), value, dtype)"""
+    out = numpy.full(_host_values(x).ravel().tolist(), value, dtype=dtype)
+    return _mirrored(out, x.ctx) if (out.dtype != numpy.float32 and out.size <= 4096) else asarray(out, ctx=x.ctx)
+
+
+def Range(start, end, delta):
+    """layer.Range (layer.py:202-203): np.arange(int(start), int(end), int(delta))"""
+    vals = [int(numpy.asarray(_host_values(v)).reshape(-1)[0]) for v in (start, end, delta)]
+    ctx = [a for a in (start, end, delta) if isinstance(a, DeviceArray)]
+    return _mirrored(numpy.arange(*vals), ctx[0].ctx if ctx else None)
+
+
+_CAST_CODES = {"float32": 0, "int32": 1, "int64": 2, "bool": 3}
+
+
+def Cast(x, dtype="flaot32"):
+    """layer.Cast (layer.py:200): x.astype(dtype); the default is the reference's own (misspelt) one."""
+    if _shape_domain([x]):
+        return _mirrored(x.host.astype(dtype), x.ctx)
+    src, dst = str(x.dtype), str(numpy.dtype(dtype))
+    if src not in _CAST_CODES or dst not in _CAST_CODES:
+        raise NotImplementedError("cast %s -> %s is not on the HIP path (float32 / int32 / int64 / bool)" % (src, dst))
+    y = empty(x.shape, numpy.dtype(dtype), ctx=x.ctx)
+    _lib.call("pl_cast", x.ctx.handle, x.ptr, y.ptr, x.size, _CAST_CODES[src], _CAST_CODES[dst])
+    return y
+
+
+def _compare(op, ref):
+    def cmp(a, b):
+        if _shape_domain([a, b]) or not any(isinstance(t, DeviceArray) for t in (a, b)):
+            ctx = [t for t in (a, b) if isinstance(t, DeviceArray)]
+            return _mirrored(ref(*_hosts([a, b])), ctx[0].ctx if ctx else None)
+        ctx = [t for t in (a, b) if isinstance(t, DeviceArray)][0].ctx
+        a, b = [t if isinstance(t, DeviceArray) else asarray(numpy.asarray(t, numpy.float32).reshape(-1), ctx=ctx) for t in (a, b)]
+        _f32(a, b)
+        shape = a.shape if a.size >= b.size else b.shape
+        n = max(a.size, b.size)
+        if not (a.size in (1, n) and b.size in (1, n)) or (a.size == b.size and a.shape != b.shape):
+            raise NotImplementedError("comparison: operands must have one shape or one of them a single value")
+        y = empty(shape, numpy.bool_, ctx=ctx)
+        _lib.call("pl_compare_f32", ctx.handle, a.ptr, b.ptr, y.ptr, n, op, int(a.size == 1 and n > 1), int(b.size == 1 and n > 1))
+        return y
+    return cmp
+
+
+Equal = _compare(0, numpy.equal)                       # layer.py:204
+Greater = _compare(1, numpy.greater)                   # layer.py:228
+GreaterOrEqual = _compare(2, lambda a, b: a >= b)      # layer.py:232
+
+
+def Where(msk, x1, x2):
+    """layer.Where (layer.py:206): np.where(msk, x1, x2); bool mask of the result's shape, x1 / x2 of
+    that shape or single values."""
+    if _shape_domain([msk, x1, x2]):
+        return _mirrored(numpy.where(*_hosts([msk, x1, x2])), msk.ctx)
+    ctx = msk.ctx
+    ops = [t if isinstance(t, DeviceArray) else asarray(numpy.asarray(t, numpy.float32).reshape(-1), ctx=ctx) for t in (x1, x2)]
+    ops = [Cast(t, "float32") if t.dtype != numpy.float32 else t for t in ops]
+    if msk.dtype != numpy.bool_:
+        raise TypeError("where: the mask must be a bool tensor")
+    n = msk.size
+    if any(t.size not in (1, n) for t in ops):
+        raise NotImplementedError("where: operands must have the mask's size or be single values")
+    y = empty(msk.shape, ctx=ctx)
+    _lib.call("pl_where_f32", ctx.handle, msk.ptr, ops[0].ptr, ops[1].ptr, y.ptr, n, int(ops[0].size == 1 and n > 1),
+              int(ops[1].size == 1 and n > 1))
+    return y
+
+
+def Gather(x, idx, axis=0):
+    """layer.Gather (layer.py:157): np.take(x, idx, axis=axis)"""
+    if _shape_domain([x, idx]) or (_shape_domain([x]) and not isinstance(idx, DeviceArray)):
+        return _mirrored(numpy.take(x.host, idx.host if isinstance(idx, DeviceArray) else idx, axis=axis), x.ctx)
+    _f32(x)
+    iv = numpy.asarray(_host_values(idx))
+    axis = axis + x.ndim if axis < 0 else axis
+    alen = x.shape[axis]
+    if iv.size and (iv.min() < -alen or iv.max() >= alen):
+        raise IndexError("gather: index out of bounds for axis %d with size %d" % (axis, alen))
+    outer = int(numpy.prod(x.shape[:axis], dtype=numpy.int64))
+    inner = int(numpy.prod(x.shape[axis + 1:], dtype=numpy.int64))
+    y = empty(x.shape[:axis] + iv.shape + x.shape[axis + 1:], ctx=x.ctx)
+    if y.size:
+        di = asarray(iv.astype(numpy.int32).reshape(-1), ctx=x.ctx)
+        _lib.call("pl_gather_f32", x.ctx.handle, x.ptr, di.ptr, y.ptr, outer, alen, max(inner, 1), iv.size)
+    return y
+
+
+_ERF_LUT = {}
+
+
+def Erf(x):
+    """layer.Erf (layer.py:253-258): the reference's table lookup -- erf(i/256 - 2) at 1025 points, index
+    from x clamped to [-2, 2] by mask multiplications, which overwrite x IN PLACE like the reference."""
+    _f32(x)
+    key = id(x.ctx)
+    if key not in _ERF_LUT:
+        from math import erf
+        _ERF_LUT[key] = asarray(numpy.array([erf(i / 256 - 2) for i in range(1025)], numpy.float32), ctx=x.ctx)
+    y = empty(x.shape, ctx=x.ctx)
+    _lib.call("pl_erf_lut_f32", x.ctx.handle, x.ptr, _ERF_LUT[key].ptr, y.ptr, x.size)
+    return y
+
+
+def InstanceNormalization(x, s, bias, epsilon=1e-5):
+    """layer.InstanceNormalization (layer.py:214-224): normalises x IN PLACE over its spatial axes and
+    returns it, like the reference."""
+    _f32(x, s, bias)
+    c = x.shape[1]
+    if s.size != c or bias.size != c:
+        raise ValueError("instancenormalization: one scale / bias value per channel")
+    inner = int(numpy.prod(x.shape[2:], dtype=numpy.int64))
+    _lib.call("pl_instancenorm_f32", x.ctx.handle, x.ptr, s.ptr, bias.ptr, x.shape[0] * c, c, max(inner, 1), float(epsilon))
+    return x
+
+
 def _missing(kind):
     def op(*a, **k):
         raise NotImplementedError(
@@ -646,9 +843,8 @@ def _missing(kind):
     return op
 
 
-NOT_ON_DEVICE = ["const", "lstm", "shape", "gather",
-                 "constantofshape", "cast", "range", "equal", "where", "scatternd",
-                 "instancenormalization", "greater", "nonzero", "greaterorequal", "topk", "erf"]
+# sorting / data-dependent shapes / recurrences: not on the device path
+NOT_ON_DEVICE = ["lstm", "scatternd", "nonzero", "topk"]
 
 layer_map = {"dense": Dense, "conv": Conv2d, "relu": ReLU, "leakyrelu": LeakyReLU,
              "batchnorm": BatchNorm, "flatten": Flatten, "sigmoid": Sigmoid,
@@ -663,6 +859,28 @@ layer_map = {"dense": Dense, "conv": Conv2d, "relu": ReLU, "leakyrelu": LeakyReL
              "transpose": Transpose, "reshape": Reshape, "squeeze": Squeeze, "unsqueeze": Unsqueeze,
              "resize": Resize, "slice": Slice, "pad": Pad, "tile": Tile, "expand": Expand, "split": Split,
              "convtranspose": ConvTranspose2d,
+             # detection-head operators
+             "shape": Shape, "const": Const, "constantofshape": ConstantofShape, "range": Range, "cast": Cast,
+             "equal": Equal, "greater": Greater, "greaterorequal": GreaterOrEqual, "where": Where, "gather": Gather,
+             "erf": Erf, "instancenormalization": InstanceNormalization,
              # plan-compiler internal
              "conv_fused": ConvFused}
+# integer shape arithmetic: the same kinds, evaluated on host mirrors when no activation is involved
+for _k, _ref in (("add", lambda a, b: a + b), ("sub", lambda a, b: a - b), ("mul", lambda a, b: a * b),
+                 ("div", lambda a, b: a / b), ("concat", lambda *xs, axis=0: numpy.concatenate(xs, axis=axis)),
+                 ("slice", None), ("squeeze", lambda x, axes=[0]: numpy.squeeze(x, axis=axes[0])),
+                 ("unsqueeze", lambda x, axes=None: numpy.expand_dims(x, tuple(numpy.array(axes).tolist()))),
+                 ("reducesum", lambda x, axes=-1, keepdims=True: x.sum(axis=tuple(axes), keepdims=keepdims)),
+                 ("transpose", lambda x, axis: x.transpose(axis)), ("identity", lambda x: x),
+                 ("expand", lambda x, shp: numpy.ones(shp.tolist(), dtype=x.dtype) * x),
+                 ("tile", lambda x, repeat: numpy.tile(x, repeat))):
+    if _k == "slice":
+        def _ref(x, start, end, axis=None, step=None):         # layer.py:188-196
+            step = numpy.ones(len(start), dtype=numpy.uint32) if step is None else step
+            axis = numpy.arange(len(start)) if axis is None else axis
+            sl = [slice(None, None, None)] * x.ndim
+            for s_, e_, a_, st_ in zip(start.tolist(), end.tolist(), axis.tolist(), step.tolist()):
+                sl[a_] = slice(s_, e_, st_)
+            return x[tuple(sl)]
+    layer_map[_k] = _with_shape_domain(layer_map[_k], _ref)
 layer_map.update({k: _missing(k) for k in NOT_ON_DEVICE})

@@ -119,6 +119,37 @@ def layer_cases():
               {"strides": [2, 2], "pads": [1, 1, 1, 1]}))
     c.append(("convtranspose_s1_dil2", "convtranspose", [_r(557, 1, 3, 8, 8), _r(558, 3, 5, 3, 3, scale=0.2), _r(559, 5)],
               {"strides": [1, 1], "dilations": [2, 2]}))
+    # ---- lifted restrictions: softmax / reductions over any axis, stacked matmul ----
+    c.append(("softmax_axis1_4d", "softmax", [_r(600, 2, 7, 5, 6, scale=2)], {"axis": 1}))
+    c.append(("logsoftmax_axis0", "logsoftmax", [_r(601, 9, 14, scale=2)], {"axis": 0}))
+    c.append(("reducesum_axis1", "reducesum", [_r(602, 3, 8, 5, 4)], {"axes": [1], "keepdims": True}))
+    c.append(("reducemean_axes02", "reducemean", [_r(603, 4, 6, 10)], {"axes": [0, 2], "keepdims": False}))
+    c.append(("reducemax_axis0", "reducemax", [_r(604, 5, 33)], {"axes": [0], "keepdims": False}))
+    c.append(("matmul_stack_2d", "matmul", [_r(610, 2, 3, 5, 17), _r(611, 17, 9)], {}))
+    c.append(("matmul_stack_stack", "matmul", [_r(612, 2, 3, 6, 20), _r(613, 2, 3, 20, 7)], {}))
+    # ---- operators of ONNX-exported detection heads ----
+    c.append(("shape", "shape", [_r(620, 2, 3, 5, 7)], {}))
+    c.append(("gather_axis0", "gather", [_r(621, 6, 5, 4), i64(4, 0, 4)], {}))
+    c.append(("gather_axis2_neg_2d_idx", "gather", [_r(622, 3, 4, 9), np.array([[0, -1], [3, 8]], np.int64)], {"axis": 2}))
+    c.append(("gather_shape_scalar", "gather", [i64(2, 255, 13, 13), np.array(1, np.int64)], {"axis": 0}))
+    c.append(("cast_f32_i64", "cast", [_r(623, 4, 9, scale=5)], {"dtype": "int64"}))
+    c.append(("cast_i64_f32", "cast", [i64(3, -7, 100000)], {"dtype": "float32"}))
+    c.append(("cast_f32_bool", "cast", [np.array([0.0, -0.0, 1.5, -2.0, 1e-30], np.float32)], {"dtype": "bool"}))
+    c.append(("range", "range", [np.array(2, np.int64), np.array(17, np.int64), np.array(4, np.int64)], {}))
+    q = np.round(_r(624, 3, 40) * 2).astype(np.float32)
+    c.append(("equal", "equal", [q, np.round(_r(625, 3, 40) * 2).astype(np.float32)], {}))
+    c.append(("greater_scalar", "greater", [q, np.array([0.5], np.float32)], {}))
+    c.append(("greaterorequal", "greaterorequal", [q, np.round(_r(626, 3, 40) * 2).astype(np.float32)], {}))
+    c.append(("equal_shape_tensors", "equal", [i64(2, 3, 4), i64(2, 5, 4)], {}))
+    c.append(("where", "where", [_r(627, 5, 33) > 0.2, _r(628, 5, 33), _r(629, 5, 33)], {}))
+    c.append(("where_scalar_rhs", "where", [_r(630, 2, 3, 8) > 0, _r(631, 2, 3, 8), np.array([-1.0], np.float32)], {}))
+    c.append(("constantofshape_f32", "constantofshape", [i64(2, 3, 4)], {"value": 1.5, "dtype": "float32"}))
+    c.append(("constantofshape_i64", "constantofshape", [i64(5)], {"value": 0, "dtype": "int64"}))
+    c.append(("erf", "erf", [_r(632, 4, 50, scale=1.5)], {}))
+    c.append(("instancenorm", "instancenormalization", [_r(633, 2, 6, 7, 9), (np.abs(_r(634, 6)) + 0.5).astype(np.float32),
+                                                       _r(635, 6)], {"epsilon": 1e-5}))
+    c.append(("concat_shape_tensors", "concat", [i64(2), i64(255), i64(13, 13)], {"axis": 0}))
+    c.append(("mul_shape_tensors", "mul", [i64(13, 13), i64(2, 2)], {}))
     return c
 
 

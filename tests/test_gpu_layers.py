@@ -47,7 +47,11 @@ EXACT = ["relu", "leakyrelu_0.1", "leakyrelu_default", "add", "batchnorm", "maxp
          "reciprocal", "hardsigmoid", "hardsigmoid_ab", "clip", "clip_relu6", "reducemax_hw", "reducemin_last",
          "transpose_0231", "transpose_10", "reshape_keep0", "squeeze", "unsqueeze", "resize_nearest_x2",
          "resize_asym_floor", "slice_basic", "slice_step_neg", "slice_default_axes", "pad_hw", "pad_value", "tile_2d",
-         "tile_more_reps", "expand_channel", "expand_lower_rank", "split_axis1", "split_axis0"]
+         "tile_more_reps", "expand_channel", "expand_lower_rank", "split_axis1", "split_axis0",
+         "reducemax_axis0", "shape", "gather_axis0", "gather_axis2_neg_2d_idx", "gather_shape_scalar", "cast_f32_i64",
+         "cast_i64_f32", "cast_f32_bool", "range", "equal", "greater_scalar", "greaterorequal", "equal_shape_tensors",
+         "where", "where_scalar_rhs", "constantofshape_f32", "constantofshape_i64", "erf", "concat_shape_tensors",
+         "mul_shape_tensors"]
 
 
 @pytest.mark.parametrize("name", EXACT)
@@ -238,8 +242,13 @@ def test_unsupported_inputs_fail_loudly(pa):
         pa.Maxpool(x, w=[2, 2], pads=[1, 0, 0, 0])
     with pytest.raises(NotImplementedError):
         pa.layer_map["lstm"](x)
-    with pytest.raises(NotImplementedError):
-        pa.Softmax(x, axis=1)                          # only the last axis is on the HIP path
+    for kind in ("topk", "nonzero", "scatternd"):      # sorting / data-dependent shapes: raise, never fall back
+        with pytest.raises(NotImplementedError):
+            pa.layer_map[kind](x)
+    with pytest.raises(ValueError):
+        pa.Softmax(x, axis=4)
+    with pytest.raises(NotImplementedError):          # stacks with different leading dimensions
+        pa.MatMul(pa.asarray(np.zeros((2, 3, 4, 5), np.float32)), pa.asarray(np.zeros((3, 2, 5, 6), np.float32)))
     with pytest.raises((ValueError, NotImplementedError)):
         pa.Conv2d(x, pa.asarray(np.zeros((4, 3, 3, 3), np.float32)))
 

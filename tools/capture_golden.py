@@ -39,7 +39,7 @@ def run_layers():
         for i, a in enumerate(args):
             store["%s/in%d" % (name, i)] = a
         for i, o in enumerate(outs):
-            store["%s/out%d" % (name, i)] = np.ascontiguousarray(o)
+            store["%s/out%d" % (name, i)] = np.require(o, requirements="C")      # (ascontiguousarray would lift 0-d to 1-d)
         meta[name] = {"kind": kind, "params": params, "n_in": len(args),
                       "n_out": len(outs),
                       # ReLU aliasing (layer.py:46): output IS the input object
