@@ -1,0 +1,141 @@
+// 3x3 / stride 1 convolution on 1..4 input channels, NCHW in and out -- included by conv_igemm.hip inside
+// its anonymous namespace.  BASELINE config 2 (Conv2d 3->64 on (8,3,224,224), reference util.conv_for,
+// util.py:17-44) is this shape: K = 27, 1.39 GFLOP against 107.6 MB of traffic of which 102.8 MB are
+// the output -- HBM-WRITE-bound (floor 13.4 us at 8 TB/s, ~17 us at the achievable 6.3 TB/s), the
+// matrix cores need 8.8 us.  So the kernel is built around the store stream:
+//   * a workgroup owns tpw x 256 consecutive output pixels of one image x 64 output channels; the filter
+//     (k-major [K][64]) and the few input rows those pixels touch (zero border included) are staged in
+//     LDS once -- x is read from HBM once (plus a two-row halo per workgroup), nothing is re-read;
+//   * M = output channels, N = pixels on v_mfma_f32_32x32x2_f32: a lane's accumulator rows are output
+//     channels and its column is ONE pixel, consecutive lanes = consecutive pixels, so every store
+//     instruction writes two full 128-byte lines of two NCHW channel planes (no partial lines, no
+//     transposition through LDS);
+//   * K order (cin, kh, kw) = K.reshape(Cout, -1) exactly as the reference's sgemm sees it; the im2col
+//     value of (pixel, k) is one ds_read_b32 at pixel base + a per-k offset kept in registers.
+struct SmallCinArgs {
+    const float *x, *w, *bias;
+    float *y;
+    int N, Cin, H, W, Cout, Ho, Wo, pad;
+    int HoWo, Wp, K, steps;          // Wp = W + 2: every staged row carries one zero column at each end
+    int tpw;                         // 256-pixel tiles per workgroup (filter and input rows are staged once for all of them)
+    FastDiv divWo, divK;
+};
+
+constexpr int SC_PIX = 256, SC_CO = 64, SC_MAXK = 36;
+
+__global__ void __launch_bounds__(256) conv_smallcin_nchw_kernel(const SmallCinArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *As = smem;                         // [steps*2][64]   filter, k-major, zero padded
+    float *Bs = smem + SC_MAXK * SC_CO;       // [64] bias (zeros without one)
+    float *Ps = Bs + SC_CO + 4;               // [Cin][rows][Wp] input rows with zero borders; Ps[-1] = 0 (K padding reads it)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int n = blockIdx.z, co0 = blockIdx.y * SC_CO, pw0 = blockIdx.x * SC_PIX * p.tpw;
+    const int p0 = pw0;
+    const int plast = min(pw0 + SC_PIX * p.tpw, p.HoWo) - 1;
+    const int r0 = (int)p.divWo.div((unsigned)p0), r1 = (int)p.divWo.div((unsigned)plast);
+    const int rows = r1 - r0 + 3;             // input rows r0-pad .. r1-pad+2
+    // ---- stage the filter (As[k][co] = w[co0+co][k]), the bias and the input rows (a thread = one column,
+    //      coalesced along W; zero outside the image).  Every global load of the first batch -- 9 filter
+    //      values, the bias, up to 24 (channel, row) lines -- is issued before the first LDS write, so a
+    //      workgroup pays ONE memory round trip before its MFMAs start ----
+    {
+        constexpr int LB = 24;
+        const int lines = p.Cin * rows;
+        float fv[SC_MAXK * SC_CO / 256], xv[LB];
+#pragma unroll
+        for (int j = 0; j < SC_MAXK * SC_CO / 256; ++j) {          // flat, coalesced read of the 64 filters' K values
+            const int i = tid + j * 256;
+            fv[j] = (i < SC_CO * p.K && (size_t)co0 * p.K + i < (size_t)p.Cout * p.K) ? p.w[(size_t)co0 * p.K + i] : 0.f;
+        }
+        const float bv = (tid < SC_CO && p.bias && co0 + tid < p.Cout) ? p.bias[co0 + tid] : 0.f;
+        for (int l0 = 0; l0 < lines; l0 += LB)
+            for (int cc = tid; cc < p.Wp || (l0 == 0 && cc == tid); cc += 256) {
+                const int w = cc - p.pad;
+                int c = l0 / rows, rr = l0 - c * rows;              // uniform
+#pragma unroll
+                for (int j = 0; j < LB; ++j) {
+                    const int h = r0 - p.pad + rr;
+                    xv[j] = 0.f;
+                    if (l0 + j < lines && cc < p.Wp && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W)
+                        xv[j] = p.x[(((size_t)n * p.Cin + c) * p.H + h) * p.W + w];
+                    if (++rr == rows) { rr = 0; ++c; }
+                }
+                if (l0 == 0 && cc == tid) {                         // first batch: the filter rides along
+#pragma unroll
+                    for (int j = 0; j < SC_MAXK * SC_CO / 256; ++j) {       // element i = (co, k) -> As[k][co]
+                        const int i = tid + j * 256;
+                        unsigned co, k;
+                        p.divK.divmod((unsigned)i, co, k);
+                        if (i < SC_CO * p.K) As[k * SC_CO + co] = fv[j];
+                    }
+                    if (tid < SC_CO) Bs[tid] = bv;
+                    if (tid < 4) Bs[SC_CO + tid] = 0.f;
+                }
+                if (cc < p.Wp) {
+#pragma unroll
+                    for (int j = 0; j < LB; ++j)
+                        if (l0 + j < lines) Ps[(l0 + j) * p.Wp + cc] = xv[j];
+                }
+            }
+    }
+    // per-k offsets into the staged rows for this lane's k = 2s + lhi
+    int koff[SC_MAXK / 2];
+#pragma unroll
+    for (int s = 0; s < SC_MAXK / 2; ++s) {
+        const int k = 2 * s + lhi;
+        const int c = k / 9, t = k - 9 * c, dy = t / 3, dx = t - 3 * dy;
+        koff[s] = k < p.K ? (c * rows + dy) * p.Wp + dx : -1;
+    }
+    __syncthreads();
+    for (int t = 0; t < p.tpw; ++t) {
+        const int pt0 = pw0 + t * SC_PIX;
+        if (pt0 >= p.HoWo) break;
+        // this wave's pixels: two blocks of 32
+        int pbase[2];
+        bool pok[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int pix = pt0 + wave * 64 + b * 32 + l31;
+            pok[b] = pix < p.HoWo;
+            unsigned ho, wo;
+            p.divWo.divmod((unsigned)(pok[b] ? pix : p0), ho, wo);
+            pbase[b] = ((int)ho - r0) * p.Wp + (int)wo;   // staged (row ho-r0, column wo) = image (ho-pad, wo-pad)
+        }
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < SC_MAXK / 2; ++s) {
+            if (s < p.steps) {
+                const float a0 = As[(2 * s + lhi) * SC_CO + l31], a1 = As[(2 * s + lhi) * SC_CO + 32 + l31];
+                const float b0 = Ps[koff[s] >= 0 ? pbase[0] + koff[s] : -1];      // K padding reads the zero slot
+                const float b1 = Ps[koff[s] >= 0 ? pbase[1] + koff[s] : -1];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        }
+        // ---- bias + store: lanes = consecutive pixels of one channel plane -> full 128-byte lines ----
+        float *yb = p.y + ((size_t)n * p.Cout + co0) * p.HoWo + pt0 + wave * 64 + l31;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (co0 + co >= p.Cout) continue;
+                const float bv = Bs[co];
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    if (pok[b]) {
+                        const float v = acc[a][b][r];
+                        yb[(size_t)co * p.HoWo + b * 32] = p.bias ? __fadd_rn(v, bv) : v;
+                    }
+            }
+    }
+}

@@ -263,3 +263,18 @@ def test_empty_and_ragged(pa):
     d = pa.asarray(a)
     np.testing.assert_array_equal(pa.LeakyReLU(d[1], 0.1).get(), onp.leakyrelu(a[1].copy(), 0.1))
     np.testing.assert_array_equal(pa.Add(d[1], d[2]).get(), a[1] + a[2])
+
+
+def test_small_cin_store_stream_kernel_matches_oracle(pa, monkeypatch):
+    """conv_smallcin_nchw_kernel (opt-in, PLANER_HIP_SMALLCIN=1): 3x3 / stride 1 on 1..4 input channels, the
+    BASELINE config-2 shape class -- ragged widths, pad 0 / 1, channel counts that are not multiples of 64."""
+    monkeypatch.setenv("PLANER_HIP_SMALLCIN", "1")
+    rng = np.random.default_rng(77)
+    for n, c, h, w, co, pad, bias in [(2, 3, 9, 11, 20, 1, True), (1, 1, 5, 300, 70, 0, False), (3, 4, 17, 16, 64, 1, True),
+                                      (2, 2, 40, 7, 130, 1, True), (2, 3, 64, 64, 64, 1, True)]:
+        x = rng.standard_normal((n, c, h, w)).astype(np.float32)
+        k = (rng.standard_normal((co, c, 3, 3)) * 0.1).astype(np.float32)
+        b = rng.standard_normal(co).astype(np.float32) if bias else None
+        y = pa.Conv2d(pa.asarray(x), pa.asarray(k), pa.asarray(b) if bias else None, pads=[pad] * 4)
+        assert pa.hip.context().last_conv_plan().startswith("smallcin3x3")
+        assert_close(y.get(), np.ascontiguousarray(onp.conv2d(x, k, b, pads=[pad] * 4)), RTOL, str((n, c, h, w, co)))
