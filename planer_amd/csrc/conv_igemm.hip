@@ -1114,6 +1114,7 @@ int conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const
             SmallCinArgs sa;
             sa.x = x; sa.w = w; sa.bias = bias; sa.y = y;
             sa.N = N; sa.Cin = Cin; sa.H = H; sa.W = W; sa.Cout = Cout; sa.Ho = Ho; sa.Wo = Wo; sa.pad = pt;
+            sa.x_bytes = (int)(in_elems * 4);
             sa.HoWo = Ho * Wo; sa.Wp = W + 2; sa.K = Cin * 9; sa.steps = (sa.K + 1) / 2; sa.tpw = tpw;
             sa.divWo = FastDiv(Wo); sa.divK = FastDiv(sa.K);
             int rc = ensure_lds_attr((const void *)conv_smallcin_nchw_kernel, 64 * 1024);

@@ -16,6 +16,7 @@ struct SmallCinArgs {
     const float *x, *w, *bias;
     float *y;
     int N, Cin, H, W, Cout, Ho, Wo, pad;
+    int x_bytes;
     int HoWo, Wp, K, steps;          // Wp = W + 2: every staged row carries one zero column at each end
     int tpw;                         // 256-pixel tiles per workgroup (filter and input rows are staged once for all of them)
     FastDiv divWo, divK;
@@ -41,12 +42,16 @@ __global__ void __launch_bounds__(256) conv_smallcin_nchw_kernel(const SmallCinA
     //      workgroup pays ONE memory round trip before its MFMAs start ----
     {
         constexpr int LB = 24;
+        constexpr int OOB = (int)0x80000000;
+        // zero fill by the buffers' range check: a predicated plain load makes hipcc wait for each element in turn
+        const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, p.x_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, p.Cout * p.K * 4, 0x00020000);
         const int lines = p.Cin * rows;
         float fv[SC_MAXK * SC_CO / 256], xv[LB];
 #pragma unroll
         for (int j = 0; j < SC_MAXK * SC_CO / 256; ++j) {          // flat, coalesced read of the 64 filters' K values
             const int i = tid + j * 256;
-            fv[j] = (i < SC_CO * p.K && (size_t)co0 * p.K + i < (size_t)p.Cout * p.K) ? p.w[(size_t)co0 * p.K + i] : 0.f;
+            fv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrsrc, i < SC_CO * p.K ? (co0 * p.K + i) << 2 : OOB, 0, 0));
         }
         const float bv = (tid < SC_CO && p.bias && co0 + tid < p.Cout) ? p.bias[co0 + tid] : 0.f;
         for (int l0 = 0; l0 < lines; l0 += LB)
@@ -56,9 +61,9 @@ __global__ void __launch_bounds__(256) conv_smallcin_nchw_kernel(const SmallCinA
 #pragma unroll
                 for (int j = 0; j < LB; ++j) {
                     const int h = r0 - p.pad + rr;
-                    xv[j] = 0.f;
-                    if (l0 + j < lines && cc < p.Wp && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W)
-                        xv[j] = p.x[(((size_t)n * p.Cin + c) * p.H + h) * p.W + w];
+                    const bool ok = l0 + j < lines && cc < p.Wp && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+                    xv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                          xrsrc, ok ? (((n * p.Cin + c) * p.H + h) * p.W + w) << 2 : OOB, 0, 0));
                     if (++rr == rows) { rr = 0; ++c; }
                 }
                 if (l0 == 0 && cc == tid) {                         // first batch: the filter rides along
@@ -68,6 +73,7 @@ __global__ void __launch_bounds__(256) conv_smallcin_nchw_kernel(const SmallCinA
                         unsigned co, k;
                         p.divK.divmod((unsigned)i, co, k);
                         if (i < SC_CO * p.K) As[k * SC_CO + co] = fv[j];
+                        else if (i < SC_CO * 2 * p.steps) As[i] = 0.f;          // K padding rows
                     }
                     if (tid < SC_CO) Bs[tid] = bv;
                     if (tid < 4) Bs[SC_CO + tid] = 0.f;

@@ -301,6 +301,51 @@ __global__ void __launch_bounds__(TPB) pool2d_q4_kernel(const float4 *x, float4 
     }
 }
 
+// 3x3 / stride 2 / pad 1 max pool (ResNet's stem pool) on Q4: a thread owns TWO vertically adjacent outputs and
+// reads its 5x3 input window once (15 float4 instead of 18; an input row is fetched for 2 output rows instead of
+// 1.5) while consecutive lanes stay consecutive output columns -- the generic kernel above re-read 23 % of its input
+// from HBM (profiles/r01_hbm_traffic.md).  Same zero padding, -1e4 start and per-output accumulation order as
+// pool2d_q4_kernel<0> (util.py:79-95), so results are bit-identical.
+__global__ void __launch_bounds__(TPB) maxpool_q4_k3s2p1_2x1(const float4 *x, float4 *y, unsigned total, int H, int W,
+                                                             int Ho, int Wo, int Hb, unsigned x_bytes, FastDiv divWo,
+                                                             FastDiv divHb) {
+    const unsigned stride = gridDim.x * TPB;
+    // the zero padding comes from the buffer's range check (an out-of-window lane gets an out-of-range offset):
+    // all 15 loads of a thread are in flight together, no branch per element
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(x), 0, x_bytes, 0x00020000);
+    constexpr int OOB = (int)0x80000000;
+    for (unsigned i = blockIdx.x * TPB + threadIdx.x; i < total; i += stride) {      // i = (nc*Hb + a)*Wo + ow
+        unsigned row, ow, nc, a;
+        divWo.divmod(i, row, ow);
+        divHb.divmod(row, nc, a);
+        const int h0 = 4 * (int)a - 1, w0 = 2 * (int)ow - 1;
+        const int base = (int)nc * H * W;                                            // in float4s; < 2^27 (host check)
+        float4 v[5][3];
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            const int hi = h0 + r;
+            const bool hok = (unsigned)hi < (unsigned)H;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int wi = w0 + q;
+                const bool ok = hok && (unsigned)wi < (unsigned)W;
+                v[r][q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? (base + hi * W + wi) << 4 : OOB, 0, 0));
+            }
+        }
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            const int oh = 2 * (int)a + dy;
+            if (oh >= Ho) continue;
+            float4 acc = make_float4(-1e4f, -1e4f, -1e4f, -1e4f);
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) acc = f4max(v[2 * dy + r][q], acc);
+            y[((size_t)nc * Ho + oh) * Wo + ow] = acc;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(TPB) upsample_q4_kernel(const float4 *x, float4 *y, unsigned total, int H, int W,
                                                           int OH, int OW, FastDiv divOW, FastDiv divOH,
                                                           FastDiv divFh, FastDiv divFw) {
@@ -801,6 +846,16 @@ int pl_pool2d_q4_f32(pl_ctx *ctx, const float *xq, float *yq, int N, int C, int 
     if (!total) return PL_OK;
     PL_REQUIRE(total < (1ull << 30) && NC * H * W < (1ull << 30), PL_EUNSUPPORTED, "pool: tensor too large");
     CtxGuard g(ctx);
+    if (mode == 0 && kh == 3 && kw == 3 && sh == 2 && sw == 2 && pt == 1 && pl == 1 && !getenv("PLANER_HIP_POOL_GENERIC") &&
+        (size_t)N * ((C + 3) / 4) * H * W < (1ull << 27)) {
+        const int Hb = (Ho + 1) / 2;
+        const size_t blocks = total / ((size_t)Ho * Wo) * Hb * Wo;
+        maxpool_q4_k3s2p1_2x1<<<stream_grid(ctx, blocks), TPB, 0, ctx->stream>>>((const float4 *)xq, (float4 *)yq, (unsigned)blocks, H, W,
+                                                                                Ho, Wo, Hb, (unsigned)((size_t)N * ((C + 3) / 4) * H * W * 16),
+                                                                                FastDiv(Wo), FastDiv(Hb));
+        PL_LAUNCH_CHECK();
+        return PL_OK;
+    }
     const unsigned grid = stream_grid(ctx, total);
     if (mode == 0)
         pool2d_q4_kernel<0><<<grid, TPB, 0, ctx->stream>>>((const float4 *)xq, (float4 *)yq, (unsigned)total, H, W, Ho, Wo,

@@ -389,3 +389,17 @@ def test_w1d4_persistent_variant_matches_oracle(pa, monkeypatch):
                        pa.asarray(sh), q4.to_q4(pa.asarray(res)), pads=[1, 1, 1, 1], act=1, w_layout=8)
         assert ctx.last_conv_plan().startswith("w1d4pc"), ctx.last_conv_plan()
         assert_close(q4.from_q4(yq).get(), ref, RTOL, "w1d4pc %s" % ((n, c, h, w, co),))
+
+
+def test_q4_stem_maxpool_block_kernel_is_bit_exact(pa):
+    """maxpool_q4_k3s2p1_2x1 (a thread = two vertically adjacent outputs from one 5x3 window): odd / even extents, negative
+    inputs (zero padding and the -1e4 start of util.py:88,95 show), against the oracle and the NCHW kernel."""
+    from planer_amd import q4
+    rng = np.random.default_rng(9)
+    for shape in [(2, 8, 13, 15), (1, 5, 7, 9), (3, 4, 6, 6), (2, 64, 112, 112), (1, 3, 1, 1), (1, 4, 2, 5)]:
+        x = rng.standard_normal(shape).astype(np.float32)
+        x[0, 0] = -np.abs(x[0, 0]) - 0.5
+        yq = q4.MaxpoolQ4(q4.to_q4(pa.asarray(x)), (3, 3), (1, 1, 1, 1), (2, 2))
+        want = onp.maxpool(x, (3, 3), (1, 1, 1, 1), (2, 2))
+        np.testing.assert_array_equal(q4.from_q4(yq).get(), want)
+        np.testing.assert_array_equal(yq.get(), q4_host(want))
