@@ -1718,7 +1718,8 @@ int w1d_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const
     a.HoWo = H * W; a.HW = H * W;
     const size_t in_elems = (size_t)N * Cin * H * W, out_elems = (size_t)N * a.Coq * 4 * H * W;
     const size_t w_elems = (size_t)(f43 ? 6 : 4) * a.Qpad * Cout * 4;
-    PL_REQUIRE(in_elems < (1ull << 29) && out_elems < (1ull << 31) && w_elems < (1ull << 29) &&
+    // (output addressed through a 32-bit buffer offset in the F(4,3) kernels' epilogue: < 2 GiB)
+    PL_REQUIRE(in_elems < (1ull << 29) && out_elems < (1ull << 29) && w_elems < (1ull << 29) &&
                    (size_t)N * H * Tw < (1ull << 31), PL_EUNSUPPORTED, "winograd-1d: tensor too large");
     a.x_bytes = (int)(in_elems * 4); a.w_bytes = (int)(w_elems * 4);
     a.divHoWo = FastDiv(H * Tw); a.divWo = FastDiv(Tw); a.divCpt = FastDiv(a.cqg);

@@ -384,26 +384,37 @@ conv_w1d4_kernel(const ConvArgs p) {
     }
     if (k <= last) step(P0{}, k);
 
-    // ---- epilogue: y = A^T m per lane (4 pixels of one output row), fused tail, b128 stores ----
-    const int jc = col0 + wn * 32 + l31;
-    if (jc >= p.cols) return;
+    // ---- epilogue: y = A^T m per lane (4 pixels of one output row), fused tail, b128 stores.  Branch-free:
+    //      the residual is fetched and y is written through buffer descriptors whose range check drops what falls
+    //      outside the tensor (a predicated plain load / store costs a branch and a wait per element), and all 16
+    //      residual quads of the lane are in flight before the first is used -- one memory round trip per tile ----
+    const int jc = min(col0 + wn * 32 + l31, p.cols - 1);
+    const bool live = col0 + wn * 32 + l31 < p.cols;
     unsigned n, rem, h, t;
     p.divHoWo.divmod((unsigned)jc, n, rem);
     p.divWo.divmod(rem, h, t);
     const int wo = 4 * (int)t;
-    float4 *y4 = reinterpret_cast<float4 *>(p.y);
-    const float4 *res4 = reinterpret_cast<const float4 *>(p.ep.res);
     const float4 *prm4 = reinterpret_cast<const float4 *>(prm);
+    const unsigned out_bytes = (unsigned)p.N * (unsigned)p.Coq * (unsigned)(p.H * p.W) * 16u;
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.ep.res), 0, p.ep.res ? out_bytes : 0u, 0x00020000);
     const unsigned obase = (n * (unsigned)p.Coq * (unsigned)p.H + h) * (unsigned)p.W + (unsigned)wo;
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    int off[4][4];
+    float4 rs[4][4];
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) {
         const int Rt = wm * 32 + 8 * rq + 4 * lhi;
-        if (m0 + Rt >= p.Cout) continue;
         const unsigned idx = obase + (unsigned)((m0 + Rt) >> 2) * (unsigned)(p.H * p.W);
-        float4 rs[4];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) rs[b] = (res4 && wo + b < p.W) ? res4[idx + b] : z;
+        for (int b = 0; b < 4; ++b) {
+            off[rq][b] = (live && m0 + Rt < p.Cout && wo + b < p.W) ? (int)((idx + b) << 4) : OOB;
+            rs[rq][b] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off[rq][b], 0, 0));
+        }
+    }
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+        const int Rt = wm * 32 + 8 * rq + 4 * lhi;
         const float4 bias = prm4[Rt >> 2], scale = prm4[(C::BM + Rt) >> 2], shift = prm4[(2 * C::BM + Rt) >> 2];
         const int valid = p.Cout - (m0 + Rt);
         float o[4][4];                                       // [pixel][channel lane]
@@ -418,10 +429,11 @@ conv_w1d4_kernel(const ConvArgs p) {
             o[3][e] = __builtin_fmaf(8.f, tt, qs) + m5;
         }
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
-            if (wo + b < p.W)
-                y4[idx + b] = apply_epilogue4(p.ep, bias, scale, shift, rs[b], valid,
-                                              make_float4(o[b][0], o[b][1], o[b][2], o[b][3]));
+        for (int b = 0; b < 4; ++b) {
+            const float4 v = apply_epilogue4(p.ep, bias, scale, shift, rs[rq][b], valid, make_float4(o[b][0], o[b][1], o[b][2], o[b][3]));
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
+                                                   yrsrc, off[rq][b], 0, 0);
+        }
     }
 }
 
