@@ -185,6 +185,9 @@ def main():
                          "conv2 = config 2's single Conv2d 3->64 on (8,3,224,224)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive net(x_host) leg")
     ap.add_argument("--per-layer-csv", help="write the per-layer table (HIP events) to this file")
+    ap.add_argument("--settle-ms", type=float, default=300.0,
+                    help="run the step loop untimed for this long before the W warm-up steps, so the timed region sees "
+                         "steady-state clocks (DVFS ramps over ~100 ms; the K timed steps last ~15-35 ms)")
     args = ap.parse_args()
 
     import planer_amd
@@ -248,6 +251,11 @@ def main():
         plan.join()                            # side streams -> main stream
         ctx.synchronize()
 
+    t_settle = time.perf_counter()
+    while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:      # untimed: clocks and caches reach steady state
+        for _ in range(10):
+            step()
+        sync()
     elapsed = dist.timed_steps(comm, step, sync, args.steps, args.warmup)
     ms_per_step = elapsed / args.steps * 1e3
     value = global_batch * args.steps / elapsed
@@ -428,7 +436,8 @@ def main():
                       "streams": plan.streams,
                       "pcie_inclusive_images_per_sec": None if e2e is None else round(e2e, 1),
                       "device": ctx.arch, "cu_count": ctx.cu_count,
-                      "tune_cache": os.environ.get("PLANER_HIP_TUNE_CACHE"),
+                      "tune_cache": os.environ.get("PLANER_HIP_TUNE_CACHE"), "settle_ms": args.settle_ms,
+                      "timed_region_ms": round(elapsed * 1e3, 3),
                       "algos": algo_list},
            "roofline": roofline, "roofline_hbm": hbm,
            "per_layer": [{"layer": r["layer"], "kernel": r["kernel"].split(" ")[0], "us": round(r["ms"] * 1e3, 2),
