@@ -59,6 +59,7 @@ struct ConvArgs {
     // channel-quad (Q4) layout only: input quads per group / in total, output quads in total,
     // k-quads per group (real / padded), and whether a BK chunk always sits inside one filter tap
     int cqg, Cq, Coq, Qtot, Qpad, uni;
+    int y_bytes;      // Q4 output size in bytes when it is under 2 GiB (buffer-addressed tail), else 0
     int rp_rq;        // > 0: row-packed small-Cin input (x = padded NHWC, H/W = padded extents); quads per filter row
     FastDiv divKhw, divKw, divHoWo, divWo, divMt, divCpt;
     Epilogue ep;
@@ -1156,6 +1157,7 @@ int conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const
     }
     a.cols = N * Ho * Wo;
     a.HoWo = Ho * Wo; a.HW = H * W;
+    a.y_bytes = ((layout == 2 || layout == 6) && (size_t)N * a.Coq * Ho * Wo * 16 < (1ull << 31)) ? (int)((size_t)N * a.Coq * Ho * Wo * 16) : 0;
     a.x_bytes = (int)(in_elems * 4); a.w_bytes = (int)(w_elems * 4);
     a.divKhw = FastDiv(kh * kw); a.divKw = FastDiv(kw);
     a.divHoWo = FastDiv(a.HoWo); a.divWo = FastDiv(Wo);

@@ -123,6 +123,54 @@ __device__ __forceinline__ void store_tile_q4(const ConvArgs &p, const TileCoord
     float4 *y4 = reinterpret_cast<float4 *>(p.y);
     const float4 *res4 = reinterpret_cast<const float4 *>(p.ep.res);
     const float4 *prm4 = reinterpret_cast<const float4 *>(prm);
+    if (p.y_bytes) {
+        // Branch-free tail (outputs under 2 GiB): residual and y go through buffer descriptors whose range check
+        // drops lanes outside the tensor -- a predicated plain load / store costs a branch and a wait per element.
+        // All residual quads of a 32-row block are in flight before the first is used.
+        constexpr int OOB = (int)0x80000000;
+        const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (unsigned)p.y_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(p.ep.res), 0, p.ep.res ? (unsigned)p.y_bytes : 0u, 0x00020000);
+        unsigned ob[TN];
+        bool ck[TN];
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int jc = tc.col0 + wn * WTN + b * 32 + l31;
+            ck[b] = jc < p.cols;
+            unsigned n, pix;
+            p.divHoWo.divmod((unsigned)(ck[b] ? jc : 0), n, pix);
+            ob[b] = (n * (unsigned)p.Coq + (unsigned)(((int)tc.g * p.cout_g + tc.m0 + wm * WTM) >> 2)) * (unsigned)p.HoWo + pix;
+        }
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            int off[4][TN];
+            float4 rs[4][TN];
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    const int Rl = a * 32 + 8 * rq + 4 * lhi;
+                    const bool ok = ck[b] && tc.m0 + wm * WTM + Rl < p.cout_g;
+                    off[rq][b] = ok ? (int)((ob[b] + (unsigned)(Rl >> 2) * (unsigned)p.HoWo) << 4) : OOB;
+                    rs[rq][b] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off[rq][b], 0, 0));
+                }
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int Rt = wm * WTM + a * 32 + 8 * rq + 4 * lhi;
+                const float4 bias = prm4[Rt >> 2], scale = prm4[(BM + Rt) >> 2], shift = prm4[(2 * BM + Rt) >> 2];
+                const int valid = p.cout_g - (tc.m0 + Rt);
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    const float4 v =
+                        make_float4(acc[a][b][4 * rq], acc[a][b][4 * rq + 1], acc[a][b][4 * rq + 2], acc[a][b][4 * rq + 3]);
+                    const float4 o = apply_epilogue4(p.ep, bias, scale, shift, rs[rq][b], valid, v);
+                    __builtin_amdgcn_raw_buffer_store_b128(
+                        __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o), yrsrc, off[rq][b], 0, 0);
+                }
+            }
+        }
+        return;
+    }
     // quad index of (first row of the wave tile, this lane's pixel); < 2^29 (checked by the host)
     unsigned obase[TN];
     bool cok[TN];
