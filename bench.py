@@ -375,12 +375,14 @@ def main():
     tpath = os.path.join(ROOT, "profiles", PROFILE_TAG + "_hbm_traffic.json")
     if os.path.exists(tpath):
         try:
-            want_k = re.search(r"\((\w+)\)", dom_name)
-            for r in json.load(open(tpath)):
-                if want_k and want_k.group(1) in r["kernel"] and "reduce" not in r["kernel"]:
-                    traffic = round(r["read_mb_per_launch_corrected"] * 1e6 + r["write_kb_per_launch"] * 1e3)
-                    traffic_src = "profiles/%s_hbm_traffic.json (%s, %d launches)" % (PROFILE_TAG, r["kernel"][:60], r["launches"])
-                    break
+            tok = re.findall(r"(\w+_kernel)", dom_name)[-1]            # the family's MFMA kernel
+            fam = [r for r in json.load(open(tpath)) if tok in r["kernel"] and "reduce" not in r["kernel"]]
+            n_l = sum(r["launches"] for r in fam)
+            if n_l:
+                traffic = round(sum((r["read_mb_per_launch_corrected"] * 1e6 + r["write_kb_per_launch"] * 1e3) * r["launches"]
+                                    for r in fam) / n_l)
+                traffic_src = ("profiles/%s_hbm_traffic.json: HBM bytes per launch of %s (launch-weighted mean over its %d "
+                               "tile configurations, %d launches in the PMC run of this command)" % (PROFILE_TAG, tok, len(fam), n_l))
         except Exception:
             pass
     roofline = {

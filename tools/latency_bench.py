@@ -14,6 +14,7 @@ size = 416 if which == "yolov3" else 224
 x = planer_amd.asarray(np.random.default_rng(1).standard_normal((batch, 3, size, size)).astype(np.float32), ctx=ctx)
 net = planer_amd.from_graph(g, b)
 net(x); ctx.synchronize()
+ctx.save_tune_cache(); net.save_algo_cache()
 ts = []
 for _ in range(50):
     t0 = time.perf_counter()
