@@ -121,7 +121,7 @@ def per_layer(out, tag, trace, bench):
         for frag in expected_kernels(a):
             seq.append((a["layer"], frag))
         if a["layer"].startswith("stem"):
-            seq.append(("maxpool", "pool2d_q4_kernel"))
+            seq.append(("maxpool", "pool"))          # pool2d_q4_kernel or maxpool_q4_k3s2p1_2x1
         if a["layer"].startswith("l41b"):
             seq.append(("gap", "gap_q4_kernel"))
     rows = [r for r in csv.DictReader(open(trace)) if "rocclr" not in r["Kernel_Name"]]
