@@ -1,0 +1,75 @@
+"""GPU: do the launch plans (tile configuration, occupancy pin) that win in ISOLATION also win inside the
+three-stream throughput plan?  Coordinate descent over the tune-cache lines of the shapes ResNet-18 runs at batch 32:
+for each, try other tile configs / occupancy pins, reload the cache, rebuild the pipelined plan, measure images/s.
+Writes the improved cache to argv[1] (default /tmp/plan_search_cache.txt)."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import planer_amd
+from planer_amd.irgen import resnet18
+
+out_path = sys.argv[1] if len(sys.argv) > 1 else "/tmp/plan_search_cache.txt"
+base_cache = "/tmp/plan_search_base.txt"
+os.environ["PLANER_HIP_TUNE_CACHE"] = base_cache
+ctx = planer_amd.hip.context()
+g, blob = resnet18.build()
+xs = [planer_amd.asarray(np.random.default_rng(1 + i).standard_normal((32, 3, 224, 224)).astype(np.float32), ctx=ctx) for i in range(2)]
+algo_keep = {}
+
+
+def measure(steps=120):
+    net = planer_amd.from_graph(g, blob)
+    net.streams = "pipe3"
+    if algo_keep:
+        net._algo_loaded, net._algo = True, dict(algo_keep)
+    plan = net.compile(xs[0], mode="throughput")
+    algo_keep.update(net._algo)
+    best = 0.0
+    for rep in range(3):
+        for i in range(10):
+            plan.feed([xs[i & 1]]); plan.launch(join=False)
+        plan.join(); ctx.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            plan.feed([xs[i & 1]]); plan.launch(join=False)
+        plan.join(); ctx.synchronize()
+        best = max(best, 32 * steps / (time.perf_counter() - t0))
+    return best, plan
+
+
+base, plan = measure()
+ctx.save_tune_cache(base_cache)
+used = set(a["plan"].split()[0].strip("wino4[") for a in plan.algos)
+lines = [l.split() for l in open(base_cache).read().strip().splitlines()]
+# the lines this net's Q4 plan really uses: layout 2 / 6 entries at batch 32 or the 36-group GEMMs
+cand = [i for i, l in enumerate(lines) if l[0] in ("2", "6") and (l[1] == "32" or l[14] == "36")]
+print("isolated plans: %.0f img/s; %d plan lines to vary" % (base, len(cand)), flush=True)
+cur, cur_rate = [list(l) for l in lines], base
+CFGS = ["q64x64x16", "q64x64x32", "q128x32x32", "q128x64x16", "q64x128x16", "q32x128x32"]
+for i in cand:
+    l = cur[i]
+    label = "N%s C%s %sx%s->%s k%s s%s g%s" % (l[1], l[2], l[3], l[4], l[5], l[6], l[8], l[14])
+    for cfg in [l[18]] + [c for c in CFGS if c != l[18]]:
+        for occ in ("0", "2", "3"):
+            if cfg == lines[i][18] and occ == lines[i][21]:
+                continue
+            if cfg != l[18] and l[20] != "1":
+                continue                                     # keep split-K plans on their tile shape
+            trial = [list(x) for x in cur]
+            trial[i][18], trial[i][21] = cfg, occ
+            if cfg != l[18]:
+                trial[i][19] = "1000000"                      # all tiles data-parallel
+            open(out_path + ".trial", "w").write("\n".join(" ".join(x) for x in trial) + "\n")
+            ctx.load_tune_cache(out_path + ".trial")
+            try:
+                rate, _ = measure()
+            except Exception as e:
+                print("  %s %s occ %s failed: %s" % (label, cfg, occ, str(e)[:60])); continue
+            mark = ""
+            if rate > cur_rate * 1.004:
+                cur, cur_rate, mark = trial, rate, "  <-- kept"
+            print("  %-34s %-11s occ %s: %.0f img/s (%+.1f%%)%s" % (label, cfg, occ, rate, 100 * (rate / base - 1), mark), flush=True)
+    ctx.load_tune_cache(out_path + ".trial") if False else None
+    open(out_path, "w").write("\n".join(" ".join(x) for x in cur) + "\n")
+    ctx.load_tune_cache(out_path)
+print("after search: %.0f img/s (%+.1f%% over the isolated plans)" % (cur_rate, 100 * (cur_rate / base - 1)))
