@@ -302,7 +302,22 @@ int pl_strided_map_f32(pl_ctx *ctx, const float *x, float *y, int ndim, const in
  * pl_cast:        layer.Cast between 0 float32, 1 int32, 2 int64, 3 bool (numpy astype: truncation, != 0).
  * pl_gather_f32:  layer.Gather, np.take(x, idx, axis) on x viewed (outer, axis_len, inner); idx int32, negatives wrap.
  * pl_erf_lut_f32: layer.Erf -- clamps x IN PLACE like the reference and looks y up in its 1025-entry table `lut`.
- * pl_instancenorm_f32: layer.InstanceNormalization on (rows = N*C, inner) IN PLACE, scale/bias per channel. */
+ * pl_instancenorm_f32: layer.InstanceNormalization on (rows = N*C, inner) IN PLACE, scale/bias per channel.
+ * pl_scatter_rows_f32: the device side of layer.Scatternd (layer.py:208-212): dst row dst_row[j] (rows of
+ *                 row_len floats) = src row src_row[j]; the caller resolves index tuples to rows and keeps
+ *                 only the last write to each row (the reference applies updates in order).
+ * pl_nonzero_count / pl_nonzero_write: layer.NonZero (layer.py:230) = np.array(np.nonzero(x)) in two steps,
+ *                 because the result's shape depends on the data: _count fills `scratch`
+ *                 (ceil(n / PL_NONZERO_BLOCK) + 1 int64, device) and returns the number of non-zero elements in
+ *                 *total (host; SYNCHRONISES the stream); _write fills out (ndim x total, int64, row-major
+ *                 coordinates in ascending flat order).  elem_type as pl_cast.
+ * pl_topk_f32:    layer.TopK (layer.py:234-239) on x viewed (outer, n, inner) along the middle axis: values /
+ *                 int64 indices (outer, k, inner).  largest = 1: the k greatest, descending; largest = 0: k
+ *                 copies of the smallest (the reference's index list is arange(k)*0).  NaN sorts last like
+ *                 numpy; ties by ascending index (numpy leaves them unspecified).
+ * pl_lstm_cell_f32: one time step of util.lstm (util.py:109-118) after the GEMMs: gates_x = x_t W^T,
+ *                 gates_h = h R^T, both (N, 4H) in ONNX i|o|f|c order, bias (8H) = Wb | Rb; writes h, c (N, H). */
+#define PL_NONZERO_BLOCK 2048
 int pl_compare_f32(pl_ctx *ctx, const float *a, const float *b, unsigned char *y, size_t n, int op, int a_one, int b_one);
 int pl_where_f32(pl_ctx *ctx, const unsigned char *mask, const float *a, const float *b, float *y, size_t n,
                  int a_one, int b_one);
@@ -311,6 +326,15 @@ int pl_gather_f32(pl_ctx *ctx, const float *x, const int *idx, float *y, int out
 int pl_erf_lut_f32(pl_ctx *ctx, float *x, const float *lut, float *y, size_t n);
 int pl_instancenorm_f32(pl_ctx *ctx, float *x, const float *scale, const float *bias, int rows, int C, int inner,
                         double eps);
+int pl_scatter_rows_f32(pl_ctx *ctx, float *dst, const long long *dst_row, const float *src, const int *src_row,
+                        int n_rows, int row_len);
+int pl_nonzero_count(pl_ctx *ctx, const void *x, size_t n, int elem_type, long long *scratch, long long *total);
+int pl_nonzero_write(pl_ctx *ctx, const void *x, size_t n, int elem_type, const long long *scratch,
+                     const long long *shape, int ndim, long long *out, long long total);
+int pl_topk_f32(pl_ctx *ctx, const float *x, int outer, int n, int inner, int k, int largest, float *values,
+                long long *indices);
+int pl_lstm_cell_f32(pl_ctx *ctx, const float *gates_x, const float *gates_h, const float *bias, const float *c_prev,
+                     float *h, float *c, int N, int H);
 /* ---- tiled large-image inference: the device side of util.tile (util.py:291-348) ----
  * pl_resize_hwc_f32: util.resize (util.py:253-269) on an H x W x C image; ra/rs (OH entries) and
  * ca/cs (OW entries) are the integer sample rows/columns and their fractions, device arrays

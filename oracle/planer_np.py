@@ -386,6 +386,35 @@ def erf(x):
     return np.array(_ERF_LUT, x.dtype)[x.astype("int16")]
 
 
+def lstm(X, W, R, B=0, sequence_lens=0, initial_h=0, initial_c=0, hidden_size=None, direction="forward"):
+    """layer.LSTM (layer.py:36-42) + util.lstm (util.py:102-119).  X (L, N, D); per direction W (4H, D),
+    R (4H, H), B (8H) = Wb | Rb, gates in ONNX order i, o, f, c.  sequence_lens is ignored; Y is
+    (L, dirs, N, H); the returned H is (N, H) and C is (1, N, H) (the split keeps a leading 1), both of the
+    LAST direction only -- the reference's shapes."""
+    order = {"forward": [1], "reverse": [-1], "bidirectional": [1, -1]}[direction]
+    L, N, _ = X.shape
+    H = R.shape[-1]
+    Y = np.zeros((L, len(order), N, H), dtype=X.dtype)
+
+    def sigm(v):
+        return 1 / (np.exp(-v) + 1)
+
+    h = c = None
+    for k, step in enumerate(order):
+        h, c = initial_h[k], initial_c[k]
+        wb, rb = B[k][:4 * H], B[k][4 * H:]
+        for t in range(L)[::step]:
+            g = X[t] @ W[k].T
+            g = g + h @ R[k].T
+            g = g + wb
+            g = (g + rb)[None]
+            gi, go, gf, gc = g[..., :H], g[..., H:2 * H], g[..., 2 * H:3 * H], g[..., 3 * H:]
+            c = sigm(gf) * c + sigm(gi) * np.tanh(gc)
+            h = (sigm(go) * np.tanh(c))[0]
+            Y[t, k] = h
+    return Y, h, c
+
+
 def scatternd(data, indices, updates):
     """layer.Scatternd (layer.py:208-212)"""
     data = data.copy()
@@ -407,7 +436,7 @@ OPS = {"shape": lambda x: np.array(x.shape), "gather": lambda x, idx, axis=0: np
        "range": lambda start, end, delta: np.arange(int(start), int(end), int(delta)),
        "equal": lambda a, b: np.equal(a, b), "greater": lambda a, b: np.greater(a, b), "greaterorequal": lambda a, b: a >= b,
        "where": lambda m, a, b: np.where(m, a, b), "nonzero": lambda x: np.array(np.nonzero(x)),
-       "scatternd": scatternd, "topk": topk, "erf": erf, "instancenormalization": instancenorm,
+       "scatternd": scatternd, "topk": topk, "lstm": lstm, "erf": erf, "instancenormalization": instancenorm,
        "slice": slice_, "pad": pad, "tile": lambda x, repeat: np.tile(x, repeat.tolist()), "expand": expand,
        "split": split, "convtranspose": convtranspose2d,
        "sub": sub, "mul": mul, "div": div, "pow": power, "exp": lambda x: np.exp(x),

@@ -6,13 +6,14 @@ the reference itself (and in oracle/ for tests), never in this package.
 """
 import ctypes
 import os
-from ctypes import (POINTER, byref, c_char_p, c_double, c_float, c_int,
+from ctypes import (POINTER, byref, c_char_p, c_double, c_float, c_int, c_longlong,
                     c_size_t, c_void_p)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libplaner_hip.so")
 
 PL_OK, PL_EINVAL, PL_EUNSUPPORTED, PL_ENOMEM, PL_EHIP, PL_ERCCL = range(6)
+NONZERO_BLOCK = 2048          # include/planer_hip.h PL_NONZERO_BLOCK
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 ACT_RES_AFTER = 16
 UNIQUE_ID_BYTES = 128
@@ -109,6 +110,11 @@ SIGNATURES = {
     "pl_gather_f32": [_P, _P, _P, _P, _I, _I, _I, _I],
     "pl_erf_lut_f32": [_P, _P, _P, _P, _Z],
     "pl_instancenorm_f32": [_P, _P, _P, _P, _I, _I, _I, c_double],
+    "pl_scatter_rows_f32": [_P, _P, _P, _P, _P, _I, _I],
+    "pl_nonzero_count": [_P, _P, _Z, _I, _P, _P],
+    "pl_nonzero_write": [_P, _P, _Z, _I, _P, _P, _I, _P, c_longlong],
+    "pl_topk_f32": [_P, _P, _I, _I, _I, _I, _I, _P, _P],
+    "pl_lstm_cell_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I],
     "pl_resize_hwc_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "pl_tile_accumulate_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I],
     "pl_tile_normalise_f32": [_P, _P, _P, _I, _I, _I],
@@ -127,6 +133,11 @@ _lib = None
 
 class HipBackendError(RuntimeError):
     pass
+
+
+class NotCapturable(ValueError):
+    """An operator needed a host round trip (upload of a host-computed index list, a data-dependent output
+    shape) while the forward pass was being captured into a hipGraph: the net runs eagerly instead."""
 
 
 def load(path=None):
@@ -155,7 +166,7 @@ def check(rc):
     msg = load().pl_last_error()
     msg = msg.decode() if msg else "status %d" % rc
     if rc == PL_EINVAL:
-        raise ValueError(msg)
+        raise (NotCapturable if "during capture" in msg else ValueError)(msg)
     if rc == PL_EUNSUPPORTED:
         raise NotImplementedError(msg)
     if rc == PL_ENOMEM:
@@ -167,5 +178,5 @@ def call(name, *args):
     check(getattr(load(), name)(*args))
 
 
-__all__ = ["load", "check", "call", "HipBackendError", "SIGNATURES", "LIB_PATH",
+__all__ = ["load", "check", "call", "HipBackendError", "NotCapturable", "SIGNATURES", "LIB_PATH",
            "byref", "c_void_p", "c_int", "c_size_t", "c_float"]

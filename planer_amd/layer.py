@@ -9,9 +9,9 @@ names and defaults, and `wrap(f, kind)(**params)` gives the Layer objects
 shape tensors -- what `Shape` returns and what is derived from it -- are
 evaluated on their host mirrors, see "shape-domain tensors" below.)
 
-The four ops of the reference's table that need sorting, data-dependent
-shapes or a recurrence (`NOT_ON_DEVICE`) raise NotImplementedError instead of
-silently running on the CPU.
+Every kind of the reference's table (layer.py:262-281) is here; an unknown
+kind raises KeyError in Net like the reference (net.py:15), and inputs a kernel
+does not cover raise NotImplementedError instead of silently running on the CPU.
 """
 import numpy
 
@@ -834,6 +834,119 @@ def InstanceNormalization(x, s, bias, epsilon=1e-5):
     return x
 
 
+def Scatternd(data, indices, updates):
+    """layer.Scatternd (layer.py:208-212): a copy of `data` with data[tuple(indices[0, i])] = updates[0, i]
+    applied for i = 0, 1, ... -- only the first batch entry of indices / updates is used, as in the
+    reference.  The index tuples (a small integer tensor) are resolved on the host to row offsets, keeping
+    the LAST update of a row (the reference's loop order); the rows are written by one kernel."""
+    _f32(data, updates)
+    iv = numpy.asarray(_host_values(indices))
+    if iv.ndim < 2:
+        raise IndexError("scatternd: indices need at least 2 dimensions, got shape %s" % (iv.shape,))
+    idx = iv[0].reshape(len(iv[0]), -1).astype(numpy.int64)          # (n, k)
+    n, k = idx.shape
+    if k > data.ndim:
+        raise IndexError("too many indices for array: array is %d-dimensional, but %d were indexed" % (data.ndim, k))
+    dims = numpy.array(data.shape[:k], numpy.int64).reshape(1, k)
+    if n and ((idx < -dims) | (idx >= dims)).any():
+        raise IndexError("scatternd: index out of bounds for shape %s" % (data.shape[:k],))
+    idx = numpy.where(idx < 0, idx + dims, idx)
+    row_len = int(numpy.prod(data.shape[k:], dtype=numpy.int64))
+    out = data.copy()
+    if not n or not row_len:
+        return out
+    if updates.ndim < 2 or updates.shape[1] < n or tuple(updates.shape[2:]) != tuple(data.shape[k:]):
+        raise NotImplementedError("scatternd: updates must be (batch, n) + data.shape[%d:] (no broadcasting on the HIP path), "
+                                  "got %s for data %s" % (k, updates.shape, data.shape))
+    rows = numpy.ravel_multi_index(tuple(idx.T), tuple(data.shape[:k])).astype(numpy.int64) if k else numpy.zeros(n, numpy.int64)
+    last = {}
+    for i, r in enumerate(rows.tolist()):
+        last[r] = i                                                   # later updates overwrite earlier ones
+    dst = numpy.fromiter(last.keys(), numpy.int64, len(last))
+    src = numpy.fromiter(last.values(), numpy.int32, len(last))
+    d_dst, d_src = asarray(dst, ctx=data.ctx), asarray(src, ctx=data.ctx)
+    _lib.call("pl_scatter_rows_f32", data.ctx.handle, out.ptr, d_dst.ptr, updates.ptr, d_src.ptr, len(dst), row_len)
+    return out
+
+
+def NonZero(x):
+    """layer.NonZero (layer.py:230): np.array(np.nonzero(x)) -- (ndim, count) int64 coordinates in row-major
+    order.  The count decides the output's shape, so this op waits for the stream once (4 + 4 bytes back)."""
+    if _shape_domain([x]):
+        return _mirrored(numpy.array(numpy.nonzero(x.host)), x.ctx)
+    if not isinstance(x, DeviceArray):
+        raise TypeError("expected DeviceArray, got %s (use planer_amd.asarray)" % type(x).__name__)
+    code = _CAST_CODES.get(str(x.dtype))
+    if code is None:
+        raise NotImplementedError("nonzero of %s is not on the HIP path (float32 / int32 / int64 / bool)" % x.dtype)
+    if not 1 <= x.ndim <= 8:
+        raise NotImplementedError("nonzero: 1 to 8 dimensions on the HIP path, got %d" % x.ndim)
+    n = x.size
+    scratch = empty((n + _lib.NONZERO_BLOCK - 1) // _lib.NONZERO_BLOCK + 1, numpy.int64, ctx=x.ctx)
+    total = _lib.c_longlong(0)
+    _lib.call("pl_nonzero_count", x.ctx.handle, x.ptr, n, code, scratch.ptr, _lib.byref(total))
+    out = empty((x.ndim, int(total.value)), numpy.int64, ctx=x.ctx)
+    if total.value:
+        shape = (_lib.c_longlong * x.ndim)(*x.shape)
+        _lib.call("pl_nonzero_write", x.ctx.handle, x.ptr, n, code, scratch.ptr, shape, x.ndim, out.ptr, total.value)
+    return out
+
+
+def TopK(x, k, axis=-1, largest=1, sorted=1):
+    """layer.TopK (layer.py:234-239): (values, int64 indices) of take(argsort(x, axis), arange(k) * -largest -
+    (largest > 0), axis).  largest = 1: the k greatest, descending.  largest = 0: the reference's index list
+    is k zeros, i.e. k copies of the smallest element -- reproduced.  One workgroup sorts a row in LDS (up to
+    16384 elements; longer rows take k selection rounds).  Equal values: numpy's sort leaves their order
+    unspecified, here the lower index sorts first."""
+    _f32(x)
+    kk = int(numpy.asarray(_host_values(k)).reshape(-1)[0])
+    if largest not in (0, 1):
+        raise NotImplementedError("topk: largest must be 0 or 1 on the HIP path")
+    if not -x.ndim <= axis < x.ndim:
+        raise ValueError("axis %d is out of bounds for array of dimension %d" % (axis, x.ndim))
+    axis = axis + x.ndim if axis < 0 else axis
+    n = x.shape[axis]
+    if kk < 0 or kk > n:
+        raise IndexError("topk: k = %d is out of bounds for axis %d with size %d" % (kk, axis, n))
+    outer = int(numpy.prod(x.shape[:axis], dtype=numpy.int64))
+    inner = int(numpy.prod(x.shape[axis + 1:], dtype=numpy.int64))
+    shape = x.shape[:axis] + (kk,) + x.shape[axis + 1:]
+    vals, idx = empty(shape, ctx=x.ctx), empty(shape, numpy.int64, ctx=x.ctx)
+    if vals.size:
+        _lib.call("pl_topk_f32", x.ctx.handle, x.ptr, outer, n, inner, kk, int(largest), vals.ptr, idx.ptr)
+    return vals, idx
+
+
+def LSTM(X, W, R, B=0, sequence_lens=0, initial_h=0, initial_c=0, hidden_size=None, direction="forward"):
+    """layer.LSTM (layer.py:36-42) over util.lstm (util.py:102-119): X (L, N, D), W (dirs, 4H, D), R (dirs, 4H, H),
+    B (dirs, 8H), initial_h / initial_c (dirs, N, H); gates in ONNX order i, o, f, c; sequence_lens is ignored
+    there too.  x_t W^T for every step is ONE MFMA GEMM per direction; a step is then h R^T (GEMM) + the cell
+    kernel.  Returns (Y (L, dirs, N, H), H, C) with the reference's shapes: H (N, H) and C (1, N, H) of the
+    LAST direction only."""
+    dirs = {"forward": [1], "reverse": [-1], "bidirectional": [1, -1]}[direction]
+    _f32(X, W, R)
+    for name, t in (("B", B), ("initial_h", initial_h), ("initial_c", initial_c)):
+        if not isinstance(t, DeviceArray):
+            raise TypeError("lstm: %s must be given (the reference indexes it per direction, layer.py:41)" % name)
+    _f32(B, initial_h, initial_c)
+    L, N, D = X.shape
+    H = R.shape[-1]
+    from .hip import zeros
+    Y = zeros((L, len(dirs), N, H), ctx=X.ctx)
+    X2 = X.reshape(L * N, D)
+    ht = ct = None
+    for i, d in enumerate(dirs):
+        gx = Dense(X2, W[i], None) if L else None                   # (L*N, 4H): every step's x_t W^T
+        ht, ct = initial_h[i], initial_c[i]
+        for t in list(range(L))[::d]:
+            gh = Dense(ht, R[i], None)
+            h_new, c_new = Y[t][i], empty((1, N, H), ctx=X.ctx)
+            _lib.call("pl_lstm_cell_f32", X.ctx.handle, gx.rows(t * N, (t + 1) * N).ptr, gh.ptr, B[i].ptr, ct.ptr, h_new.ptr,
+                      c_new.ptr, N, H)
+            ht, ct = h_new, c_new
+    return Y, ht.copy(), ct
+
+
 def _missing(kind):
     def op(*a, **k):
         raise NotImplementedError(
@@ -843,8 +956,8 @@ def _missing(kind):
     return op
 
 
-# sorting / data-dependent shapes / recurrences: not on the device path
-NOT_ON_DEVICE = ["lstm", "scatternd", "nonzero", "topk"]
+# every kind of the reference's layer_map (layer.py:262-281) has a device implementation
+NOT_ON_DEVICE = []
 
 layer_map = {"dense": Dense, "conv": Conv2d, "relu": ReLU, "leakyrelu": LeakyReLU,
              "batchnorm": BatchNorm, "flatten": Flatten, "sigmoid": Sigmoid,
@@ -863,6 +976,7 @@ layer_map = {"dense": Dense, "conv": Conv2d, "relu": ReLU, "leakyrelu": LeakyReL
              "shape": Shape, "const": Const, "constantofshape": ConstantofShape, "range": Range, "cast": Cast,
              "equal": Equal, "greater": Greater, "greaterorequal": GreaterOrEqual, "where": Where, "gather": Gather,
              "erf": Erf, "instancenormalization": InstanceNormalization,
+             "scatternd": Scatternd, "nonzero": NonZero, "topk": TopK, "lstm": LSTM,
              # plan-compiler internal
              "conv_fused": ConvFused}
 # integer shape arithmetic: the same kinds, evaluated on host mirrors when no activation is involved

@@ -708,7 +708,15 @@ class Net:
             x = [hip.asarray(i, ctx=self.ctx) if b else i for i, b in zip(x, host)]
         graphable = (self.use_graph and not key.get("debug") and not self.profile
                      and all(isinstance(i, DeviceArray) for i in x))
-        rst = self._replay(list(x)) if graphable else self.forward(*x, **key)
+        if graphable:
+            try:
+                rst = self._replay(list(x))
+            except _lib.NotCapturable:
+                # post-processing graphs (Shape / NonZero / index uploads) need the host between kernels: same
+                # kernels, launched one by one from here on
+                self.use_graph = graphable = False
+        if not graphable:
+            rst = self.forward(*x, **key)
         if need:
             rst = tuple(i.get() for i in rst) if isinstance(rst, tuple) else rst.get()
         return rst[0] if len(rst) == 1 else rst

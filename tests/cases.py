@@ -150,6 +150,32 @@ def layer_cases():
                                                        _r(635, 6)], {"epsilon": 1e-5}))
     c.append(("concat_shape_tensors", "concat", [i64(2), i64(255), i64(13, 13)], {"axis": 0}))
     c.append(("mul_shape_tensors", "mul", [i64(13, 13), i64(2, 2)], {}))
+    # ---- sorting / data-dependent shapes / recurrence ----
+    sc = np.array([[[1, 2], [3, 0], [1, 2], [-1, -2]]], np.int64)          # row (1, 2) written twice: the last wins
+    c.append(("scatternd_rows", "scatternd", [_r(640, 4, 5, 6), sc, _r(641, 1, 4, 6)], {}))
+    c.append(("scatternd_elements", "scatternd", [_r(642, 3, 7), np.array([[[0, 0], [2, 6], [1, 3], [2, 6], [0, -1]]], np.int64),
+                                                  _r(643, 1, 5)], {}))
+    nz = _r(644, 3, 4, 50)
+    nz[np.abs(nz) < 0.8] = 0
+    c.append(("nonzero_f32", "nonzero", [nz], {}))
+    c.append(("nonzero_bool", "nonzero", [_r(645, 2, 2100) > 1.5], {}))
+    c.append(("nonzero_none", "nonzero", [np.zeros((2, 3, 4), np.float32)], {}))
+    c.append(("nonzero_i64_1d", "nonzero", [np.array([0, 3, 0, 0, -1, 7], np.int64)], {}))
+    c.append(("topk_last", "topk", [_r(646, 4, 50), np.array([5], np.int64)], {}))
+    c.append(("topk_axis1", "topk", [_r(647, 3, 20, 7), np.array([3], np.int64)], {"axis": 1}))
+    c.append(("topk_smallest_quirk", "topk", [_r(648, 3, 33), np.array([4], np.int64)], {"largest": 0}))
+    c.append(("topk_yolo_candidates", "topk", [_r(649, 2, 10647), np.array([100], np.int64)], {"axis": -1, "largest": 1, "sorted": 1}))
+    c.append(("topk_long_row", "topk", [_r(650, 20000), np.array([6], np.int64)], {}))
+    c.append(("topk_long_row_smallest", "topk", [_r(651, 17000), np.array([3], np.int64)], {"largest": 0}))
+    L_, N_, D_, H_ = 5, 3, 6, 8
+
+    def lstm_args(seed, dirs):
+        return [_r(seed, L_, N_, D_), _r(seed + 1, dirs, 4 * H_, D_, scale=0.4), _r(seed + 2, dirs, 4 * H_, H_, scale=0.4),
+                _r(seed + 3, dirs, 8 * H_, scale=0.2), np.full((N_,), L_, np.int64), _r(seed + 4, dirs, N_, H_, scale=0.5),
+                _r(seed + 5, dirs, N_, H_, scale=0.5)]
+    c.append(("lstm_forward", "lstm", lstm_args(660, 1), {"hidden_size": H_, "direction": "forward"}))
+    c.append(("lstm_reverse", "lstm", lstm_args(670, 1), {"hidden_size": H_, "direction": "reverse"}))
+    c.append(("lstm_bidirectional", "lstm", lstm_args(680, 2), {"hidden_size": H_, "direction": "bidirectional"}))
     return c
 
 

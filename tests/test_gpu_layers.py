@@ -51,7 +51,9 @@ EXACT = ["relu", "leakyrelu_0.1", "leakyrelu_default", "add", "batchnorm", "maxp
          "reducemax_axis0", "shape", "gather_axis0", "gather_axis2_neg_2d_idx", "gather_shape_scalar", "cast_f32_i64",
          "cast_i64_f32", "cast_f32_bool", "range", "equal", "greater_scalar", "greaterorequal", "equal_shape_tensors",
          "where", "where_scalar_rhs", "constantofshape_f32", "constantofshape_i64", "erf", "concat_shape_tensors",
-         "mul_shape_tensors"]
+         "mul_shape_tensors", "scatternd_rows", "scatternd_elements", "nonzero_f32", "nonzero_bool", "nonzero_none",
+         "nonzero_i64_1d", "topk_last", "topk_axis1", "topk_smallest_quirk", "topk_yolo_candidates", "topk_long_row",
+         "topk_long_row_smallest"]
 
 
 @pytest.mark.parametrize("name", EXACT)
@@ -240,11 +242,17 @@ def test_unsupported_inputs_fail_loudly(pa):
         pa.Conv2d(x, k, pads=[1, 1, 0, 0])
     with pytest.raises(NotImplementedError):
         pa.Maxpool(x, w=[2, 2], pads=[1, 0, 0, 0])
-    with pytest.raises(NotImplementedError):
-        pa.layer_map["lstm"](x)
-    for kind in ("topk", "nonzero", "scatternd"):      # sorting / data-dependent shapes: raise, never fall back
-        with pytest.raises(NotImplementedError):
-            pa.layer_map[kind](x)
+    with pytest.raises(TypeError):                    # the reference indexes B / initial_h / initial_c per direction
+        pa.layer_map["lstm"](x.reshape(4, 16, 4), x.reshape(1, 16, 16), x.reshape(1, 16, 16))
+    with pytest.raises(NotImplementedError):          # arange(k) * -largest only means something for 0 / 1
+        pa.layer_map["topk"](x, np.array([2]), largest=2)
+    with pytest.raises(IndexError):                   # np.take would raise too
+        pa.layer_map["topk"](x, np.array([9]))
+    with pytest.raises(IndexError):
+        pa.layer_map["scatternd"](x, np.array([[[0, 4]]]), pa.asarray(np.zeros((1, 1, 8, 8), np.float32)))
+    with pytest.raises(NotImplementedError):          # an update that would need broadcasting
+        pa.layer_map["scatternd"](x, np.array([[[0, 1]]]), pa.asarray(np.zeros((1, 1, 1, 8), np.float32)))
+    assert pa.layer.NOT_ON_DEVICE == []
     with pytest.raises(ValueError):
         pa.Softmax(x, axis=4)
     with pytest.raises(NotImplementedError):          # stacks with different leading dimensions

@@ -199,3 +199,37 @@ def test_relu_mutates_its_input_like_the_reference(pa):
     r = pa.ReLU(d)
     assert r is d
     np.testing.assert_array_equal(d.get(), onp.relu(x.copy()))
+
+
+def test_postprocessing_flow_with_data_dependent_shapes(pa):
+    """conv -> sigmoid -> reshape -> TopK / Greater -> NonZero -> ScatterND in one flow (what an ONNX detection head
+    appends to the trunk): NonZero's output shape depends on the data, so the flow cannot live in a hipGraph --
+    the net must notice and launch the same kernels one by one, with the oracle's results."""
+    rng = np.random.default_rng(5)
+    inits = [("K", rng.standard_normal((12, 8, 1, 1)).astype(np.float32)), ("B", rng.standard_normal(12).astype(np.float32)),
+             ("shp", np.array([1, 12, -1], np.int64)), ("kk", np.array([5], np.int64)), ("thr", np.array([0.8], np.float32)),
+             ("sidx", np.array([[[0, 3], [0, 7], [0, 3]]], np.int64)), ("supd", rng.standard_normal((1, 3, 100)).astype(np.float32))]
+    graph = {"input": ["x"], "inits": [[n, list(a.shape), str(a.dtype)] for n, a in inits],
+             "layers": [["conv", "conv", {"group": 1, "strides": [1, 1], "dilations": [1, 1], "pads": [0, 0, 0, 0]}],
+                        ["sig", "sigmoid", {}], ["rs", "reshape", {}], ["topk", "topk", {"axis": -1, "largest": 1, "sorted": 1}],
+                        ["gt", "greater", {}], ["nz", "nonzero", {}], ["sc", "scatternd", {}], ["return", "return", {}]],
+             "flow": [[["x", "K", "B"], ["conv"], "c"], ["c", ["sig"], "s"], [["s", "shp"], ["rs"], "r"],
+                      [["r", "kk"], ["topk"], ["tv", "ti"]], [["r", "thr"], ["gt"], "m"], ["m", ["nz"], "nzi"],
+                      [["r", "sidx", "supd"], ["sc"], "scat"], [["tv", "ti", "nzi", "scat"], ["return"], "plrst"]]}
+    blob = np.concatenate([a.reshape(-1).view(np.uint8) for _, a in inits])
+    x = rng.standard_normal((1, 8, 10, 10)).astype(np.float32)
+    ref = onp.OracleNet()
+    ref.load_json(graph["input"], graph["inits"], graph["layers"], graph["flow"])
+    ref.load_weights(blob)
+    want = ref(x.copy())
+    net = pa.from_graph(graph, blob)
+    assert net.use_graph
+    for rnd in range(2):
+        got = net(x)
+        assert net.use_graph is False                      # noticed on the first call, eager from then on
+        assert len(got) == 4
+        assert_close(got[0], want[0], RTOL, "topk values")
+        np.testing.assert_array_equal(got[1], want[1])
+        assert got[2].dtype == np.int64 and got[2].shape == want[2].shape and want[2].shape[1] > 0
+        np.testing.assert_array_equal(got[2], want[2])
+        assert_close(got[3], want[3], RTOL, "scatternd")
