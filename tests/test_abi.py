@@ -69,3 +69,22 @@ def test_product_never_imports_oracle_or_torch():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+(oracle|torch)\b", src, flags=re.M), f
+
+
+# the kinds of the reference's operator table (layer.py:262-281), names only
+REFERENCE_KINDS = """add averagepool batchnorm cast clip concat const constantofshape conv convtranspose dense div equal erf
+exp expand flatten gap gather greater greaterorequal hardsigmoid identity instancenormalization leakyrelu log logsoftmax
+lstm matmul maxpool mul nonzero pad pow range reciprocal reducemax reducemean reducemin reducesum relu reshape resize
+return scatternd shape sigmoid slice softmax split sqrt squeeze sub tanh tile topk transpose unsqueeze upsample
+where""".split()
+
+
+def test_operator_table_covers_every_reference_kind():
+    from planer_amd import layer
+    assert len(REFERENCE_KINDS) == 58
+    assert [k for k in REFERENCE_KINDS if k not in layer.layer_map] == []
+    assert layer.NOT_ON_DEVICE == []
+    assert not any(f.__name__.startswith("missing_") for f in layer.layer_map.values())
+    # the importer's op table only emits kinds the operator table has
+    from planer_amd.onnx_import import OP_TABLE
+    assert [kind for kind, _ in OP_TABLE.values() if kind not in layer.layer_map] == []
