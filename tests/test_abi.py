@@ -81,7 +81,7 @@ where""".split()
 
 def test_operator_table_covers_every_reference_kind():
     from planer_amd import layer
-    assert len(REFERENCE_KINDS) == 58
+    assert len(REFERENCE_KINDS) == 60
     assert [k for k in REFERENCE_KINDS if k not in layer.layer_map] == []
     assert layer.NOT_ON_DEVICE == []
     assert not any(f.__name__.startswith("missing_") for f in layer.layer_map.values())
