@@ -170,6 +170,17 @@ int pl_conv2d_rowpack_q4_f32(pl_ctx *ctx, const float *x, int N, int Cin, int H,
                              const float *wq, int Cout, int kh, int kw, const float *bias,
                              float *yq, int sh, int sw, int pt, int pl, const float *scale,
                              const float *shift, const float *resq, int act, double alpha);
+/* conv + layer.Maxpool(w = 3x3, strides 2, pads 1) (layer.py:71-72 -> util.py:79-95) in ONE kernel: the conv tile is
+ * max-pooled through LDS (zero padding, -1e4 start, the reference's tap order) and yq is the POOLED Q4 tensor
+ * (N, Cout, (Ho+1)/2, (Wo+1)/2): the full-resolution conv output never reaches HBM.  No residual.  Emitted by the
+ * plan compiler for conv -> [batchnorm] -> [relu] -> maxpool chains (ResNet's stem); results are bit-identical to
+ * pl_conv2d_q4_f32 / pl_conv2d_rowpack_q4_f32 followed by pl_pool2d_q4_f32. */
+int pl_conv2d_pool_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const float *wq, int Cout, int kh,
+                          int kw, const float *bias, float *yq, int sh, int sw, int dh, int dw, int pt, int pl, int group,
+                          const float *scale, const float *shift, int act, double alpha);
+int pl_conv2d_rowpack_pool_q4_f32(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const float *wq, int Cout,
+                                  int kh, int kw, const float *bias, float *yq, int sh, int sw, int pt, int pl,
+                                  const float *scale, const float *shift, int act, double alpha);
 
 /* Winograd F(4x4,3x3) on Q4 tensors (same constraints as the F(2x2,3x3) entry points): 6x6 input
  * tiles, 36 grouped GEMMs, 4x fewer multiplies than the direct conv and less transform traffic

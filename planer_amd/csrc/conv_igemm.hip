@@ -63,6 +63,12 @@ struct ConvArgs {
     int rp_rq;        // > 0: row-packed small-Cin input (x = padded NHWC, H/W = padded extents); quads per filter row
     FastDiv divKhw, divKw, divHoWo, divWo, divMt, divCpt;
     Epilogue ep;
+    // conv + maxpool(3x3, stride 2, pad 1) fused (conv_q4_kernel<C, true>): a column tile = one patch of
+    // (2*ph+1) x (2*pw+1) conv pixels = ph x pw pooled pixels; y is the POOLED Q4 tensor (Hp x Wp)
+    struct {
+        int ph, pw, npx, Hp, Wp;
+        FastDiv divPatches, divPpx, divCw, divPerQuad, divPw;
+    } pool;
 };
 
 // blockIdx.x -> (group, m-tile, n-tile).  XCD-aware: the 8 XCDs (private L2s)
@@ -1060,11 +1066,16 @@ int winograd_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, c
                     const float *bias, float *y, const float *scale, const float *shift, const float *res, int act,
                     double alpha);
 
+int conv_pool_run(pl_ctx *ctx, ConvArgs a);
+
+// pool != 0: the conv is followed by maxpool(3x3, stride 2, pad 1) and y is the POOLED Q4 tensor (layouts 2 / 6)
 int conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const float *w, int Cout, int kh, int kw,
                 const float *bias, float *y, int sh, int sw, int dh, int dw, int pt, int pl, int pb, int pr,
                 int group, const float *scale, const float *shift, const float *res, int act, double alpha,
-                int layout) {
+                int layout, int pool = 0) {
     PL_REQUIRE(ctx && x && w && y, PL_EINVAL, "conv2d: null pointer");
+    PL_REQUIRE(!pool || ((layout == 2 || layout == 6) && !res), PL_EUNSUPPORTED,
+               "conv + maxpool: channel-quad direct conv without a residual only");
     PL_REQUIRE(N >= 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0 && kh > 0 && kw > 0, PL_EINVAL, "conv2d: bad shape");
     PL_REQUIRE(sh > 0 && sw > 0 && dh > 0 && dw > 0 && pt >= 0 && pl >= 0 && group > 0, PL_EINVAL, "conv2d: bad parameter");
     // util.pad only honours pads[0]/pads[1] (util.py:8): anything else is undefined there
@@ -1164,6 +1175,7 @@ int conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const
     a.divMt = FastDiv(1); a.divCpt = FastDiv(1);
     a.ep = make_epilogue(bias, scale, shift, res, act, alpha);
     const bool avec = (a.K % 4 == 0) && ((reinterpret_cast<uintptr_t>(w) & 15u) == 0);
+    if (pool) return conv_pool_run(ctx, a);
 
     // forced configuration (tests / tuning tools): split > 1 means split-K over all tiles
     if (ctx->conv_cfg >= 0 && ctx->conv_cfg < kNumCfgs && cfg_applies(kCfgs[ctx->conv_cfg], layout, a.cin_g, a.Qpad)) {
@@ -1194,6 +1206,51 @@ int conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const
         }
     }
     return run_plan(ctx, a, plan, avec, y);
+}
+
+// conv + maxpool(3x3 / stride 2 / pad 1) in one launch: 64 x 256 tiles, a column tile = one patch of conv pixels.
+// The patch (ph x pw pooled pixels) is the one that covers the pooled map with the fewest tiles -- 7 x 8 on
+// ResNet's 56 x 56: 15 x 17 = 255 of 256 columns used, 14 % of the conv pixels computed twice (the halo),
+// against the 103 MB write + 107 MB read of the full-resolution tensor that no longer happen.
+int conv_pool_run(pl_ctx *ctx, ConvArgs a) {
+    using C = Q64x256x16;
+    const int Hp = (a.Ho + 1) / 2, Wp = (a.Wo + 1) / 2;          // (H + 2 - 3 + 2) // 2, util.py:84-85
+    int best_ph = 1, best_pw = 1;
+    long best_tiles = -1, best_px = 0;
+    for (int ph = 1; ph <= 64; ++ph)
+        for (int pw = 1; pw <= 64; ++pw) {
+            const long px = (long)(2 * ph + 1) * (2 * pw + 1);
+            if (px > C::BN) break;
+            const long tiles = (long)((Hp + ph - 1) / ph) * ((Wp + pw - 1) / pw);
+            if (best_tiles < 0 || tiles < best_tiles || (tiles == best_tiles && px < best_px)) {
+                best_tiles = tiles; best_px = px; best_ph = ph; best_pw = pw;
+            }
+        }
+    const int ph = best_ph, pw = best_pw, ppy = (Hp + ph - 1) / ph, ppx = (Wp + pw - 1) / pw;
+    a.pool.ph = ph; a.pool.pw = pw; a.pool.npx = (2 * ph + 1) * (2 * pw + 1); a.pool.Hp = Hp; a.pool.Wp = Wp;
+    a.pool.divPatches = FastDiv(ppy * ppx); a.pool.divPpx = FastDiv(ppx); a.pool.divCw = FastDiv(2 * pw + 1);
+    a.pool.divPerQuad = FastDiv(ph * pw); a.pool.divPw = FastDiv(pw);
+    PL_REQUIRE((size_t)a.N * ppy * ppx * C::BN < (1ull << 31) && (size_t)a.N * a.Coq * Hp * Wp < (1ull << 27), PL_EUNSUPPORTED,
+               "conv + maxpool: tensor too large");
+    a.mtiles = (a.cout_g + C::BM - 1) / C::BM;
+    a.ntiles = a.N * ppy * ppx;
+    a.tiles = a.mtiles * a.ntiles;
+    a.cols = a.ntiles * C::BN;
+    a.divMt = FastDiv(a.mtiles);
+    const int kg = C::BK / 4, total_chunks = (a.Qtot + kg - 1) / kg;
+    a.splits = 1; a.k_per_split = total_chunks; a.tile_offset = 0; a.tile_count = a.tiles * a.groups;
+    a.uni = a.rp_rq ? 0 : a.cqg % kg == 0;
+    a.divCpt = FastDiv(a.rp_rq ? a.rp_rq : a.cqg);
+    const int lds = std::max<int>(C::LDS_BYTES, 1024 * ((3 * C::BM * 4 + 1023) / 1024) + (C::BM / 4) * C::BN * 16);
+    auto kern = conv_q4_kernel<C, true>;
+    int rc = ensure_lds_attr((const void *)kern, lds);
+    if (rc != PL_OK) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles * a.groups)), dim3(256), lds, ctx->stream, a);
+    PL_LAUNCH_CHECK();
+    char buf[96];
+    snprintf(buf, sizeof buf, "q64x256x16+maxpool patch=%dx%d tiles=%d", ph, pw, a.tiles * a.groups);
+    ctx->last_plan = buf;
+    return PL_OK;
 }
 
 // =============================================================================
@@ -1315,11 +1372,6 @@ __global__ void __launch_bounds__(256) wino_output_kernel(const float *M, float 
         }
     }
 }
-
-int conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const float *w, int Cout, int kh, int kw,
-                const float *bias, float *y, int sh, int sw, int dh, int dw, int pt, int pl, int pb, int pr,
-                int group, const float *scale, const float *shift, const float *res, int act, double alpha,
-                int layout);
 
 int winograd_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const float *U, int Cout,
                     const float *bias, float *y, const float *scale, const float *shift, const float *res, int act,
@@ -1703,6 +1755,135 @@ __global__ void __launch_bounds__(256) wino4_output_q4_kernel(const float4 *M, f
     }
 }
 
+// ---- row-split variants for small maps (batch-1 detection nets: a 52x52x256 map is 43 workgroups of the kernels
+//      above on 256 CUs, latency-bound).  blockIdx.y picks ONE row of the transformed tile: a thread then needs only
+//      the operand rows with a non-zero coefficient in that row of B^T / A^T (the other loads are dead code), does
+//      one row pass and 6 (input) or 4 (output) stores -- 6x / 4x the threads, the same arithmetic per element. ----
+template <int A>
+__device__ __forceinline__ float w4_bt_row(const float (&d)[6]) {
+    if constexpr (A == 0) return 4.f * d[0] - 5.f * d[2] + d[4];
+    else if constexpr (A == 1) return -4.f * (d[1] + d[2]) + d[3] + d[4];
+    else if constexpr (A == 2) return 4.f * (d[1] - d[2]) - d[3] + d[4];
+    else if constexpr (A == 3) return 2.f * (d[3] - d[1]) - d[2] + d[4];
+    else if constexpr (A == 4) return 2.f * (d[1] - d[3]) - d[2] + d[4];
+    else return 4.f * d[1] - 5.f * d[3] + d[5];
+}
+template <int A>
+__device__ __forceinline__ void wino4_input_row(const float *x, float *V, const WinoArgs &p, int Cq, unsigned total,
+                                                const __amdgpu_buffer_rsrc_t xrsrc) {
+    const unsigned stride = gridDim.x * 256;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        const unsigned e = i & 3, it = i >> 2;
+        unsigned cq, t, n, r, ty, tx;
+        p.divT.divmod(it, cq, t);
+        p.divTw.divmod(t, r, tx);
+        p.divTh.divmod(r, n, ty);
+        const int h0 = (int)ty * 4 - 1, w0 = (int)tx * 4 - 1;
+        const int xbase = (int)(((n * (unsigned)Cq + cq) * (unsigned)(p.H * p.W)) * 4 + e);
+        float m[6];
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            const int wi = w0 + b;
+            const bool wok = (unsigned)wi < (unsigned)p.W;
+            float d[6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                const int hi = h0 + a;
+                const bool ok = wok && (unsigned)hi < (unsigned)p.H;
+                d[a] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                     xrsrc, ok ? (xbase + (hi * p.W + wi) * 4) << 2 : (int)0x80000000, 0, 0));
+            }
+            m[b] = w4_bt_row<A>(d);
+        }
+        float o[6];
+        w4_bt(m, o);
+        const size_t plane = (size_t)Cq * p.T * 4;
+        float *vp = V + (size_t)it * 4 + e;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) vp[(size_t)(A * 6 + b) * plane] = o[b];
+    }
+}
+__global__ void __launch_bounds__(256) wino4_input_rows_q4_kernel(const float *x, float *V, const WinoArgs p, int Cq,
+                                                                  unsigned total) {
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(x), 0, (unsigned)p.N * (unsigned)Cq * (unsigned)(p.H * p.W) * 16u, 0x00020000);
+    switch (blockIdx.y) {
+    case 0: wino4_input_row<0>(x, V, p, Cq, total, xrsrc); break;
+    case 1: wino4_input_row<1>(x, V, p, Cq, total, xrsrc); break;
+    case 2: wino4_input_row<2>(x, V, p, Cq, total, xrsrc); break;
+    case 3: wino4_input_row<3>(x, V, p, Cq, total, xrsrc); break;
+    case 4: wino4_input_row<4>(x, V, p, Cq, total, xrsrc); break;
+    default: wino4_input_row<5>(x, V, p, Cq, total, xrsrc); break;
+    }
+}
+
+template <int A>
+__device__ __forceinline__ float4 w4_at4_row(const float4 (&m)[6]) {
+    if constexpr (A == 0) return f4sum(f4sum(m[0], f4sum(m[1], m[2])), f4sum(m[3], m[4]));
+    else {
+        const float4 q = f4sub(m[1], m[2]), t = f4sub(m[3], m[4]), pp = f4sum(m[1], m[2]), r = f4sum(m[3], m[4]);
+        if constexpr (A == 1) return make_float4(q.x + 2.f * t.x, q.y + 2.f * t.y, q.z + 2.f * t.z, q.w + 2.f * t.w);
+        else if constexpr (A == 2) return make_float4(pp.x + 4.f * r.x, pp.y + 4.f * r.y, pp.z + 4.f * r.z, pp.w + 4.f * r.w);
+        else return make_float4(q.x + 8.f * t.x + m[5].x, q.y + 8.f * t.y + m[5].y, q.z + 8.f * t.z + m[5].z, q.w + 8.f * t.w + m[5].w);
+    }
+}
+template <int A>
+__device__ __forceinline__ void wino4_output_row(const float4 *M, const WinoArgs &p, int Coq, unsigned total,
+                                                 const __amdgpu_buffer_rsrc_t yrsrc, const __amdgpu_buffer_rsrc_t rrsrc) {
+    const unsigned stride = gridDim.x * 256;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        unsigned coq, t, n, r, ty, tx;
+        p.divT.divmod(i, coq, t);
+        p.divTw.divmod(t, r, tx);
+        p.divTh.divmod(r, n, ty);
+        const size_t plane = (size_t)Coq * p.T;
+        const float4 *mp = M + i;
+        float4 s[6];
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            float4 m[6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) m[a] = mp[(size_t)(a * 6 + b) * plane];
+            s[b] = w4_at4_row<A>(m);
+        }
+        float bs[4], sc[4], sh[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) load_chan_params(p.ep, (int)coq * 4 + e, bs[e], sc[e], sh[e]);
+        const float4 bias = make_float4(bs[0], bs[1], bs[2], bs[3]), scale = make_float4(sc[0], sc[1], sc[2], sc[3]);
+        const float4 shift = make_float4(sh[0], sh[1], sh[2], sh[3]);
+        const int ho = (int)ty * 4 + A, wo = (int)tx * 4;
+        const unsigned row = ((n * (unsigned)Coq + coq) * (unsigned)p.Ho + (unsigned)ho) * (unsigned)p.Wo + (unsigned)wo;
+        int off[4];
+        float4 rs[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            off[b] = (ho < p.Ho && wo + b < p.Wo) ? (int)((row + b) << 4) : (int)0x80000000;
+            rs[b] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off[b], 0, 0));
+        }
+        float4 o[4];
+        w4_at4(s, o);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const float4 v = apply_epilogue4(p.ep, bias, scale, shift, rs[b], 4, o[b]);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
+                                                   yrsrc, off[b], 0, 0);
+        }
+    }
+}
+__global__ void __launch_bounds__(256) wino4_output_rows_q4_kernel(const float4 *M, float4 *y, const WinoArgs p, int Coq,
+                                                                   unsigned total) {
+    const unsigned out_bytes = (unsigned)p.N * (unsigned)Coq * (unsigned)(p.Ho * p.Wo) * 16u;
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(y, 0, out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.ep.res), 0, p.ep.res ? out_bytes : 0u, 0x00020000);
+    switch (blockIdx.y) {
+    case 0: wino4_output_row<0>(M, p, Coq, total, yrsrc, rrsrc); break;
+    case 1: wino4_output_row<1>(M, p, Coq, total, yrsrc, rrsrc); break;
+    case 2: wino4_output_row<2>(M, p, Coq, total, yrsrc, rrsrc); break;
+    default: wino4_output_row<3>(M, p, Coq, total, yrsrc, rrsrc); break;
+    }
+}
+
 int winograd4_q4_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const float *Uq, int Cout,
                         const float *bias, float *yq, const float *scale, const float *shift, const float *resq,
                         int act, double alpha) {
@@ -1726,12 +1907,24 @@ int winograd4_q4_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int
     }
     const unsigned cap = (unsigned)(ctx->cu_count > 0 ? ctx->cu_count : 256) * 8;
     const unsigned tin = (unsigned)((size_t)Cin * p.T), tout = (unsigned)((size_t)Coq * p.T);
-    wino4_input_q4_kernel<<<std::min(cap, (tin + 255) / 256), 256, 0, ctx->stream>>>(xq, V, p, Cq, tin);
+    // small maps: one transformed row per thread (see the row-split kernels); PLANER_HIP_WINO_ROWS=0/1 forces
+    static const char *rows_env = getenv("PLANER_HIP_WINO_ROWS");
+    const unsigned cus = (unsigned)(ctx->cu_count > 0 ? ctx->cu_count : 256);
+    const bool in_rows = rows_env ? atoi(rows_env) != 0 : (tin + 255) / 256 < cus;
+    const bool out_rows = rows_env ? atoi(rows_env) != 0 : (tout + 255) / 256 < cus / 2;
+    if (in_rows)
+        wino4_input_rows_q4_kernel<<<dim3(std::min(cap, (tin + 255) / 256), 6), 256, 0, ctx->stream>>>(xq, V, p, Cq, tin);
+    else
+        wino4_input_q4_kernel<<<std::min(cap, (tin + 255) / 256), 256, 0, ctx->stream>>>(xq, V, p, Cq, tin);
     rc = conv_launch(ctx, V, 1, 36 * Cin, N * p.th, p.tw, Uq, 36 * Cout, 1, 1, nullptr, M, 1, 1, 1, 1, 0, 0, 0, 0, 36,
                      nullptr, nullptr, nullptr, PL_ACT_NONE, 0.0, 2);
     if (rc == PL_OK) {
-        wino4_output_q4_kernel<<<std::min(cap, (tout + 255) / 256), 256, 0, ctx->stream>>>((const float4 *)M, (float4 *)yq, p,
-                                                                                           Coq, tout);
+        if (out_rows)
+            wino4_output_rows_q4_kernel<<<dim3(std::min(cap, (tout + 255) / 256), 4), 256, 0, ctx->stream>>>(
+                (const float4 *)M, (float4 *)yq, p, Coq, tout);
+        else
+            wino4_output_q4_kernel<<<std::min(cap, (tout + 255) / 256), 256, 0, ctx->stream>>>((const float4 *)M, (float4 *)yq, p,
+                                                                                               Coq, tout);
         hipError_t le = hipGetLastError();
         if (le != hipSuccess) {
             pl_set_error("winograd F(4,3) transform launch: %s", hipGetErrorString(le));
@@ -1872,9 +2065,9 @@ int pl_conv2d_prepare_rowpack_f32(pl_ctx *ctx, const float *w, int Cout, int Cin
     return PL_OK;
 }
 
-int pl_conv2d_rowpack_q4_f32(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const float *wq, int Cout, int kh,
-                             int kw, const float *bias, float *yq, int sh, int sw, int pt, int pl, const float *scale,
-                             const float *shift, const float *resq, int act, double alpha) {
+static int rowpack_conv(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const float *wq, int Cout, int kh,
+                        int kw, const float *bias, float *yq, int sh, int sw, int pt, int pl, const float *scale,
+                        const float *shift, const float *resq, int act, double alpha, int pool) {
     PL_REQUIRE(ctx && x && wq && yq, PL_EINVAL, "pl_conv2d_rowpack_q4_f32: null pointer");
     PL_REQUIRE(N >= 0 && Cin > 0 && Cin < 4 && H > 0 && W > 0 && Cout > 0 && kh > 0 && kw > 0 && sh > 0 && sw > 0 &&
                    pt >= 0 && pl >= 0, PL_EINVAL, "pl_conv2d_rowpack_q4_f32: bad shape (Cin must be 1..3)");
@@ -1894,9 +2087,31 @@ int pl_conv2d_rowpack_q4_f32(pl_ctx *ctx, const float *x, int N, int Cin, int H,
     nchw_to_rowpack_kernel<<<std::min<unsigned>((total4 + 255) / 256, 256 * 16), 256, 0, ctx->stream>>>(
         x, xp, total4, total, Cin, H, W, Hp, Wp, pt, pl, FastDiv(Cin), FastDiv(Wp), FastDiv(Hp));
     rc = conv_launch(ctx, xp, N, Cin, H, W, wq, Cout, kh, kw, bias, yq, sh, sw, 1, 1, pt, pl, pt, pl, 1, scale, shift, resq,
-                     act, alpha, 6);
+                     act, alpha, 6, pool);
     pl_free(ctx, xp);            // stream-ordered
     return rc;
+}
+
+int pl_conv2d_rowpack_q4_f32(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const float *wq, int Cout, int kh,
+                             int kw, const float *bias, float *yq, int sh, int sw, int pt, int pl, const float *scale,
+                             const float *shift, const float *resq, int act, double alpha) {
+    return rowpack_conv(ctx, x, N, Cin, H, W, wq, Cout, kh, kw, bias, yq, sh, sw, pt, pl, scale, shift, resq, act, alpha, 0);
+}
+
+int pl_conv2d_rowpack_pool_q4_f32(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const float *wq, int Cout, int kh,
+                                  int kw, const float *bias, float *yq, int sh, int sw, int pt, int pl, const float *scale,
+                                  const float *shift, int act, double alpha) {
+    return rowpack_conv(ctx, x, N, Cin, H, W, wq, Cout, kh, kw, bias, yq, sh, sw, pt, pl, scale, shift, nullptr, act, alpha, 1);
+}
+
+int pl_conv2d_pool_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const float *wq, int Cout, int kh,
+                          int kw, const float *bias, float *yq, int sh, int sw, int dh, int dw, int pt, int pl, int group,
+                          const float *scale, const float *shift, int act, double alpha) {
+    PL_REQUIRE(!xq || !yq || ((reinterpret_cast<uintptr_t>(xq) | reinterpret_cast<uintptr_t>(yq) |
+                               reinterpret_cast<uintptr_t>(wq)) & 15u) == 0,
+               PL_EINVAL, "pl_conv2d_pool_q4_f32: Q4 tensors must be 16-byte aligned");
+    return conv_launch(ctx, xq, N, Cin, H, W, wq, Cout, kh, kw, bias, yq, sh, sw, dh, dw, pt, pl, pt, pl, group, scale, shift,
+                       nullptr, act, alpha, 2, 1);
 }
 
 static int w1d_filter_elems(int Cout, int Cin, int freqs, size_t *elems) {

@@ -399,7 +399,39 @@ class Net:
                     srcs[1] = key
                     out_body[name] = [name, "conv_fused", dict(entry[2], w_layout=lay)]
             out_flow.append([srcs, [name], dst])
-        return [out_body[b[0]] for b in body], out_flow
+        # conv + maxpool in one kernel: bit-identical, measured SLOWER on ResNet-18's stem -> opt-in
+        if os.environ.get("PLANER_HIP_FUSE_POOL", "0") != "0":
+            out_flow = self._fuse_conv_maxpool(out_body, out_flow)
+        used = {n for _, names, _ in out_flow for n in names}
+        return [out_body[b[0]] for b in body if b[0] in used], out_flow
+
+    @staticmethod
+    def _fuse_conv_maxpool(body, flow):
+        """conv_q4 (direct kernel, no residual) whose only reader is maxpool_q4(w=3x3, strides 2, pads 1) -> one
+        conv_q4 step with pool=True (csrc/conv_q4_kernel.h, POOL): the full-resolution tensor is never written."""
+        readers = {}
+        for i, (src, names, dst) in enumerate(flow):
+            for k in (src if isinstance(src, list) else [src]):
+                readers.setdefault(k, []).append(i)
+        drop, out = set(), []
+        for i, (src, names, dst) in enumerate(flow):
+            entry = body[names[0]]
+            if (entry[1] == "conv_q4" and entry[2].get("w_layout") in (2, 6) and isinstance(dst, str)
+                    and (len(src) < 6 or src[5] == "None") and len(readers.get(dst, [])) == 1):
+                j = readers[dst][0]
+                psrc, pnames, pdst = flow[j]
+                pe = body[pnames[0]]
+                if (pe[1] == "maxpool_q4" and len(pnames) == 1 and (psrc == dst or psrc == [dst])
+                        and [int(v) for v in pe[2].get("w", (2, 2))] == [3, 3]
+                        and [int(v) for v in pe[2].get("strides", (2, 2))] == [2, 2]
+                        and [int(v) for v in pe[2].get("pads", (0, 0, 0, 0))] == [1, 1, 1, 1]):
+                    body[names[0]] = [entry[0], "conv_q4", dict(entry[2], pool=True)]
+                    out.append([src, names, pdst])
+                    drop.add(j)
+                    continue
+            if i not in drop:
+                out.append([src, names, dst])
+        return out
 
     def _pick_conv_algo(self, ConvFused, K, srcs, para, shapes, wmap, q4=False):
         """Time the direct implicit GEMM and the Winograd variants for this conv's real shape and

@@ -166,11 +166,14 @@ def w1d_q4_eligible(k_shape, group=1, strides=(1, 1), dilations=(1, 1), pads=(0,
 
 
 def ConvQ4(xq, Kq, B=None, scale=None, shift=None, resq=None, group=1, strides=(1, 1),
-           dilations=(1, 1), pads=(0, 0, 0, 0), act=ACT_NONE, alpha=0.0, w_layout=2, **_):
+           dilations=(1, 1), pads=(0, 0, 0, 0), act=ACT_NONE, alpha=0.0, w_layout=2, pool=False, **_):
     """layer.ConvFused on Q4 tensors: act((conv(x,K)+B)*scale + shift + res), all activations Q4.
     w_layout=2: Kq from prepare_q4_weights(); w_layout=4: Winograd filters from
-    prepare_winograd_q4_weights()."""
+    prepare_winograd_q4_weights().  pool=True (w_layout 2 / 6, no residual): the conv is followed by
+    layer.Maxpool(w=3x3, strides 2, pads 1) inside the same kernel and the POOLED tensor comes back."""
     _f32(xq, Kq, B, scale, shift, resq)
+    if pool and (w_layout not in (2, 6) or resq is not None):
+        raise ValueError("conv + maxpool fusion serves the direct channel-quad kernels without a residual")
     if w_layout == 6:
         # row-packed stem: the input is the reference's NCHW tensor, the output is Q4
         if is_q4(xq) or (resq is not None and not is_q4(resq)):
@@ -183,6 +186,11 @@ def ConvQ4(xq, Kq, B=None, scale=None, shift=None, resq=None, group=1, strides=(
             raise ValueError("conv: weight %s does not match input %s" % (Kq.shape, xq.shape))
         pads, strides = [int(p) for p in pads], [int(s) for s in strides]
         ho, wo = conv_out_hw(h, w, kh, kw, strides, [1, 1], pads)
+        if pool:
+            y = _new_q4(n, cout, (ho + 1) // 2, (wo + 1) // 2, xq.ctx)
+            _lib.call("pl_conv2d_rowpack_pool_q4_f32", xq.ctx.handle, xq.ptr, n, cin, h, w, Kq.ptr, cout, kh, kw, _ptr(B), y.ptr,
+                      strides[0], strides[1], pads[0], pads[1], _ptr(scale), _ptr(shift), int(act), float(alpha))
+            return y
         y = _new_q4(n, cout, ho, wo, xq.ctx)
         if resq is not None and resq.shape != y.shape:
             raise ValueError("fused residual shape %s != conv output %s" % (resq.shape, y.shape))
@@ -199,6 +207,14 @@ def ConvQ4(xq, Kq, B=None, scale=None, shift=None, resq=None, group=1, strides=(
     strides = [int(s) for s in strides]
     dilations = [int(d) for d in dilations]
     ho, wo = conv_out_hw(h, w, kh, kw, strides, dilations, pads)
+    if pool:
+        if pads[0] != pads[2] or pads[1] != pads[3]:
+            raise NotImplementedError("asymmetric pads are undefined in the reference (util.py:8)")
+        y = _new_q4(n, cout, (ho + 1) // 2, (wo + 1) // 2, xq.ctx)
+        _lib.call("pl_conv2d_pool_q4_f32", xq.ctx.handle, xq.ptr, n, cin, h, w, Kq.ptr, cout, kh, kw, _ptr(B), y.ptr,
+                  strides[0], strides[1], dilations[0], dilations[1], pads[0], pads[1], int(group), _ptr(scale), _ptr(shift),
+                  int(act), float(alpha))
+        return y
     y = _new_q4(n, cout, ho, wo, xq.ctx)
     if resq is not None and resq.shape != y.shape:
         raise ValueError("fused residual shape %s != conv output %s" % (resq.shape, y.shape))

@@ -403,3 +403,41 @@ def test_q4_stem_maxpool_block_kernel_is_bit_exact(pa):
         want = onp.maxpool(x, (3, 3), (1, 1, 1, 1), (2, 2))
         np.testing.assert_array_equal(q4.from_q4(yq).get(), want)
         np.testing.assert_array_equal(yq.get(), q4_host(want))
+
+
+@pytest.mark.parametrize("shape", [
+    # (N, Cin, H, W, Cout, k, stride, pad)
+    (2, 8, 23, 29, 12, 3, 1, 1),        # ragged everything: odd map, Cout under one tile, patches hang over the edge
+    (1, 16, 56, 56, 130, 3, 1, 1),      # three 64-row tiles of output channels, the last one ragged
+    (3, 3, 37, 41, 64, 7, 2, 3),        # the row-packed stem gather (Cin = 3), stride 2
+    (2, 3, 224, 224, 64, 7, 2, 3),      # ResNet-18's stem at full size: 7 x 8 patches of 56 x 56
+    (1, 4, 9, 7, 8, 1, 1, 0),           # 1x1 conv, a map smaller than one patch
+])
+def test_conv_maxpool_fused_kernel_is_bit_exact(pa, shape):
+    """conv (+bias, bn, relu) + maxpool(3x3, s2, p1) in one kernel == the conv kernel followed by the pool kernel,
+    bit for bit (same accumulation order per conv pixel; max is exact), and matches the oracle."""
+    from planer_amd import q4
+    n, cin, h, w, cout, k, st, pd = shape
+    rng = np.random.default_rng(sum(shape))
+    x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+    K = (rng.standard_normal((cout, cin, k, k)) * 0.2).astype(np.float32)
+    B = rng.standard_normal(cout).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, (1, cout, 1, 1)).astype(np.float32)
+    sh = (rng.standard_normal((1, cout, 1, 1)) * 0.3).astype(np.float32)
+    para = dict(strides=[st, st], pads=[pd] * 4, dilations=[1, 1], group=1)
+    dK, dB, dsc, dsh = pa.asarray(K), pa.asarray(B), pa.asarray(sc), pa.asarray(sh)
+    rowpack = cin < 4 and q4.rowpack_eligible(K.shape, **para)
+    if rowpack:
+        xin, Kq, lay = pa.asarray(x), q4.prepare_rowpack_weights(dK), 6
+    else:
+        xin, Kq, lay = q4.to_q4(pa.asarray(x)), q4.prepare_q4_weights(dK), 2
+    for act in (1, 0):                      # relu / none: without relu negative maxima meet the zero padding
+        two = q4.MaxpoolQ4(q4.ConvQ4(xin, Kq, dB, dsc, dsh, None, act=act, w_layout=lay, **para), w=[3, 3], pads=[1, 1, 1, 1],
+                           strides=[2, 2])
+        one = q4.ConvQ4(xin, Kq, dB, dsc, dsh, None, act=act, w_layout=lay, pool=True, **para)
+        assert "maxpool" in pa.hip.context().last_conv_plan()
+        assert one.shape == two.shape and one.chan == two.chan
+        np.testing.assert_array_equal(one.get(), two.get())
+        conv = onp.batchnorm(onp.conv2d(x, K, B, **para), sc, sh)
+        want = onp.maxpool(onp.relu(conv) if act else conv, w=[3, 3], pads=[1, 1, 1, 1], strides=[2, 2])
+        assert_close(q4.from_q4(one).get(), want, RTOL, "conv+maxpool %s act %d" % (shape, act))
