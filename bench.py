@@ -82,6 +82,10 @@ def executed_flops(rec, c):
 
     def gemm(rows, cols, kquads, groups=1):
         return 2.0 * groups * cdiv(rows, bm) * bm * cdiv(cols, bn) * bn * cdiv(kquads * 4, bk) * bk
+    pooled = re.search(r"\+maxpool .*tiles=(\d+)", rec["plan"])
+    if pooled:                         # conv + max-pool kernel: whole tiles, halo pixels computed twice
+        kq = kh * cdiv(kw * cin, 4) if lay == 6 else kh * kw * cdiv(cin // c["group"], 4)
+        return 2.0 * int(pooled.group(1)) * bm * bn * cdiv(kq * 4, bk) * bk
     if lay == 2:
         grp = c["group"]
         return gemm(cout // grp, n * ho * wo, kh * kw * cdiv(cin // grp, 4), grp)
@@ -98,6 +102,26 @@ def executed_flops(rec, c):
     if lay in (0, 1) and rec["kind"] in ("dense", "conv", "conv_fused"):
         return 2.0 * cdiv(cout, bm) * bm * cdiv(n * ho * wo, bn) * bn * cdiv(cin // c["group"] * kh * kw, bk) * bk
     return None
+
+
+def sample_sclk(step, sync, seconds=1.2):
+    """Shader clock (MHz) of GPU[0] as `rocm-smi --showclocks` sees it while `step` runs back to back for about
+    `seconds` (untimed; a few samples, the median).  None when the tool or its output is not there."""
+    import subprocess
+    samples, t0 = [], time.perf_counter()
+    try:
+        while time.perf_counter() - t0 < seconds and len(samples) < 3:
+            proc = subprocess.Popen(["rocm-smi", "--showclocks"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+            while proc.poll() is None:
+                for _ in range(10):
+                    step()
+                sync()
+            m = re.search(r"GPU\[0\]\s*:\s*sclk clock level:\s*\S+\s*\((\d+)Mhz\)", proc.stdout.read())
+            if m:
+                samples.append(int(m.group(1)))
+    except OSError:
+        return None
+    return sorted(samples)[len(samples) // 2] if samples else None
 
 
 def oracle_net(g, b):
@@ -277,6 +301,9 @@ def main():
     if rank != 0:
         return
 
+    # ---- clock state (untimed): the shader clock rocm-smi reports while the same pipelined loop runs ----
+    sclk_mhz = sample_sclk(step, sync)
+
     cpu_rep, want = None, None
     if args.workload == "resnet18" and world == 1 and not args.no_cpu_baseline:
         cpu_rep, want = cpu_baseline(g, blob, xs_host[0], args.cpu_iters)
@@ -439,6 +466,7 @@ def main():
                       "pcie_inclusive_images_per_sec": None if e2e is None else round(e2e, 1),
                       "device": ctx.arch, "cu_count": ctx.cu_count,
                       "tune_cache": os.environ.get("PLANER_HIP_TUNE_CACHE"), "settle_ms": args.settle_ms,
+                      "sclk_mhz_under_load": sclk_mhz,
                       "timed_region_ms": round(elapsed * 1e3, 3),
                       "algos": algo_list},
            "roofline": roofline, "roofline_hbm": hbm,
