@@ -104,24 +104,24 @@ def executed_flops(rec, c):
     return None
 
 
-def sample_sclk(step, sync, seconds=1.2):
-    """Shader clock (MHz) of GPU[0] as `rocm-smi --showclocks` sees it while `step` runs back to back for about
-    `seconds` (untimed; a few samples, the median).  None when the tool or its output is not there."""
-    import subprocess
-    samples, t0 = [], time.perf_counter()
+def sample_sclk(ctx, step, sync, samples=5):
+    """Shader clock (MHz) of this GPU while `step` runs back to back (untimed): the level sysfs marks active in
+    /sys/bus/pci/devices/<bus id>/pp_dpm_sclk, sampled between bursts, the median.  None when sysfs is not there.
+    (No management CLI is forked: a fork with captured graphs in flight crashes rocprofv3's interception.)"""
     try:
-        while time.perf_counter() - t0 < seconds and len(samples) < 3:
-            proc = subprocess.Popen(["rocm-smi", "--showclocks"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
-            while proc.poll() is None:
-                for _ in range(10):
-                    step()
-                sync()
-            m = re.search(r"GPU\[0\]\s*:\s*sclk clock level:\s*\S+\s*\((\d+)Mhz\)", proc.stdout.read())
+        path = "/sys/bus/pci/devices/%s/pp_dpm_sclk" % ctx.pci_bus_id()
+        seen = []
+        for _ in range(samples):
+            for _ in range(10):                        # the settle loop's burst: ~7 ms of queued work
+                step()
+            with open(path) as f:                      # read while the queue is still full
+                m = re.search(r":\s*(\d+)\s*Mhz\s*\*", f.read(), re.I)
+            sync()
             if m:
-                samples.append(int(m.group(1)))
-    except OSError:
+                seen.append(int(m.group(1)))
+        return sorted(seen)[len(seen) // 2] if seen else None
+    except Exception:
         return None
-    return sorted(samples)[len(samples) // 2] if samples else None
 
 
 def oracle_net(g, b):
@@ -208,6 +208,7 @@ def main():
                     help="resnet18 = the headline (BASELINE configs[2]); yolov3 = config 5 at batch 1; "
                          "conv2 = config 2's single Conv2d 3->64 on (8,3,224,224)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive net(x_host) leg")
+    ap.add_argument("--no-sclk", action="store_true", help="skip the rocm-smi shader-clock samples (profiling runs)")
     ap.add_argument("--per-layer-csv", help="write the per-layer table (HIP events) to this file")
     ap.add_argument("--settle-ms", type=float, default=300.0,
                     help="run the step loop untimed for this long before the W warm-up steps, so the timed region sees "
@@ -283,6 +284,8 @@ def main():
     elapsed = dist.timed_steps(comm, step, sync, args.steps, args.warmup)
     ms_per_step = elapsed / args.steps * 1e3
     value = global_batch * args.steps / elapsed
+    # clock state (untimed): the shader clock sysfs reports while the same loop keeps running
+    sclk_mhz = sample_sclk(ctx, step, sync) if rank == 0 and not args.no_sclk else None
 
     # ---- parity of what was just timed: every replica of the plan on batch 0 vs the oracle ----
     sync()
@@ -300,9 +303,6 @@ def main():
 
     if rank != 0:
         return
-
-    # ---- clock state (untimed): the shader clock rocm-smi reports while the same pipelined loop runs ----
-    sclk_mhz = sample_sclk(step, sync)
 
     cpu_rep, want = None, None
     if args.workload == "resnet18" and world == 1 and not args.no_cpu_baseline:

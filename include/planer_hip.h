@@ -57,6 +57,9 @@ int pl_ctx_create(int device, pl_ctx **out);
 int pl_ctx_destroy(pl_ctx *ctx);
 int pl_ctx_info(pl_ctx *ctx, int *device, int *cu_count, size_t *hbm_bytes,
                 char *arch_name, size_t arch_name_len);
+/* "domain:bus:device.function" of the context's GPU (what /sys/bus/pci/devices/ is keyed by): lets a host tool
+ * read the card's clocks from sysfs without forking a management CLI. */
+int pl_ctx_pci_bus_id(pl_ctx *ctx, char *bus_id, size_t len);
 int pl_sync(pl_ctx *ctx); /* wait for the context stream */
 
 /* memory: replaces numpy/cupy array allocation (np.zeros, util.py:31-32,88) */
@@ -73,6 +76,7 @@ int pl_memset(pl_ctx *ctx, void *dst, int byte, size_t bytes);
 /* timing: fills Net.timer (net.py:55,67-70) with device time */
 int pl_event_create(pl_ctx *ctx, pl_event **out);
 int pl_event_record(pl_ctx *ctx, pl_event *ev);
+int pl_event_sync(pl_event *ev);        /* host waits until the recorded point of the stream has been reached */
 int pl_event_elapsed_ms(pl_event *start, pl_event *stop, float *ms); /* syncs on stop */
 int pl_event_destroy(pl_event *ev);
 

@@ -30,6 +30,7 @@ SIGNATURES = {
     "pl_ctx_create": [_I, POINTER(_P)],
     "pl_ctx_destroy": [_P],
     "pl_ctx_info": [_P, POINTER(c_int), POINTER(c_int), POINTER(c_size_t), c_char_p, _Z],
+    "pl_ctx_pci_bus_id": [_P, c_char_p, _Z],
     "pl_sync": [_P],
     "pl_alloc": [_P, _Z, POINTER(_P)],
     "pl_free": [_P, _P],
@@ -41,6 +42,7 @@ SIGNATURES = {
     "pl_memset": [_P, _P, _I, _Z],
     "pl_event_create": [_P, POINTER(_P)],
     "pl_event_record": [_P, _P],
+    "pl_event_sync": [_P],
     "pl_event_elapsed_ms": [_P, _P, POINTER(c_float)],
     "pl_event_destroy": [_P],
     "pl_stream_wait": [_P, _P],

@@ -63,12 +63,13 @@ struct ConvArgs {
     int rp_rq;        // > 0: row-packed small-Cin input (x = padded NHWC, H/W = padded extents); quads per filter row
     FastDiv divKhw, divKw, divHoWo, divWo, divMt, divCpt;
     Epilogue ep;
-    // conv + maxpool(3x3, stride 2, pad 1) fused (conv_q4_kernel<C, true>): a column tile = one patch of
-    // (2*ph+1) x (2*pw+1) conv pixels = ph x pw pooled pixels; y is the POOLED Q4 tensor (Hp x Wp)
-    struct {
-        int ph, pw, npx, Hp, Wp;
-        FastDiv divPatches, divPpx, divCw, divPerQuad, divPw;
-    } pool;
+};
+// conv + maxpool(3x3, stride 2, pad 1) fused (conv_q4_pool_kernel): a column tile = one patch of (2*ph+1) x (2*pw+1)
+// conv pixels = ph x pw pooled pixels; y is the POOLED Q4 tensor (Hp x Wp).  A second kernel argument, so the
+// kernarg block of every other conv launch stays as small as it was (hundreds of graph launches can be in flight).
+struct PoolArgs {
+    int ph, pw, npx, Hp, Wp;
+    FastDiv divPatches, divPpx, divCw, divPerQuad, divPw;
 };
 
 // blockIdx.x -> (group, m-tile, n-tile).  XCD-aware: the 8 XCDs (private L2s)
@@ -1227,9 +1228,10 @@ int conv_pool_run(pl_ctx *ctx, ConvArgs a) {
             }
         }
     const int ph = best_ph, pw = best_pw, ppy = (Hp + ph - 1) / ph, ppx = (Wp + pw - 1) / pw;
-    a.pool.ph = ph; a.pool.pw = pw; a.pool.npx = (2 * ph + 1) * (2 * pw + 1); a.pool.Hp = Hp; a.pool.Wp = Wp;
-    a.pool.divPatches = FastDiv(ppy * ppx); a.pool.divPpx = FastDiv(ppx); a.pool.divCw = FastDiv(2 * pw + 1);
-    a.pool.divPerQuad = FastDiv(ph * pw); a.pool.divPw = FastDiv(pw);
+    PoolArgs pa;
+    pa.ph = ph; pa.pw = pw; pa.npx = (2 * ph + 1) * (2 * pw + 1); pa.Hp = Hp; pa.Wp = Wp;
+    pa.divPatches = FastDiv(ppy * ppx); pa.divPpx = FastDiv(ppx); pa.divCw = FastDiv(2 * pw + 1);
+    pa.divPerQuad = FastDiv(ph * pw); pa.divPw = FastDiv(pw);
     PL_REQUIRE((size_t)a.N * ppy * ppx * C::BN < (1ull << 31) && (size_t)a.N * a.Coq * Hp * Wp < (1ull << 27), PL_EUNSUPPORTED,
                "conv + maxpool: tensor too large");
     a.mtiles = (a.cout_g + C::BM - 1) / C::BM;
@@ -1242,10 +1244,10 @@ int conv_pool_run(pl_ctx *ctx, ConvArgs a) {
     a.uni = a.rp_rq ? 0 : a.cqg % kg == 0;
     a.divCpt = FastDiv(a.rp_rq ? a.rp_rq : a.cqg);
     const int lds = std::max<int>(C::LDS_BYTES, 1024 * ((3 * C::BM * 4 + 1023) / 1024) + (C::BM / 4) * C::BN * 16);
-    auto kern = conv_q4_kernel<C, true>;
+    auto kern = conv_q4_pool_kernel<C>;
     int rc = ensure_lds_attr((const void *)kern, lds);
     if (rc != PL_OK) return rc;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles * a.groups)), dim3(256), lds, ctx->stream, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles * a.groups)), dim3(256), lds, ctx->stream, a, pa);
     PL_LAUNCH_CHECK();
     char buf[96];
     snprintf(buf, sizeof buf, "q64x256x16+maxpool patch=%dx%d tiles=%d", ph, pw, a.tiles * a.groups);

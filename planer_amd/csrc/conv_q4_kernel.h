@@ -223,16 +223,16 @@ struct PoolPixel {
     bool ok;
 };
 template <int BN>
-__device__ __forceinline__ PoolPixel pool_pixel(const ConvArgs &p, int col0, int jl) {
+__device__ __forceinline__ PoolPixel pool_pixel(const ConvArgs &p, const PoolArgs &pa, int col0, int jl) {
     PoolPixel r;
     unsigned n, pr, PY, PX, ly, lx;
-    p.pool.divPatches.divmod((unsigned)(col0 / BN), n, pr);
-    p.pool.divPpx.divmod(pr, PY, PX);
-    p.pool.divCw.divmod((unsigned)jl, ly, lx);
+    pa.divPatches.divmod((unsigned)(col0 / BN), n, pr);
+    pa.divPpx.divmod(pr, PY, PX);
+    pa.divCw.divmod((unsigned)jl, ly, lx);
     r.n = (int)n; r.PY = (int)PY; r.PX = (int)PX;
-    r.ho = 2 * p.pool.ph * (int)PY - 1 + (int)ly;
-    r.wo = 2 * p.pool.pw * (int)PX - 1 + (int)lx;
-    r.ok = jl < p.pool.npx && (unsigned)r.ho < (unsigned)p.Ho && (unsigned)r.wo < (unsigned)p.Wo;
+    r.ho = 2 * pa.ph * (int)PY - 1 + (int)ly;
+    r.wo = 2 * pa.pw * (int)PX - 1 + (int)lx;
+    r.ok = jl < pa.npx && (unsigned)r.ho < (unsigned)p.Ho && (unsigned)r.wo < (unsigned)p.Wo;
     return r;
 }
 
@@ -241,8 +241,8 @@ __device__ __forceinline__ PoolPixel pool_pixel(const ConvArgs &p, int col0, int
 // quad, pooled pixel) windows starting from -1e4 in the reference's tap order (util.py:79-95) and writes the
 // POOLED Q4 tensor: the full-resolution conv output never reaches HBM.  smem: [3][BM] parameters, then the stage.
 template <int BM, int BN, int TM, int TN, int WTM, int WTN>
-__device__ __forceinline__ void pool_tile_q4(const ConvArgs &p, const TileCoord &tc, f32x16 (&acc)[TM][TN], int wm,
-                                             int wn, int lane, float *smem) {
+__device__ __forceinline__ void pool_tile_q4(const ConvArgs &p, const PoolArgs &pa, const TileCoord &tc,
+                                             f32x16 (&acc)[TM][TN], int wm, int wn, int lane, float *smem) {
     const int l31 = lane & 31, lhi = lane >> 5;
     const float4 *prm4 = reinterpret_cast<const float4 *>(smem);
     float4 *stage = reinterpret_cast<float4 *>(smem + 256 * ((3 * BM + 255) / 256));
@@ -250,7 +250,7 @@ __device__ __forceinline__ void pool_tile_q4(const ConvArgs &p, const TileCoord 
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
         const int px = wn * WTN + b * 32 + l31;
-        const bool in_map = pool_pixel<BN>(p, tc.col0, px).ok;
+        const bool in_map = pool_pixel<BN>(p, pa, tc.col0, px).ok;
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -264,15 +264,15 @@ __device__ __forceinline__ void pool_tile_q4(const ConvArgs &p, const TileCoord 
             }
     }
     __syncthreads();
-    const PoolPixel p0 = pool_pixel<BN>(p, tc.col0, 0);
-    const int per_quad = p.pool.ph * p.pool.pw, items = (BM / 4) * per_quad, cw = 2 * p.pool.pw + 1;
+    const PoolPixel p0 = pool_pixel<BN>(p, pa, tc.col0, 0);
+    const int per_quad = pa.ph * pa.pw, items = (BM / 4) * per_quad, cw = 2 * pa.pw + 1;
     float4 *y4 = reinterpret_cast<float4 *>(p.y);
     for (int it = threadIdx.x; it < items; it += 256) {
         unsigned ql, pp, py, px;
-        p.pool.divPerQuad.divmod((unsigned)it, ql, pp);
-        p.pool.divPw.divmod(pp, py, px);
-        const int oy = p0.PY * p.pool.ph + (int)py, ox = p0.PX * p.pool.pw + (int)px;
-        if (oy >= p.pool.Hp || ox >= p.pool.Wp || tc.m0 + (int)ql * 4 >= p.cout_g) continue;
+        pa.divPerQuad.divmod((unsigned)it, ql, pp);
+        pa.divPw.divmod(pp, py, px);
+        const int oy = p0.PY * pa.ph + (int)py, ox = p0.PX * pa.pw + (int)px;
+        if (oy >= pa.Hp || ox >= pa.Wp || tc.m0 + (int)ql * 4 >= p.cout_g) continue;
         const float4 *sp = stage + ql * BN + (2 * py) * cw + 2 * px;
         float4 m = make_float4(-1e4f, -1e4f, -1e4f, -1e4f);
 #pragma unroll
@@ -283,7 +283,7 @@ __device__ __forceinline__ void pool_tile_q4(const ConvArgs &p, const TileCoord 
                 m = make_float4(fmaxf(v.x, m.x), fmaxf(v.y, m.y), fmaxf(v.z, m.z), fmaxf(v.w, m.w));
             }
         const unsigned coq = (unsigned)(((int)tc.g * p.cout_g + tc.m0) >> 2) + ql;
-        y4[(((size_t)p0.n * p.Coq + coq) * p.pool.Hp + oy) * p.pool.Wp + ox] = m;
+        y4[(((size_t)p0.n * p.Coq + coq) * pa.Hp + oy) * pa.Wp + ox] = m;
     }
 }
 
@@ -334,9 +334,8 @@ __global__ void __launch_bounds__(256) reduce_tiles_q4_kernel(const ConvArgs p, 
 
 // POOL: the tile's BN columns are one (2*ph+1) x (2*pw+1) patch of conv pixels (rows / columns overlap the
 // neighbouring patches by one), and the tail max-pools it 3x3 / stride 2 / pad 1 through LDS (pool_tile_q4).
-template <class C, bool POOL = false>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C::MIN_WAVES)))
-conv_q4_kernel(const ConvArgs p) {
+template <class C, bool POOL>
+__device__ __forceinline__ void conv_q4_body(const ConvArgs &p, const PoolArgs *pap) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;                         // [2][KG][BM][4]
     float *Bs = smem + 2 * C::A_ELEMS;        // [2][KG][BN][4]
@@ -369,7 +368,7 @@ conv_q4_kernel(const ConvArgs p) {
     bool jok = j < p.cols && (C::B_ALL_ACTIVE || kg0 < C::KG);
     int hbase = -(1 << 20), wbase = 0, cbase = 0, j_n = 0;
     if constexpr (POOL) {
-        const PoolPixel pp = pool_pixel<C::BN>(p, col0, jl);
+        const PoolPixel pp = pool_pixel<C::BN>(p, *pap, col0, jl);
         jok = pp.ok && (C::B_ALL_ACTIVE || kg0 < C::KG);
         if (jok) {
             hbase = pp.ho * p.sh - p.pt;
@@ -605,9 +604,21 @@ conv_q4_kernel(const ConvArgs p) {
         __syncthreads();
     }
     if constexpr (POOL)
-        pool_tile_q4<C::BM, C::BN, C::TM, C::TN, C::WTM, C::WTN>(p, tc, acc, wm, wn, lane, smem);
+        pool_tile_q4<C::BM, C::BN, C::TM, C::TN, C::WTM, C::WTN>(p, *pap, tc, acc, wm, wn, lane, smem);
     else
         store_tile_q4<C::BM, C::BN, C::TM, C::TN, C::WTM, C::WTN>(p, tc, acc, wm, wn, lane, smem);
+}
+
+template <class C>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C::MIN_WAVES)))
+conv_q4_kernel(const ConvArgs p) {
+    conv_q4_body<C, false>(p, nullptr);
+}
+
+template <class C>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C::MIN_WAVES)))
+conv_q4_pool_kernel(const ConvArgs p, const PoolArgs pa) {
+    conv_q4_body<C, true>(p, &pa);
 }
 
 // OIHW [g*cout_g + co][cin_g][tap]  ->  wq[g][q][co][4], q = tap*cqg + cin/4 (zero padded to Qpad

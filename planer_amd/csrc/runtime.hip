@@ -98,6 +98,12 @@ int pl_ctx_info(pl_ctx *ctx, int *device, int *cu_count, size_t *hbm_bytes,
     return PL_OK;
 }
 
+int pl_ctx_pci_bus_id(pl_ctx *ctx, char *bus_id, size_t len) {
+    PL_REQUIRE(ctx && bus_id && len >= 16, PL_EINVAL, "pl_ctx_pci_bus_id: need a buffer of 16 bytes or more");
+    PL_HIP(hipDeviceGetPCIBusId(bus_id, (int)len, ctx->device));
+    return PL_OK;
+}
+
 int pl_sync(pl_ctx *ctx) {
     PL_REQUIRE(ctx, PL_EINVAL, "null ctx");
     CtxGuard g(ctx);
@@ -230,6 +236,13 @@ int pl_event_record(pl_ctx *ctx, pl_event *ev) {
     PL_REQUIRE(ctx && ev, PL_EINVAL, "pl_event_record: null argument");
     CtxGuard g(ctx);
     PL_HIP(hipEventRecord(ev->ev, ctx->stream));
+    return PL_OK;
+}
+
+int pl_event_sync(pl_event *ev) {
+    PL_REQUIRE(ev, PL_EINVAL, "pl_event_sync: null argument");
+    CtxGuard g(ev->ctx);
+    PL_HIP(hipEventSynchronize(ev->ev));
     return PL_OK;
 }
 

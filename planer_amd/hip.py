@@ -48,6 +48,12 @@ class Context:
         if path:
             _lib.call("pl_tune_cache_save", self.handle, path.encode())
 
+    def pci_bus_id(self):
+        """'0000:c1:00.0'-style id of this context's GPU (the key of /sys/bus/pci/devices/)."""
+        buf = ctypes.create_string_buffer(32)
+        _lib.call("pl_ctx_pci_bus_id", self.handle, buf, 32)
+        return buf.value.decode().lower()
+
     def synchronize(self):
         _lib.call("pl_sync", self.handle)
 
@@ -116,6 +122,11 @@ class Event:
 
     def record(self):
         _lib.call("pl_event_record", self.ctx.handle, self.handle)
+        return self
+
+    def synchronize(self):
+        """Host waits for the recorded point (and nothing after it)."""
+        _lib.call("pl_event_sync", self.handle)
         return self
 
     def elapsed_ms(self, stop):

@@ -68,6 +68,10 @@ class _Plan:
         self.inputs, self.outputs, self.graph, self.ctx = inputs, outputs, graph, ctx
         self.fused_steps, self.ms, self.streams = fused_steps, None, "1x1"
         self.algos = []              # per conv step: kernel family + launch plan (filled by Net._capture)
+        # bounded host run-ahead: launch k waits (on the host) for launch k - max_in_flight of this plan's stream.
+        # A free-running loop otherwise queues every batch it is asked for at once; eight batches keep the GPU fed
+        # for milliseconds, and tools that intercept dispatches (rocprofv3) crash with ~2000 of them outstanding.
+        self.max_in_flight, self._ring = 8, []
 
     def feed(self, xs):
         """Copy new inputs into the plan's static input buffers (on the plan's stream)."""
@@ -77,6 +81,13 @@ class _Plan:
 
     def launch(self, join=True):
         _lib.call("pl_graph_launch", self.graph)
+        if self.max_in_flight:
+            if len(self._ring) >= self.max_in_flight:
+                ev = self._ring.pop(0)
+                ev.synchronize()
+            else:
+                ev = hip.Event(self.ctx)
+            self._ring.append(ev.record())
 
     def join(self):
         pass
