@@ -178,7 +178,7 @@ int pl_conv2d_rowpack_q4_f32(pl_ctx *ctx, const float *x, int N, int Cin, int H,
  * max-pooled through LDS (zero padding, -1e4 start, the reference's tap order) and yq is the POOLED Q4 tensor
  * (N, Cout, (Ho+1)/2, (Wo+1)/2): the full-resolution conv output never reaches HBM.  No residual.  Emitted by the
  * plan compiler for conv -> [batchnorm] -> [relu] -> maxpool chains (ResNet's stem); results are bit-identical to
- * pl_conv2d_q4_f32 / pl_conv2d_rowpack_q4_f32 followed by pl_pool2d_q4_f32. */
+ * pl_conv2d_q4_f32 / pl_conv2d_rowpack_q4_f32 (on an unsplit launch plan: same K order) followed by pl_pool2d_q4_f32. */
 int pl_conv2d_pool_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const float *wq, int Cout, int kh,
                           int kw, const float *bias, float *yq, int sh, int sw, int dh, int dw, int pt, int pl, int group,
                           const float *scale, const float *shift, int act, double alpha);
