@@ -153,3 +153,22 @@ def test_random_pointwise_layers_nchw_and_q4_are_bit_exact(pa, seed):
     np.testing.assert_array_equal(q4.from_q4(q4.BatchNormQ4(xq, pa.asarray(sc), pa.asarray(sh))).get(), bn)
     np.testing.assert_array_equal(q4.from_q4(q4.LeakyReLUQ4(q4.to_q4(pa.asarray(x)), alpha=0.1)).get(), onp.leakyrelu(x, 0.1))
     np.testing.assert_array_equal(q4.from_q4(q4.ReLUQ4(q4.to_q4(pa.asarray(x)))).get(), onp.relu(x.copy()))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_dense_small_batch_and_general(pa, seed):
+    """layer.Dense on random (batch, K, N): batches up to 64 with K % 8 == 0 take the dedicated small-batch MFMA kernel,
+    everything else the implicit-GEMM path; both against the oracle, with and without bias."""
+    r = np.random.default_rng(9000 + seed)
+    m = int(r.choice([1, 2, 5, 31, 32, 33, 64, 65, 100]))
+    k = int(r.choice([64, 72, 96, 512, 1000, 1024, 77]))
+    n = int(r.choice([10, 32, 33, 40, 255, 1000, 1031]))
+    x = r.standard_normal((m, k)).astype(np.float32)
+    W = (r.standard_normal((n, k)) * 0.1).astype(np.float32)
+    B = r.standard_normal(n).astype(np.float32)
+    y = pa.Dense(pa.asarray(x), pa.asarray(W), pa.asarray(B)).get()
+    plan = pa.hip.context().last_conv_plan()
+    assert ("dense32x32" in plan) == (m <= 64 and n >= 32 and k % 8 == 0), (plan, m, k, n)
+    assert_close(y, onp.dense(x, W, B), RTOL, "dense %s [%s]" % ((m, k, n), plan))
+    again = pa.Dense(pa.asarray(x), pa.asarray(W), pa.asarray(B)).get()
+    np.testing.assert_array_equal(y, again)              # fixed summation order
