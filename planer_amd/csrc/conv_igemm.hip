@@ -1751,7 +1751,7 @@ __global__ void __launch_bounds__(256) wino4_output_q4_kernel(const float4 *M, f
             for (int b = 0; b < 4; ++b) {
                 const float4 v = apply_epilogue4(p.ep, bias, scale, shift, rs[a][b], 4, o[b]);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
-                                                       yrsrc, off[a][b], 0, 0);
+                                                       yrsrc, off[a][b], 0, PLANER_STORE_AUX);
             }
         }
     }
@@ -1868,7 +1868,7 @@ __device__ __forceinline__ void wino4_output_row(const float4 *M, const WinoArgs
         for (int b = 0; b < 4; ++b) {
             const float4 v = apply_epilogue4(p.ep, bias, scale, shift, rs[b], 4, o[b]);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
-                                                   yrsrc, off[b], 0, 0);
+                                                   yrsrc, off[b], 0, PLANER_STORE_AUX);
         }
     }
 }

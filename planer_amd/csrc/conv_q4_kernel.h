@@ -165,7 +165,7 @@ __device__ __forceinline__ void store_tile_q4(const ConvArgs &p, const TileCoord
                         make_float4(acc[a][b][4 * rq], acc[a][b][4 * rq + 1], acc[a][b][4 * rq + 2], acc[a][b][4 * rq + 3]);
                     const float4 o = apply_epilogue4(p.ep, bias, scale, shift, rs[rq][b], valid, v);
                     __builtin_amdgcn_raw_buffer_store_b128(
-                        __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o), yrsrc, off[rq][b], 0, 0);
+                        __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o), yrsrc, off[rq][b], 0, PLANER_STORE_AUX);
                 }
             }
         }

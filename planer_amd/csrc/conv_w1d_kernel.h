@@ -432,7 +432,7 @@ conv_w1d4_kernel(const ConvArgs p) {
         for (int b = 0; b < 4; ++b) {
             const float4 v = apply_epilogue4(p.ep, bias, scale, shift, rs[rq][b], valid, make_float4(o[b][0], o[b][1], o[b][2], o[b][3]));
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
-                                                   yrsrc, off[rq][b], 0, 0);
+                                                   yrsrc, off[rq][b], 0, PLANER_STORE_AUX);
         }
     }
 }
