@@ -1122,15 +1122,19 @@ int conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const
     CtxGuard guard(ctx);
 
     // 1..4 input channels, 3x3 / stride 1, plain NCHW conv (+bias): the store-stream kernel of
-    // conv_smallcin_kernel.h (BASELINE config 2).  Measured 45-50 us on (8,3,224,224)->64 against 47 us for the
-    // generic kernel below (both ~2.2 TB/s of the 7 TB/s a memset reaches), so it is opt-in: PLANER_HIP_SMALLCIN=1
+    // conv_smallcin_kernel.h (BASELINE config 2).  40 us on (8,3,224,224)->64 against 47 us for the generic kernel
+    // below (0.34 against 0.29 of 8 TB/s) once a workgroup takes four tiles; on small outputs its staging pass makes it
+    // slower than the generic kernel, so it takes over from ~3 tiles per CU upwards.  PLANER_HIP_SMALLCIN=0 / 1 forces.
+    const char *sc_env = getenv("PLANER_HIP_SMALLCIN");
+    const int sc_cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
+    const bool sc_big = (long long)N * ((Ho * Wo + SC_PIX - 1) / SC_PIX) * ((Cout + SC_CO - 1) / SC_CO) >= 3LL * sc_cus;
     if (layout == 0 && kh == 3 && kw == 3 && sh == 1 && sw == 1 && dh == 1 && dw == 1 && group == 1 && Cin <= 4 &&
-        pt == pl && pt <= 1 && !scale && !shift && !res && act == PL_ACT_NONE && ctx->conv_cfg < 0 &&
-        getenv("PLANER_HIP_SMALLCIN") && atoi(getenv("PLANER_HIP_SMALLCIN")) != 0) {
-        // 256-pixel tiles per workgroup: as many as keep ~2.5 workgroups per CU in flight and the staged rows in 64 KB
-        const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
+        pt == pl && pt <= 1 && !scale && !shift && !res && act == PL_ACT_NONE && ctx->conv_cfg < 0 && out_elems < (1ull << 29) &&
+        (sc_env ? atoi(sc_env) != 0 : sc_big)) {
+        // 256-pixel tiles per workgroup: as many as keep ~1.5 workgroups per CU in flight and the staged rows in 64 KB
+        const int cus = sc_cus;
         const int tiles_img = (Ho * Wo + SC_PIX - 1) / SC_PIX, co_blocks = (Cout + SC_CO - 1) / SC_CO;
-        int tpw = std::max(1, std::min(8, (int)((long long)tiles_img * co_blocks * N / (cus * 5 / 2))));
+        int tpw = std::max(1, std::min(8, (int)((long long)tiles_img * co_blocks * N / (cus * 3 / 2))));
         auto lds_for = [&](int t) {
             const int rows_max = (SC_PIX * t + Wo - 1) / Wo + 3;
             return ((size_t)SC_MAXK * SC_CO + SC_CO + 4 + (size_t)Cin * rows_max * (W + 2)) * sizeof(float);
@@ -1142,6 +1146,7 @@ int conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const
             sa.x = x; sa.w = w; sa.bias = bias; sa.y = y;
             sa.N = N; sa.Cin = Cin; sa.H = H; sa.W = W; sa.Cout = Cout; sa.Ho = Ho; sa.Wo = Wo; sa.pad = pt;
             sa.x_bytes = (int)(in_elems * 4);
+            sa.y_bytes = (int)(out_elems * 4);
             sa.HoWo = Ho * Wo; sa.Wp = W + 2; sa.K = Cin * 9; sa.steps = (sa.K + 1) / 2; sa.tpw = tpw;
             sa.divWo = FastDiv(Wo); sa.divK = FastDiv(sa.K);
             int rc = ensure_lds_attr((const void *)conv_smallcin_nchw_kernel, 64 * 1024);

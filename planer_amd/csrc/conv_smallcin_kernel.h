@@ -16,7 +16,7 @@ struct SmallCinArgs {
     const float *x, *w, *bias;
     float *y;
     int N, Cin, H, W, Cout, Ho, Wo, pad;
-    int x_bytes;
+    int x_bytes, y_bytes;
     int HoWo, Wp, K, steps;          // Wp = W + 2: every staged row carries one zero column at each end
     int tpw;                         // 256-pixel tiles per workgroup (filter and input rows are staged once for all of them)
     FastDiv divWo, divK;
@@ -94,54 +94,90 @@ __global__ void __launch_bounds__(256) conv_smallcin_nchw_kernel(const SmallCinA
         koff[s] = k < p.K ? (c * rows + dy) * p.Wp + dx : -1;
     }
     __syncthreads();
-    for (int t = 0; t < p.tpw; ++t) {
-        const int pt0 = pw0 + t * SC_PIX;
-        if (pt0 >= p.HoWo) break;
-        // this wave's pixels: two blocks of 32
+    // ---- tiles, software-pipelined: the stores of tile t-1 (64 per lane) are issued in 16 groups of four
+    //      between the MFMA steps of tile t, out of the other accumulator set -- the write stream (3.3 us per tile
+    //      per CU at 5 TB/s) and the matrix pipe (1.5 us) overlap inside every wave instead of adding up
+    //      chip-wide when all workgroups reach the same phase together ----
+    // the lane's 32 bias values live in registers: an LDS read per store group would put an lgkmcnt wait -- which
+    // is in-order, so it also waits for the operand reads of the MFMA steps ahead -- in front of every group
+    float bias_r[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) bias_r[i] = Bs[(i >> 4) * 32 + (i & 3) + 8 * ((i & 15) >> 2) + 4 * lhi];
+    struct TileAt {
         int pbase[2];
-        bool pok[2];
+        int yoff[2];                 // byte offset of (channel co0, this lane's pixel) in y, out of range when masked
+        bool live;
+    };
+    constexpr int YOOB = (int)0x80000000;
+    // y goes through a buffer descriptor: a store of a masked lane gets an out-of-range offset and is dropped --
+    // no branch per store (a predicated plain store costs a branch each and serialises the tail)
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+    auto locate = [&](int t) {
+        TileAt ta;
+        const int pt0 = pw0 + t * SC_PIX;
+        ta.live = t < p.tpw && pt0 < p.HoWo;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const int pix = pt0 + wave * 64 + b * 32 + l31;
-            pok[b] = pix < p.HoWo;
+            const bool ok = ta.live && pix < p.HoWo;
             unsigned ho, wo;
-            p.divWo.divmod((unsigned)(pok[b] ? pix : p0), ho, wo);
-            pbase[b] = ((int)ho - r0) * p.Wp + (int)wo;   // staged (row ho-r0, column wo) = image (ho-pad, wo-pad)
+            p.divWo.divmod((unsigned)(ok ? pix : p0), ho, wo);
+            ta.pbase[b] = ((int)ho - r0) * p.Wp + (int)wo;   // staged (row ho-r0, column wo) = image (ho-pad, wo-pad)
+            ta.yoff[b] = ok ? (int)((((unsigned)(n * p.Cout + co0)) * (unsigned)p.HoWo + (unsigned)pix) << 2) : YOOB;
         }
-        f32x16 acc[2][2];
+        return ta;
+    };
+    auto zero = [&](f32x16 (&acc)[2][2]) {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    };
+    auto mma_step = [&](f32x16 (&acc)[2][2], const TileAt &ta, int s2) {
+        const float a0 = As[(2 * s2 + lhi) * SC_CO + l31], a1 = As[(2 * s2 + lhi) * SC_CO + 32 + l31];
+        const float b0 = Ps[koff[s2] >= 0 ? ta.pbase[0] + koff[s2] : -1];      // K padding reads the zero slot
+        const float b1 = Ps[koff[s2] >= 0 ? ta.pbase[1] + koff[s2] : -1];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    };
+    // bias + store, group g of 16: accumulator rows 2g, 2g+1 of both 32-channel blocks... lanes = consecutive pixels of
+    // one channel plane -> full 128-byte lines
+    auto store_group = [&](const f32x16 (&acc)[2][2], const TileAt &ta, int g) {
 #pragma unroll
-        for (int s = 0; s < SC_MAXK / 2; ++s) {
-            if (s < p.steps) {
-                const float a0 = As[(2 * s + lhi) * SC_CO + l31], a1 = As[(2 * s + lhi) * SC_CO + 32 + l31];
-                const float b0 = Ps[koff[s] >= 0 ? pbase[0] + koff[s] : -1];      // K padding reads the zero slot
-                const float b1 = Ps[koff[s] >= 0 ? pbase[1] + koff[s] : -1];
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        for (int q = 0; q < 2; ++q) {
+            const int idx = 2 * g + q, a = idx >> 4, r = idx & 15;
+            const int co = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            const bool cok = co0 + co < p.Cout;
+            const float bv = bias_r[idx];
+            const int plane = (co * p.HoWo) << 2;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const float v = acc[a][b][r];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, p.bias ? __fadd_rn(v, bv) : v), yrsrc,
+                                                      (cok && ta.yoff[b] != YOOB) ? ta.yoff[b] + plane : YOOB, 0, 0);
             }
         }
-        // ---- bias + store: lanes = consecutive pixels of one channel plane -> full 128-byte lines ----
-        float *yb = p.y + ((size_t)n * p.Cout + co0) * p.HoWo + pt0 + wave * 64 + l31;
+    };
+    f32x16 acc0[2][2], acc1[2][2];
+    TileAt cur = locate(0), prev = cur;
+    prev.live = false;
+    auto run_tile = [&](f32x16 (&acc)[2][2], const f32x16 (&old)[2][2]) {       // tile `cur` into acc, tile `prev` out of old
+        zero(acc);
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                if (co0 + co >= p.Cout) continue;
-                const float bv = Bs[co];
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-                    if (pok[b]) {
-                        const float v = acc[a][b][r];
-                        yb[(size_t)co * p.HoWo + b * 32] = p.bias ? __fadd_rn(v, bv) : v;
-                    }
-            }
+        for (int s2 = 0; s2 < SC_MAXK / 2; ++s2) {
+            if (s2 < p.steps && cur.live) mma_step(acc, cur, s2);
+            if (s2 < 16 && prev.live) store_group(old, prev, s2);
+        }
+    };
+    for (int t = 0; t <= p.tpw; t += 2) {
+        run_tile(acc0, acc1);
+        prev = cur; cur = locate(t + 1);
+        run_tile(acc1, acc0);
+        prev = cur; cur = locate(t + 2);
+        if (!prev.live && !cur.live) break;
     }
 }

@@ -274,7 +274,7 @@ def test_empty_and_ragged(pa):
 
 
 def test_small_cin_store_stream_kernel_matches_oracle(pa, monkeypatch):
-    """conv_smallcin_nchw_kernel (opt-in, PLANER_HIP_SMALLCIN=1): 3x3 / stride 1 on 1..4 input channels, the
+    """conv_smallcin_nchw_kernel (forced here with PLANER_HIP_SMALLCIN=1; by default it serves big outputs only): 3x3 / stride 1 on 1..4 input channels, the
     BASELINE config-2 shape class -- ragged widths, pad 0 / 1, channel counts that are not multiples of 64."""
     monkeypatch.setenv("PLANER_HIP_SMALLCIN", "1")
     rng = np.random.default_rng(77)
