@@ -1135,6 +1135,37 @@ int conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const
         const int cus = sc_cus;
         const int tiles_img = (Ho * Wo + SC_PIX - 1) / SC_PIX, co_blocks = (Cout + SC_CO - 1) / SC_CO;
         int tpw = std::max(1, std::min(8, (int)((long long)tiles_img * co_blocks * N / (cus * 3 / 2))));
+        // producer/consumer variant (conv_smallcin_pc_kernel): one 512-thread workgroup per CU, MFMA waves and store waves
+        // (opt-in, PLANER_HIP_SMALLCIN_PC=1: 33.6 against 40 us for one launch, but 30.3 against 27.4 us per batch when three
+        //  streams pipeline -- a workgroup that owns its CU's LDS leaves the other streams nothing to interleave with)
+        const char *scp_env = getenv("PLANER_HIP_SMALLCIN_PC");
+        if ((Ho * Wo) % 4 == 0 && scp_env && atoi(scp_env) != 0) {
+            const long long total_tiles = (long long)tiles_img * co_blocks * N;
+            int t7 = (int)std::max<long long>(1, (total_tiles + cus - 1) / cus);          // one round of workgroups
+            auto lds_pc = [&](int t) {
+                const int rows_max = (SC_PIX * t + Wo - 1) / Wo + 3;
+                return ((size_t)SC_MAXK * SC_CO + SC_CO + 4 + 60 + 2 * SC_CO * SCP_PIX + 4 + (size_t)Cin * rows_max * (W + 2)) * sizeof(float);
+            };
+            while (t7 > 1 && lds_pc(t7) > 156 * 1024) --t7;
+            if (lds_pc(t7) <= 156 * 1024) {
+                SmallCinArgs sa;
+                sa.x = x; sa.w = w; sa.bias = bias; sa.y = y;
+                sa.N = N; sa.Cin = Cin; sa.H = H; sa.W = W; sa.Cout = Cout; sa.Ho = Ho; sa.Wo = Wo; sa.pad = pt;
+                sa.x_bytes = (int)(in_elems * 4);
+                sa.y_bytes = (int)(out_elems * 4);
+                sa.HoWo = Ho * Wo; sa.Wp = W + 2; sa.K = Cin * 9; sa.steps = (sa.K + 1) / 2; sa.tpw = t7;
+                sa.divWo = FastDiv(Wo); sa.divK = FastDiv(sa.K);
+                void (*kern)(const SmallCinArgs) = Cin == 1 ? conv_smallcin_pc_kernel<5> : Cin == 2 ? conv_smallcin_pc_kernel<9>
+                                                   : Cin == 3 ? conv_smallcin_pc_kernel<14> : conv_smallcin_pc_kernel<18>;
+                int rc = ensure_lds_attr((const void *)kern, 156 * 1024);
+                if (rc != PL_OK) return rc;
+                hipLaunchKernelGGL(kern, dim3((unsigned)((tiles_img + t7 - 1) / t7), (unsigned)co_blocks, (unsigned)N), dim3(512),
+                                   lds_pc(t7), ctx->stream, sa);
+                PL_LAUNCH_CHECK();
+                ctx->last_plan = "smallcin3x3pc " + std::to_string(t7) + "x256px x 64co";
+                return PL_OK;
+            }
+        }
         auto lds_for = [&](int t) {
             const int rows_max = (SC_PIX * t + Wo - 1) / Wo + 3;
             return ((size_t)SC_MAXK * SC_CO + SC_CO + 4 + (size_t)Cin * rows_max * (W + 2)) * sizeof(float);

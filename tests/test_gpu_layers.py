@@ -286,3 +286,26 @@ def test_small_cin_store_stream_kernel_matches_oracle(pa, monkeypatch):
         y = pa.Conv2d(pa.asarray(x), pa.asarray(k), pa.asarray(b) if bias else None, pads=[pad] * 4)
         assert pa.hip.context().last_conv_plan().startswith("smallcin3x3")
         assert_close(y.get(), np.ascontiguousarray(onp.conv2d(x, k, b, pads=[pad] * 4)), RTOL, str((n, c, h, w, co)))
+
+
+def test_small_cin_producer_consumer_kernel_matches_oracle(pa, monkeypatch):
+    """conv_smallcin_pc_kernel (opt-in, PLANER_HIP_SMALLCIN_PC=1): MFMA waves and store waves of one 512-thread
+    workgroup hand half tiles over through LDS; maps whose Ho*Wo is a multiple of 4, every Cin 1..4, ragged channel
+    counts, several tiles per workgroup, bias / no bias; config 2 at full size bit-equal to the one-role kernel."""
+    monkeypatch.setenv("PLANER_HIP_SMALLCIN", "1")
+    rng = np.random.default_rng(78)
+    for n, c, h, w, co, pad, bias in [(3, 4, 17, 16, 64, 1, True), (2, 2, 40, 7, 130, 1, True), (2, 3, 64, 64, 64, 1, False),
+                                      (1, 1, 6, 302, 70, 0, True), (3, 3, 50, 46, 20, 1, True), (8, 3, 224, 224, 64, 1, True)]:
+        x = rng.standard_normal((n, c, h, w)).astype(np.float32)
+        k = (rng.standard_normal((co, c, 3, 3)) * 0.1).astype(np.float32)
+        b = rng.standard_normal(co).astype(np.float32) if bias else None
+        args = (pa.asarray(x), pa.asarray(k), pa.asarray(b) if bias else None)
+        monkeypatch.setenv("PLANER_HIP_SMALLCIN_PC", "1")
+        y = pa.Conv2d(*args, pads=[pad] * 4).get()
+        assert pa.hip.context().last_conv_plan().startswith("smallcin3x3pc"), pa.hip.context().last_conv_plan()
+        monkeypatch.setenv("PLANER_HIP_SMALLCIN_PC", "0")
+        y1 = pa.Conv2d(*args, pads=[pad] * 4).get()
+        assert pa.hip.context().last_conv_plan().startswith("smallcin3x3 ")
+        np.testing.assert_array_equal(y, y1)             # same k order, same bias add
+        if n * h * w <= 20000:
+            assert_close(y, np.ascontiguousarray(onp.conv2d(x, k, b, pads=[pad] * 4)), RTOL, str((n, c, h, w, co)))
