@@ -155,6 +155,9 @@ def load(path=None):
             "libplaner_hip.so not found at %s -- build it with "
             "`python -m planer_amd._build` (needs hipcc, gfx950). "
             "planer_amd has no CPU fallback." % path)
+    # multi-process RCCL on this driver stack needs dmabuf IPC (the legacy path fails with hipIpcGetMemHandle: invalid
+    # argument); must be in the environment before the HSA runtime comes up, i.e. before the first HIP call
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     lib = ctypes.CDLL(path)
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if a symbol is missing
