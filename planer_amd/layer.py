@@ -843,6 +843,8 @@ def Scatternd(data, indices, updates):
     iv = numpy.asarray(_host_values(indices))
     if iv.ndim < 2:
         raise IndexError("scatternd: indices need at least 2 dimensions, got shape %s" % (iv.shape,))
+    if len(iv[0]) == 0:
+        return data.copy()                                            # the reference's loop body never runs
     idx = iv[0].reshape(len(iv[0]), -1).astype(numpy.int64)          # (n, k)
     n, k = idx.shape
     if k > data.ndim:

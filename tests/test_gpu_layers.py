@@ -309,3 +309,50 @@ def test_small_cin_producer_consumer_kernel_matches_oracle(pa, monkeypatch):
         np.testing.assert_array_equal(y, y1)             # same k order, same bias add
         if n * h * w <= 20000:
             assert_close(y, np.ascontiguousarray(onp.conv2d(x, k, b, pads=[pad] * 4)), RTOL, str((n, c, h, w, co)))
+
+
+def test_sorting_and_data_dependent_ops_edge_cases(pa):
+    """TopK with NaNs / repeated values / k = n / long rows, NonZero with nothing, everything and NaN, ScatterND with
+    no updates, LSTM with a single step -- against numpy's own answers."""
+    rng = np.random.default_rng(91)
+    topk, nonzero, scat, lstm = (pa.layer_map[k] for k in ("topk", "nonzero", "scatternd", "lstm"))
+    # NaN sorts last (numpy): with largest=1 the NaNs come first, then the greatest finite values
+    x = rng.standard_normal((3, 37)).astype(np.float32)
+    x[0, 5] = x[2, 0] = x[2, 36] = np.nan
+    v, i = topk(pa.asarray(x), np.array([4]))
+    want_v, want_i = onp.topk(x, np.array(4))
+    np.testing.assert_array_equal(v.get(), want_v)
+    np.testing.assert_array_equal(x[np.arange(3)[:, None], i.get()], want_v)          # indices point at those values
+    # repeated values: the values agree with numpy, the indices point at equal values and are all different
+    y = np.round(rng.standard_normal((2, 300)) * 2).astype(np.float32)
+    v, i = topk(pa.asarray(y), np.array([300]))                                        # k = n: a full sort
+    np.testing.assert_array_equal(v.get(), np.sort(y, axis=-1)[:, ::-1])
+    ii = i.get()
+    np.testing.assert_array_equal(np.take_along_axis(y, ii, -1), v.get())
+    assert all(len(set(row.tolist())) == 300 for row in ii)
+    # a row longer than the LDS sort holds, with duplicates of the maximum
+    z = rng.standard_normal(40000).astype(np.float32)
+    z[[7, 39999, 20000]] = 9.0
+    v, i = topk(pa.asarray(z), np.array([5]))
+    np.testing.assert_array_equal(v.get(), np.sort(z)[::-1][:5])
+    assert sorted(i.get()[:3].tolist()) == [7, 20000, 39999]
+    # NonZero: nothing, everything, NaN counts, bool input, one element
+    for a in (np.zeros((4, 5), np.float32), np.ones((3, 2, 2), np.float32), np.array([0.0, np.nan, -0.0, 1e-38], np.float32),
+              rng.standard_normal((70, 130)) > 2.5, np.array([3.0], np.float32)):
+        got = nonzero(pa.asarray(a)).get()
+        want = np.array(np.nonzero(a))
+        assert got.dtype == np.int64 and got.shape == want.shape
+        np.testing.assert_array_equal(got, want)
+    # ScatterND with an empty update list returns a copy
+    d = rng.standard_normal((3, 4)).astype(np.float32)
+    out = scat(pa.asarray(d), np.zeros((1, 0, 2), np.int64), pa.asarray(np.zeros((1, 0), np.float32)))
+    np.testing.assert_array_equal(out.get(), d)
+    # LSTM, one time step, batch 1
+    L, N, D, H = 1, 1, 5, 4
+    args = [rng.standard_normal(s).astype(np.float32) * 0.5 for s in ((L, N, D), (1, 4 * H, D), (1, 4 * H, H), (1, 8 * H))]
+    h0, c0 = rng.standard_normal((1, N, H)).astype(np.float32), rng.standard_normal((1, N, H)).astype(np.float32)
+    got = lstm(*[pa.asarray(a) for a in args], np.array([1]), pa.asarray(h0), pa.asarray(c0), hidden_size=H)
+    want = onp.lstm(*args, np.array([1]), h0, c0, hidden_size=H)
+    for g_, w_ in zip(got, want):
+        assert g_.shape == w_.shape
+        assert_close(g_.get(), w_, RTOL, "lstm one step")
