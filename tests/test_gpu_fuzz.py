@@ -172,3 +172,114 @@ def test_random_dense_small_batch_and_general(pa, seed):
     assert_close(y, onp.dense(x, W, B), RTOL, "dense %s [%s]" % ((m, k, n), plan))
     again = pa.Dense(pa.asarray(x), pa.asarray(W), pa.asarray(B)).get()
     np.testing.assert_array_equal(y, again)              # fixed summation order
+
+
+def _try(fn):
+    """An input a kernel does not cover must raise NotImplementedError / ValueError (never return something else)."""
+    try:
+        return fn()
+    except (NotImplementedError, ValueError):
+        return None
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_second_wave_ops_match_the_oracle(pa, seed):
+    """Slice / Pad / Tile / Expand / Transpose / Reshape / Squeeze / Unsqueeze / Split (pure data movement: bit-exact),
+    Softmax / LogSoftmax / Reduce* over random axes, Gather with random indices, Where / comparisons, ConvTranspose with
+    random stride / pad / dilation / output_padding -- random ranks and shapes, each against the oracle.  A combination
+    a kernel does not cover may raise; it may not return a different answer."""
+    r = np.random.default_rng(7000 + seed)
+    nd = int(r.integers(1, 5))
+    shape = tuple(int(v) for v in r.integers(1, 9, nd))
+    x = r.standard_normal(shape).astype(np.float32)
+    dx = lambda: pa.asarray(x.copy())
+    lm, O = pa.layer_map, onp.OPS
+    i64 = lambda *v: np.array(v, np.int64)
+
+    def same(kind, args, dargs, exact=True, **para):
+        try:
+            want = O[kind](*[a.copy() if isinstance(a, np.ndarray) else a for a in args], **para)
+        except ValueError:                     # a geometry the reference itself cannot run (e.g. an empty conv output)
+            return
+        got = _try(lambda: lm[kind](*dargs, **para))
+        if got is None:
+            return
+        wants = want if isinstance(want, (list, tuple)) else [want]
+        gots = got if isinstance(got, (list, tuple)) else [got]
+        assert len(wants) == len(gots), kind
+        for g_, w_ in zip(gots, wants):
+            g_ = g_.get() if hasattr(g_, "get") else np.asarray(g_)
+            assert g_.shape == np.asarray(w_).shape, (kind, g_.shape, np.asarray(w_).shape, para)
+            if exact:
+                np.testing.assert_array_equal(g_, w_, err_msg="%s %s %s" % (kind, shape, para))
+            else:
+                assert_close(g_, w_, RTOL, "%s %s %s" % (kind, shape, para))
+
+    # slice: random axes subset, negative / out-of-range bounds, negative steps
+    axes = sorted(r.choice(nd, int(r.integers(1, nd + 1)), replace=False).tolist())
+    st, en, sp = [], [], []
+    for a in axes:
+        step = int(r.choice([1, 1, 2, 3, -1, -2]))
+        lo, hi = int(r.integers(-shape[a] - 1, shape[a] + 2)), int(r.integers(-shape[a] - 1, shape[a] + 2))
+        st.append(lo); en.append(hi); sp.append(step)
+    sl = [i64(*st), i64(*en), i64(*axes), i64(*sp)]
+    same("slice", [x] + sl, [dx()] + sl)
+    # pad (constant), tile, expand
+    pads = i64(*r.integers(0, 3, 2 * nd).tolist())
+    same("pad", [x, pads], [dx(), pads], constant_value=float(r.integers(-2, 3)))
+    rep = i64(*r.integers(1, 4, nd).tolist())
+    same("tile", [x, rep], [dx(), rep])
+    ex_shape = [int(v) for v in r.integers(1, 4, int(r.integers(0, 2)))] + [s if r.random() < 0.7 else s for s in shape]
+    xe = x[tuple(slice(0, 1) if r.random() < 0.4 else slice(None) for _ in shape)]
+    same("expand", [xe, i64(*ex_shape)], [pa.asarray(np.ascontiguousarray(xe)), i64(*ex_shape)])
+    # transpose / reshape / squeeze / unsqueeze
+    perm = r.permutation(nd).tolist()
+    same("transpose", [x], [dx()], axis=perm)
+    same("reshape", [x, i64(-1)], [dx(), i64(-1)])
+    if nd >= 2:
+        same("reshape", [x, i64(0, -1)], [dx(), i64(0, -1)])
+    ux = int(r.integers(0, nd + 1))
+    same("unsqueeze", [x], [dx()], axes=[ux])
+    ones = [i for i, s in enumerate(shape) if s == 1]
+    if ones:
+        same("squeeze", [x], [dx()], axes=[ones[0]])
+    # split along a random axis (the reference's leading slice is along axis 0)
+    ax = int(r.integers(0, nd))
+    parts = []
+    left = shape[ax]
+    while left > 0:
+        p = int(r.integers(1, left + 1)); parts.append(p); left -= p
+    if sum(parts) <= shape[0]:
+        same("split", [x], [dx()], split=parts, axis=ax)
+    # softmax / logsoftmax / reductions
+    ax = int(r.integers(-nd, nd))
+    same("softmax", [x], [dx()], exact=False, axis=ax)
+    same("logsoftmax", [x], [dx()], exact=False, axis=ax)
+    red_axes = sorted(r.choice(nd, int(r.integers(1, nd + 1)), replace=False).tolist())
+    kd = bool(r.integers(0, 2))
+    for kind in ("reducesum", "reducemean"):
+        same(kind, [x], [dx()], exact=False, axes=red_axes, keepdims=kd)
+    for kind in ("reducemax", "reducemin"):
+        same(kind, [x], [dx()], axes=red_axes, keepdims=kd)
+    # gather, comparisons, where
+    ax = int(r.integers(0, nd))
+    idx = r.integers(-shape[ax], shape[ax], tuple(int(v) for v in r.integers(1, 4, int(r.integers(0, 3)))))
+    same("gather", [x, idx.astype(np.int64)], [dx(), idx.astype(np.int64)], axis=ax)
+    q = np.round(x)
+    y = np.round(r.standard_normal(shape)).astype(np.float32)
+    for kind in ("equal", "greater", "greaterorequal"):
+        same(kind, [q, y], [pa.asarray(q), pa.asarray(y)])
+    m = r.random(shape) > 0.5
+    same("where", [m, x, y], [pa.asarray(m), dx(), pa.asarray(y)])
+    same("where", [m, x, np.array([0.5], np.float32)], [pa.asarray(m), dx(), np.array([0.5], np.float32)])
+    # convtranspose: random geometry
+    n, ci, co = int(r.integers(1, 3)), int(r.choice([1, 3, 4, 8])), int(r.choice([1, 2, 5, 8]))
+    k = int(r.choice([1, 2, 3, 4]))
+    s_, d_ = int(r.choice([1, 2, 3])), int(r.choice([1, 1, 2]))
+    pd = int(r.integers(0, (k - 1) * d_ + 1))
+    op = int(r.integers(0, max(s_, d_)))
+    xt = r.standard_normal((n, ci, int(r.integers(1, 8)), int(r.integers(1, 8)))).astype(np.float32)
+    Kt = (r.standard_normal((ci, co, k, k)) * 0.3).astype(np.float32)
+    Bt = r.standard_normal(co).astype(np.float32)
+    para = dict(strides=[s_, s_], dilations=[d_, d_], pads=[pd] * 4, output_padding=[op, op])
+    same("convtranspose", [xt, Kt, Bt], [pa.asarray(xt), pa.asarray(Kt), pa.asarray(Bt)], exact=False, **para)
