@@ -199,7 +199,8 @@ class Net:
         self.use_fusion = os.environ.get("PLANER_HIP_FUSE", "1") != "0"
         self.profile = os.environ.get("PLANER_HIP_PROFILE", "0") == "1"
         # compiled plans keep activations channel-quad (Q4) between layers that have Q4 kernels
-        self.use_q4 = os.environ.get("PLANER_HIP_Q4", "1") != "0"
+        # "force": channel-quad layout wherever a Q4 kernel exists, whatever the conversion-cost estimate says (tests)
+        self.use_q4 = {"0": False, "force": "force"}.get(os.environ.get("PLANER_HIP_Q4", "1"), True)
         # streams: how many sub-batch graphs a forward pass is fanned out to ("auto" measures 1/2/4)
         self.streams = os.environ.get("PLANER_HIP_STREAMS", "auto")
         self._side = []
@@ -358,7 +359,7 @@ class Net:
         else:
             body, flow, nfused = [list(b) for b in self.layer], [list(f) for f in self.flow], 0
         if self.use_q4:
-            body, flow, _ = assign_layouts(body, flow, self.inits, shapes)
+            body, flow, _ = assign_layouts(body, flow, self.inits, shapes, force=self.use_q4 == "force")
         if os.environ.get("PLANER_HIP_TAPMAJOR", "1") != "0":
             body, flow = self._prepare_filters(body, flow, shapes)
         return _Program(body, flow), nfused

@@ -196,3 +196,56 @@ def test_layouts_lone_conv_with_a_large_output_stays_nchw():
     assert nq4 == 0 and [b_[1] for b_ in body] == ["conv"] and out == [[["x", "K", "B"], ["c"], "y"]]
     body, out, nq4 = assign_layouts(layers, flow, ["K", "B"], shp, force=True)
     assert nq4 == 1 and len(out) == 2 and body[0][2].get("rowpack")           # conv (NCHW in) + from_q4
+
+
+# ---- random graphs: the plan compiler's rewrites keep the meaning of the flow (CPU, numpy stand-ins for the kernels) ----
+def _q4_standins():
+    """numpy stand-ins for the plan-internal kinds: a layout conversion is a COPY (the Q4 tensor is another buffer, so
+    an in-place ReLU on one side must not leak to the other unless the plan says so), a *_q4 layer is its NCHW op."""
+    ops = {"to_q4": lambda x: x.copy(), "from_q4": lambda x: x.copy(),
+           "conv_q4": lambda x, K, B=None, scale=None, shift=None, res=None, rowpack=False, w_layout=2, **kw:
+               conv_fused_np(x, K, B, scale, shift, res, **kw),
+           "conv_fused": conv_fused_np}
+    for kind in ("maxpool", "averagepool", "gap", "upsample", "batchnorm", "relu", "leakyrelu", "sigmoid", "add", "concat"):
+        ops[kind + "_q4"] = onp.OPS[kind]
+    return ops
+
+
+def _run(graph, blob, x, body, flow):
+    saved = dict(onp.OPS)
+    onp.OPS.update(_q4_standins())
+    try:
+        net = onp.OracleNet()
+        net.load_json(graph["input"], graph["inits"], body, flow)
+    finally:
+        onp.OPS.clear()
+        onp.OPS.update(saved)
+    net.load_weights(blob)
+    out = net(x)
+    return out if isinstance(out, tuple) else (out,)
+
+
+def test_random_graphs_fusion_and_layout_assignment_preserve_the_flow():
+    import pytest
+    from tests.random_nets import random_net
+    fused_total = q4_total = 0
+    for seed in range(150):
+        g, b, xs = random_net(40000 + seed)
+        x = xs[0]
+        shapes = shapes_of(g, b, x)
+        inits = [i[0] for i in g["inits"]]
+        want = _run(g, b, x.copy(), g["layers"], g["flow"])
+        body, flow, nf = fuse_flow(g["layers"], g["flow"], inits, shapes)
+        got = _run(g, b, x.copy(), body, flow)
+        body2, flow2, _ = assign_layouts(body, flow, inits, shapes)
+        got2 = _run(g, b, x.copy(), body2, flow2)
+        body3, flow3, nq4 = assign_layouts(body, flow, inits, shapes, force=True)     # tiny maps: the cost model says no
+        got3 = _run(g, b, x.copy(), body3, flow3)
+        fused_total += nf
+        q4_total += nq4
+        for what, outs in (("fused", got), ("fused + layouts", got2), ("fused + forced layouts", got3)):
+            assert len(outs) == len(want)
+            for o, w in zip(outs, want):
+                assert o.shape == w.shape, (seed, what)
+                assert_close(np.ascontiguousarray(o), np.ascontiguousarray(w), 1e-5, "seed %d %s" % (seed, what))
+    assert fused_total > 150 and q4_total > 300          # the generator does exercise both passes
