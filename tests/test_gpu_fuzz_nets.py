@@ -52,3 +52,39 @@ def test_random_network_plan_vs_oracle(pa, seed):
     quad.use_q4 = "force"                      # these maps are small: by its cost estimate the plan would often stay NCHW
     check(quad(xs[0].copy()), want0, "forced channel-quad plan")
     check(quad(xs[1].copy()), want1, "forced channel-quad plan, second input")
+
+
+@pytest.mark.parametrize("seed", range(0, 60, 3))
+def test_random_network_multi_stream_plans(pa, seed):
+    """The same random graphs through the multi-stream plans: sub-batch streams (the batch cut in two, each half its own
+    captured graph on its own stream) and the throughput pipeline (two whole-batch replicas used round robin)."""
+    g, blob, xs = random_net(40000 + seed)
+    ref = onp.OracleNet()
+    ref.load_json(g["input"], g["inits"], g["layers"], g["flow"])
+    ref.load_weights(blob)
+    want = [ref(x.copy()) for x in xs]
+    want = [w if isinstance(w, tuple) else (w,) for w in want]
+    n = xs[0].shape[0]
+    if n % 2 == 0:
+        net = pa.from_graph(g, blob)
+        net.streams = "2x2"
+        for x, w in zip(xs, want):
+            got = net(x.copy())
+            got = got if isinstance(got, tuple) else (got,)
+            for a, b in zip(got, w):
+                assert_close(a, np.ascontiguousarray(b), TOL, "2x2 seed %d" % seed)
+    net = pa.from_graph(g, blob)
+    net.streams = "pipe2"
+    dev = [pa.asarray(x) for x in xs]
+    plan = net.compile(dev[0], mode="throughput")
+    held = []
+    for d in dev:                                   # both replicas in flight
+        plan.feed([d])
+        plan.launch(join=False)
+        held.append(plan.outputs)
+    plan.join()
+    net.ctx.synchronize()
+    for h, w in zip(held, want):
+        h = h if isinstance(h, tuple) else (h,)
+        for a, b in zip(h, w):
+            assert_close(a.get(), np.ascontiguousarray(b), TOL, "pipe2 seed %d" % seed)
