@@ -641,6 +641,7 @@ __global__ void __launch_bounds__(256) permute_weights_kernel(const float *w, fl
 }
 
 #include "conv_q4_kernel.h"
+#include "conv_ks_kernel.h"
 #include "conv_pcg_kernel.h"
 #include "conv_smallcin_kernel.h"
 
@@ -691,6 +692,7 @@ struct CfgInfo {
     void (*reduce)(const ConvArgs, const float *, float *);
     void (*reduce4)(const ConvArgs, const float *, float *);
     bool pc;     // persistent producer/consumer kernel (conv_pcg_kernel.h): 512 threads, one workgroup per CU
+    bool ks;     // intra-workgroup K split (conv_ks_kernel.h): 1024 threads, 32x32 tile, no split-K plans
 };
 
 #define CFG_ENTRY(T, nm)                                                                                 \
@@ -728,6 +730,7 @@ const CfgInfo kCfgs[] = {
     Q4_ENTRY(Q128x32x32, "q128x32x32"),    Q4_ENTRY(Q32x128x32, "q32x128x32"),
     Q4_ENTRY(Q256x64x16, "q256x64x16"),    Q4_ENTRY(Q64x256x16, "q64x256x16"),
     PC_ENTRY(P128x128, "p128x128x16"),     PC_ENTRY(P64x256, "p64x256x16"),     PC_ENTRY(P256x64, "p256x64x16"),
+    {"k32x32x8", 2, KsCfg::BM, KsCfg::BN, KsCfg::BK, KsCfg::LDS_BYTES, conv_ks_kernel, conv_ks_kernel, nullptr, nullptr, false, true},
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 constexpr int kLdsPerCu = 160 * 1024;
@@ -742,6 +745,7 @@ bool cfg_applies(const CfgInfo &ci, int layout, int cin_g, int q_pad = 1 << 20) 
     // the persistent kernel: plain channel-quad gather only, and at least 4 chunks per tile (its
     // per-tile parameter hand-off is three tiles deep)
     if (ci.pc && (layout != 2 || q_pad / 4 < 4 || !pc_enabled())) return false;
+    if (ci.ks && (layout != 2 || (getenv("PLANER_HIP_KS") && atoi(getenv("PLANER_HIP_KS")) == 0))) return false;
     if (layout == 6) layout = 2;            // row-packed input: the channel-quad kernel with another gather
     if (ci.tap != layout) return false;
     return ci.tap != 1 || cin_g % ci.bk == 0;
@@ -816,6 +820,22 @@ int launch_pass(pl_ctx *ctx, ConvArgs a, const CfgInfo &ci, bool avec, int tile_
         if (rc != PL_OK) return rc;
         const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
         hipLaunchKernelGGL(ci.vec, dim3((unsigned)std::min(tile_count, cus)), dim3(512), ci.lds, ctx->stream, a);
+        hipError_t le = hipGetLastError();
+        if (le != hipSuccess) {
+            pl_set_error("conv launch (%s): %s", ci.name, hipGetErrorString(le));
+            return PL_EHIP;
+        }
+        *used_splits = 1;
+        return PL_OK;
+    }
+    if (ci.ks) {
+        if (splits != 1) {
+            pl_set_error("conv: the K-split-inside-the-workgroup kernel takes no split-K plan");
+            return PL_EINVAL;
+        }
+        int rc = ensure_lds_attr((const void *)ci.vec, ci.lds);
+        if (rc != PL_OK) return rc;
+        hipLaunchKernelGGL(ci.vec, dim3((unsigned)tile_count), dim3(1024), ci.lds, ctx->stream, a);
         hipError_t le = hipGetLastError();
         if (le != hipSuccess) {
             pl_set_error("conv launch (%s): %s", ci.name, hipGetErrorString(le));
@@ -899,7 +919,7 @@ Plan choose_plan(pl_ctx *ctx, int layout, const ConvArgs &a) {
     Plan pl{-1, 0, 1, 0};
     for (int c = 0; c < kNumCfgs; ++c) {
         const CfgInfo &ci = kCfgs[c];
-        if (ci.pc || !cfg_applies(ci, layout, a.cin_g)) continue;
+        if (ci.pc || ci.ks || !cfg_applies(ci, layout, a.cin_g)) continue;
         const double mt = (a.cout_g + ci.bm - 1) / ci.bm, nt = (a.cols + ci.bn - 1) / ci.bn;
         const double tiles = mt * nt * a.groups;
         const double kch = std::ceil((double)a.K / ci.bk);
@@ -973,7 +993,7 @@ Plan tune_plan(pl_ctx *ctx, int layout, const ConvArgs &a, bool avec, float *y, 
         if ((double)T * ci.bm * ci.bn > 2.5 * work + 1e5) continue;               // mostly padding
         Plan dp{c, T, 1, 0};
         stage1.push_back({time_plan(ctx, a, dp, avec, y, e0, e1, 2), dp});
-        if (ci.pc) continue;                                                      // persistent: no split-K variants
+        if (ci.pc || ci.ks) continue;                                             // persistent / intra-workgroup split: no split-K variants
         const int chunks = (a.K + ci.bk - 1) / ci.bk;
         const char *ms_env = getenv("PLANER_CONV_MAX_SPLIT");     // experiments: cap split-K
         const int max_split = ms_env ? atoi(ms_env) : 1 << 20;
@@ -1013,7 +1033,7 @@ Plan tune_plan(pl_ctx *ctx, int layout, const ConvArgs &a, bool avec, float *y, 
         if (std::find(tried.begin(), tried.end(), c) != tried.end()) continue;
         tried.push_back(c);
         const CfgInfo &ci = kCfgs[c];
-        if (ci.pc) continue;
+        if (ci.pc || ci.ks) continue;
         const int T = ((a.cout_g + ci.bm - 1) / ci.bm) * ((a.cols + ci.bn - 1) / ci.bn) * a.groups;
         const int chunks = (a.K + ci.bk - 1) / ci.bk;
         const int maxocc = std::min(8, kLdsPerCu / ci.lds);

@@ -100,7 +100,7 @@ def expected_kernels(a):
     plan, algo = a["plan"], a["algo"]
     if plan.startswith("dense32x32"):
         return ["dense_small_kernel"]
-    gemm = ["conv_q4_kernel" if "[q" in plan or plan.startswith("q") else "conv_pc_kernel" if "p" in plan.split()[0] else "conv_igemm_kernel"]
+    gemm = ["conv_ks_kernel" if "[k" in plan or plan.startswith("k") else "conv_q4_kernel" if "[q" in plan or plan.startswith("q") else "conv_pc_kernel" if "p" in plan.split()[0] else "conv_igemm_kernel"]
     if re.search(r"split=([2-9]|\d\d)", plan):
         gemm.append("reduce_tiles")
     if algo.startswith("rowpack"):
