@@ -730,7 +730,10 @@ const CfgInfo kCfgs[] = {
     Q4_ENTRY(Q128x32x32, "q128x32x32"),    Q4_ENTRY(Q32x128x32, "q32x128x32"),
     Q4_ENTRY(Q256x64x16, "q256x64x16"),    Q4_ENTRY(Q64x256x16, "q64x256x16"),
     PC_ENTRY(P128x128, "p128x128x16"),     PC_ENTRY(P64x256, "p64x256x16"),     PC_ENTRY(P256x64, "p256x64x16"),
-    {"k32x32x8", 2, KsCfg::BM, KsCfg::BN, KsCfg::BK, KsCfg::LDS_BYTES, conv_ks_kernel, conv_ks_kernel, nullptr, nullptr, false, true},
+#define KS_ENTRY(TM, TN, nm) \
+    { nm, 2, KsCfg<TM, TN>::BM, KsCfg<TM, TN>::BN, KsCfg<TM, TN>::BK, KsCfg<TM, TN>::LDS_BYTES, conv_ks_kernel<KsCfg<TM, TN> >, \
+      conv_ks_kernel<KsCfg<TM, TN> >, nullptr, nullptr, false, true }
+    KS_ENTRY(1, 1, "k32x32x8"), KS_ENTRY(2, 1, "k64x32x8"), KS_ENTRY(1, 2, "k32x64x8"), KS_ENTRY(2, 2, "k64x64x8"),
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 constexpr int kLdsPerCu = 160 * 1024;
@@ -835,7 +838,7 @@ int launch_pass(pl_ctx *ctx, ConvArgs a, const CfgInfo &ci, bool avec, int tile_
         }
         int rc = ensure_lds_attr((const void *)ci.vec, ci.lds);
         if (rc != PL_OK) return rc;
-        hipLaunchKernelGGL(ci.vec, dim3((unsigned)tile_count), dim3(1024), ci.lds, ctx->stream, a);
+        hipLaunchKernelGGL(ci.vec, dim3((unsigned)tile_count), dim3((unsigned)(16 * 32 * 32 / (ci.bm * ci.bn) * 64)), ci.lds, ctx->stream, a);
         hipError_t le = hipGetLastError();
         if (le != hipSuccess) {
             pl_set_error("conv launch (%s): %s", ci.name, hipGetErrorString(le));
