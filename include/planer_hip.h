@@ -227,6 +227,10 @@ int pl_pool2d_q4_f32(pl_ctx *ctx, const float *xq, float *yq, int N, int C, int 
                      int mode);
 int pl_upsample_nearest_q4_f32(pl_ctx *ctx, const float *xq, float *yq, int N, int C,
                                int H, int W, int fh, int fw);
+/* layer.Concatenate (axis 1) of two Q4 tensors in one launch; the first is nearest-upsampled by (fh, fw) on the way
+ * (layer.UpSample + layer.Concatenate, layer.py:80-82, 90-91): a is (N, Ca, H/fh, W/fw), b (N, Cb, H, W), y (N, Ca+Cb, H, W). */
+int pl_concat2_q4_f32(pl_ctx *ctx, const float *aq, const float *bq, float *yq, int N, int Ca, int Cb, int H, int W, int fh,
+                      int fw);
 int pl_gap_q4_f32(pl_ctx *ctx, const float *xq, float *y, int N, int C, int HW);
 int pl_scale_shift_q4_f32(pl_ctx *ctx, const float *xq, float *yq, const float *scale,
                           const float *shift, int N, int C, int HW);

@@ -81,6 +81,7 @@ SIGNATURES = {
     "pl_pool2d_q4_f32": [_P, _P, _P] + [_I] * 13,
     "pl_upsample_nearest_q4_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I],
     "pl_gap_q4_f32": [_P, _P, _P, _I, _I, _I],
+    "pl_concat2_q4_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I],
     "pl_scale_shift_q4_f32": [_P, _P, _P, _P, _P, _I, _I, _I],
     "pl_set_autotune": [_P, _I],
     "pl_tune_cache_save": [_P, c_char_p],

@@ -358,6 +358,27 @@ __global__ void __launch_bounds__(TPB) upsample_q4_kernel(const float4 *x, float
     }
 }
 
+// layer.Concatenate (layer.py:90-91) of TWO channel-quad tensors along channels in one launch, the first one optionally
+// nearest-upsampled by (fh, fw) on the way (layer.UpSample, layer.py:80-82 -> util.upsample_nearest): the route layers of
+// a detection net -- upsample -> concat -- are one pass over the output instead of three kernels.
+__global__ void __launch_bounds__(TPB) concat2_q4_kernel(const float4 *a, const float4 *b, float4 *y, unsigned total, int qa,
+                                                         int qb, int H, int W, int Ha, int Wa, FastDiv divHW, FastDiv divQ,
+                                                         FastDiv divW, FastDiv divFh, FastDiv divFw) {
+    const unsigned stride = gridDim.x * TPB;
+    for (unsigned i = blockIdx.x * TPB + threadIdx.x; i < total; i += stride) {      // i = (n*(qa+qb) + q)*H*W + pix
+        unsigned r, pix, n, q;
+        divHW.divmod(i, r, pix);
+        divQ.divmod(r, n, q);
+        if ((int)q < qa) {
+            unsigned oh, ow;
+            divW.divmod(pix, oh, ow);
+            y[i] = a[(((size_t)n * qa + q) * Ha + divFh.div(oh)) * Wa + divFw.div(ow)];
+        } else {
+            y[i] = b[((size_t)n * qb + (q - qa)) * (size_t)(H * W) + pix];
+        }
+    }
+}
+
 // global average pool: one wave64 per (n, channel quad); output is plain [N][C]
 __global__ void __launch_bounds__(TPB) gap_q4_kernel(const float4 *x, float *y, int rows, int Cq, int C, int inner,
                                                      float inv) {
@@ -878,6 +899,23 @@ int pl_upsample_nearest_q4_f32(pl_ctx *ctx, const float *xq, float *yq, int N, i
     upsample_q4_kernel<<<stream_grid(ctx, total), TPB, 0, ctx->stream>>>(
         (const float4 *)xq, (float4 *)yq, (unsigned)total, H, W, H * fh, W * fw, FastDiv(W * fw), FastDiv(H * fh),
         FastDiv(fh), FastDiv(fw));
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
+
+int pl_concat2_q4_f32(pl_ctx *ctx, const float *aq, const float *bq, float *yq, int N, int Ca, int Cb, int H, int W, int fh,
+                      int fw) {
+    PL_REQUIRE(ctx && aq && bq && yq, PL_EINVAL, "pl_concat2_q4_f32: null argument");
+    PL_REQUIRE(N >= 0 && Ca > 0 && Cb > 0 && H > 0 && W > 0 && fh > 0 && fw > 0 && Ca % 4 == 0 && Cb % 4 == 0 && H % fh == 0 &&
+                   W % fw == 0, PL_EINVAL, "pl_concat2_q4_f32: bad shape (channel counts must be multiples of 4, H, W of the factors)");
+    PL_REQUIRE(aligned16(aq) && aligned16(bq) && aligned16(yq), PL_EINVAL, "pl_concat2_q4_f32: Q4 tensors must be 16-byte aligned");
+    const size_t total = (size_t)N * ((Ca + Cb) / 4) * H * W;
+    if (!total) return PL_OK;
+    PL_REQUIRE(total < (1ull << 30), PL_EUNSUPPORTED, "concat: tensor too large");
+    CtxGuard g(ctx);
+    concat2_q4_kernel<<<stream_grid(ctx, total), TPB, 0, ctx->stream>>>(
+        (const float4 *)aq, (const float4 *)bq, (float4 *)yq, (unsigned)total, Ca / 4, Cb / 4, H, W, H / fh, W / fw,
+        FastDiv(H * W), FastDiv((Ca + Cb) / 4), FastDiv(W), FastDiv(fh), FastDiv(fw));
     PL_LAUNCH_CHECK();
     return PL_OK;
 }

@@ -414,8 +414,34 @@ class Net:
         # conv + maxpool in one kernel: bit-identical, measured SLOWER on ResNet-18's stem -> opt-in
         if os.environ.get("PLANER_HIP_FUSE_POOL", "0") != "0":
             out_flow = self._fuse_conv_maxpool(out_body, out_flow)
+        out_flow = self._fuse_upsample_concat(out_body, out_flow)
         used = {n for _, names, _ in out_flow for n in names}
         return [out_body[b[0]] for b in body if b[0] in used], out_flow
+
+    @staticmethod
+    def _fuse_upsample_concat(body, flow):
+        """upsample_q4 whose only reader is a two-input concat_q4 (axis 1) that takes it FIRST -> one upconcat_q4 step
+        (detection-net routes: the upsampled tensor is written once, into its place in the concatenation)."""
+        readers = {}
+        for i, (src, names, dst) in enumerate(flow):
+            for k in (src if isinstance(src, list) else [src]):
+                readers.setdefault(k, []).append(i)
+        drop, out = set(), {}
+        for i, (src, names, dst) in enumerate(flow):
+            entry = body[names[0]]
+            if (entry[1] == "upsample_q4" and isinstance(dst, str) and isinstance(src, list) and len(src) == 2
+                    and entry[2].get("mode", "nearest") == "nearest" and len(readers.get(dst, [])) == 1):
+                j = readers[dst][0]
+                csrc, cnames, cdst = flow[j]
+                ce = body[cnames[0]]
+                if (ce[1] == "concat_q4" and len(cnames) == 1 and isinstance(csrc, list) and len(csrc) == 2 and csrc[0] == dst
+                        and int(ce[2].get("axis", 0)) == 1 and i < j
+                        # the upsample now reads its source at step j: nobody may touch it in between (in-place ReLU)
+                        and not any(src[0] in (f[0] if isinstance(f[0], list) else [f[0]]) for f in flow[i + 1:j])):
+                    body[cnames[0]] = [ce[0], "upconcat_q4", {"mode": "nearest", "axis": 1}]
+                    out[j] = [[src[0], src[1], csrc[1]], cnames, cdst]
+                    drop.add(i)
+        return [out.get(i, f) for i, f in enumerate(flow) if i not in drop]
 
     @staticmethod
     def _fuse_conv_maxpool(body, flow):

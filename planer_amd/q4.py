@@ -340,6 +340,8 @@ def ConcatenateQ4(*xs, axis=1):
     if any(a.shape[0] != n or a.shape[2:] != xs[0].shape[2:] for a in xs):
         raise ValueError("concat: shapes differ off the axis: %s" % [logical_shape(b) for b in xs])
     total = sum(a.chan for a in xs)
+    if len(xs) == 2:
+        return UpConcatQ4(xs[0], None, xs[1])
     y = _new_q4(n, total, h, w, xs[0].ctx)
     off, pitch = 0, (total // 4) * h * w * 4
     for a in xs:
@@ -347,6 +349,27 @@ def ConcatenateQ4(*xs, axis=1):
         if width and n:
             _lib.call("pl_copy2d_f32", y.ctx.handle, y.ptr + off * 4, pitch, a.ptr, width, width, n)
         off += width
+    return y
+
+
+def UpConcatQ4(aq, k, bq, mode="nearest", axis=1):
+    """layer.Concatenate([layer.UpSample(a, k), b], axis=1) on Q4 tensors in one kernel (k = None: no upsampling).
+    Emitted by the plan compiler for upsample -> concat routes; also serves every two-input Q4 concat."""
+    _f32(aq, bq)
+    if axis != 1 or mode != "nearest" or not is_q4(aq) or not is_q4(bq) or aq.chan % 4 or bq.chan % 4:
+        raise ValueError("UpConcatQ4: two Q4 tensors with C % 4 == 0, channel axis, nearest mode")
+    fh = fw = 1
+    if k is not None:
+        kv = _host_values(k)
+        if kv.size == 0:
+            raise ValueError("upsample needs scales (the reference's size-only branch is broken, layer.py:81)")
+        fh, fw = [int(v) for v in kv[-2:].astype(int).tolist()]
+    n, ca, ha, wa = logical_shape(aq)
+    nb, cb, h, w = logical_shape(bq)
+    if nb != n or (ha * fh, wa * fw) != (h, w):
+        raise ValueError("concat: shapes differ off the axis: %s (x%d, x%d) vs %s" % ((n, ca, ha, wa), fh, fw, (nb, cb, h, w)))
+    y = _new_q4(n, ca + cb, h, w, aq.ctx)
+    _lib.call("pl_concat2_q4_f32", aq.ctx.handle, aq.ptr, bq.ptr, y.ptr, n, ca, cb, h, w, fh, fw)
     return y
 
 
@@ -358,5 +381,5 @@ Q4_LAYERS = {"maxpool": MaxpoolQ4, "averagepool": AveragePoolQ4, "gap": GlobalAv
 
 def register(layer_map):
     """Plan-internal kinds (never present in a user's IR)."""
-    layer_map.update({"to_q4": to_q4, "from_q4": from_q4, "conv_q4": ConvQ4})
+    layer_map.update({"to_q4": to_q4, "from_q4": from_q4, "conv_q4": ConvQ4, "upconcat_q4": UpConcatQ4})
     layer_map.update({k + "_q4": f for k, f in Q4_LAYERS.items()})

@@ -445,3 +445,19 @@ def test_conv_maxpool_fused_kernel_is_bit_exact(pa, shape):
         conv = onp.batchnorm(onp.conv2d(x, K, B, **para), sc, sh)
         want = onp.maxpool(onp.relu(conv) if act else conv, w=[3, 3], pads=[1, 1, 1, 1], strides=[2, 2])
         assert_close(q4.from_q4(one).get(), want, RTOL, "conv+maxpool %s act %d" % (shape, act))
+
+
+def test_upsample_concat_one_kernel_is_bit_exact(pa):
+    """UpConcatQ4 = concat([upsample(a), b], channels) in one launch, against the two numpy calls; also the plain
+    two-input concat (no upsampling) that ConcatenateQ4 now routes through the same kernel."""
+    from planer_amd import q4
+    rng = np.random.default_rng(5)
+    for n, ca, cb, h, w, fh, fw in [(1, 256, 512, 13, 13, 2, 2), (2, 8, 4, 5, 7, 2, 3), (3, 4, 12, 6, 6, 1, 1), (1, 128, 256, 26, 26, 2, 2)]:
+        a = rng.standard_normal((n, ca, h, w)).astype(np.float32)
+        b = rng.standard_normal((n, cb, h * fh, w * fw)).astype(np.float32)
+        k = np.array([1, 1, fh, fw], np.float32)
+        got = q4.from_q4(q4.UpConcatQ4(q4.to_q4(pa.asarray(a)), pa.asarray(k), q4.to_q4(pa.asarray(b)))).get()
+        np.testing.assert_array_equal(got, np.concatenate([onp.OPS["upsample"](a, k, mode="nearest"), b], 1))
+    a, b = rng.standard_normal((2, 8, 9, 5)).astype(np.float32), rng.standard_normal((2, 12, 9, 5)).astype(np.float32)
+    got = q4.from_q4(q4.ConcatenateQ4(q4.to_q4(pa.asarray(a)), q4.to_q4(pa.asarray(b)), axis=1)).get()
+    np.testing.assert_array_equal(got, np.concatenate([a, b], 1))

@@ -249,3 +249,27 @@ def test_random_graphs_fusion_and_layout_assignment_preserve_the_flow():
                 assert o.shape == w.shape, (seed, what)
                 assert_close(np.ascontiguousarray(o), np.ascontiguousarray(w), 1e-5, "seed %d %s" % (seed, what))
     assert fused_total > 150 and q4_total > 300          # the generator does exercise both passes
+
+
+def test_upsample_concat_peephole_and_its_guards():
+    """Net._fuse_upsample_concat (host logic): upsample_q4 -> concat_q4 becomes one upconcat_q4 step, unless the
+    upsampled tensor has another reader, is not the concat's first input, or its source is touched in between."""
+    from planer_amd.net import Net
+
+    def prog(extra_reader=False, first=True, touch=False):
+        body = {"up": ["up", "upsample_q4", {"mode": "nearest"}], "cat": ["cat", "concat_q4", {"axis": 1}],
+                "r": ["r", "relu_q4", {}], "s": ["s", "sigmoid_q4", {}]}
+        flow = [[["a", "k"], ["up"], "u"]]
+        if touch:
+            flow.append(["a", ["r"], "a2"])                 # in-place ReLU on the upsample's source before the concat
+        flow.append([["u", "b"] if first else ["b", "u"], ["cat"], "c"])
+        if extra_reader:
+            flow.append(["u", ["s"], "z"])
+        return body, flow
+
+    body, flow = prog()
+    out = Net._fuse_upsample_concat(body, flow)
+    assert out == [[["a", "k", "b"], ["cat"], "c"]] and body["cat"][1] == "upconcat_q4"
+    for kw in ({"extra_reader": True}, {"first": False}, {"touch": True}):
+        body, flow = prog(**kw)
+        assert Net._fuse_upsample_concat(body, flow) == flow and body["cat"][1] == "concat_q4", kw
