@@ -755,13 +755,15 @@ class Net:
         plan.algos = algos
         return plan
 
-    def _replay(self, xs):
+    def _replay(self, xs, private=True):
         plan = self.compile(*xs)
         for s, a in zip(plan.inputs, xs):          # on the main stream; launch() forks behind it
             if a is not s:
                 s.copy_from(a)
         plan.launch()
         out = plan.outputs
+        if not private:                            # the caller copies to the host right away
+            return out
         # hand back private copies: the plan's buffers are rewritten by the next replay
         if isinstance(out, tuple):
             return tuple(o.copy() if isinstance(o, DeviceArray) else o for o in out)
@@ -780,7 +782,7 @@ class Net:
                      and all(isinstance(i, DeviceArray) for i in x))
         if graphable:
             try:
-                rst = self._replay(list(x))
+                rst = self._replay(list(x), private=not need)          # host in -> host out: .get() reads the plan's buffers
             except _lib.NotCapturable:
                 # post-processing graphs (Shape / NonZero / index uploads) need the host between kernels: same
                 # kernels, launched one by one from here on
