@@ -425,7 +425,7 @@ def scatternd(data, indices, updates):
 
 def topk(x, k, axis=-1, largest=1, sorted=1):
     """layer.TopK (layer.py:234-239)"""
-    idk = np.arange(k) * -largest - (largest > 0)
+    idk = np.arange(int(np.asarray(k).reshape(-1)[0])) * -largest - (largest > 0)     # (k arrives as a 1-element tensor)
     idx = np.take(np.argsort(x, axis=axis), idk, axis=axis)
     return np.take_along_axis(x, idx, axis=axis), idx
 
