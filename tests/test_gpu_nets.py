@@ -233,3 +233,35 @@ def test_postprocessing_flow_with_data_dependent_shapes(pa):
         assert got[2].dtype == np.int64 and got[2].shape == want[2].shape and want[2].shape[1] > 0
         np.testing.assert_array_equal(got[2], want[2])
         assert_close(got[3], want[3], RTOL, "scatternd")
+
+
+def test_two_host_threads_two_contexts(pa):
+    """The library is thread-compatible: one context (stream + pool) per host thread, shared launch-plan cache behind a
+    mutex, thread-local error text.  Two threads run different nets on their own contexts at the same time."""
+    import threading
+    jobs = [(customnet, customnet.make_input(1)), (resnet18, resnet18.make_input(2, size=64))]
+    want, got, errs = [], [None, None], []
+    for mod, x in jobs:
+        g, b = mod.build()
+        ref = onp.OracleNet()
+        ref.load_json(g["input"], g["inits"], g["layers"], g["flow"])
+        ref.load_weights(b)
+        want.append(ref(x.copy()))
+
+    def work(i):
+        try:
+            ctx = pa.hip.Context(0)
+            mod, x = jobs[i]
+            g, b = mod.build()
+            net = pa.from_graph(g, b, ctx=ctx)
+            for _ in range(10):
+                y = net(x.copy())
+            got[i] = y
+        except Exception as e:                     # noqa: BLE001 -- reported by the main thread
+            errs.append(repr(e))
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    for y, w in zip(got, want):
+        assert_close(y, w, RTOL, "threaded")
