@@ -197,6 +197,30 @@ int pl_conv2d_winograd4_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int
                                const float *scale, const float *shift, const float *resq,
                                int act, double alpha);
 
+/* The same F(4x4,3x3) pipeline stage by stage, for plans that chain consecutive Winograd convs
+ * (replaces util.conv_for, util.py:17-44, for 3x3 / stride 1 / pad 1 convs; the fused tail is
+ * layer.BatchNorm / Add / ReLU / LeakyReLU, layer.py:125-127, 93-95, 44-51).
+ * V (transformed input) and M (per-frequency products) are [36][C/4][T][4] with
+ * T = N * ceil(H/4) * ceil(W/4); pl_wino4_elems gives their size in floats.
+ *   pl_wino4_input_q4_f32    xq (N,C,H,W) -> V
+ *   pl_wino4_gemm_q4_f32     V (Cin), uq (prepare_winograd4) -> M (Cout): 36 grouped GEMMs on the MFMA kernel
+ *   pl_wino4_output_q4_f32   M -> yq = act((A^T m A + bias)*scale + shift + res)
+ *   pl_wino4_chain_q4_f32    M -> yq (may be NULL: nobody else reads it) AND Vnext, the transformed input of
+ *                            the next 3x3 conv on yq, in one kernel: yq never makes the round trip through HBM
+ * pl_wino4_chain_supported: *ok = 1 when an (N,C,H,W) map fits the LDS transform kernel (whole planes per
+ * workgroup); otherwise pl_wino4_chain_q4_f32 returns PL_EUNSUPPORTED and input / output use the register
+ * kernels.  Results are bit-identical to pl_conv2d_winograd4_q4_f32 whichever kernels run. */
+int pl_wino4_elems(int N, int C, int H, int W, size_t *elems);
+int pl_wino4_chain_supported(pl_ctx *ctx, int N, int C, int H, int W, int *ok);
+int pl_wino4_input_q4_f32(pl_ctx *ctx, const float *xq, int N, int C, int H, int W, float *V);
+int pl_wino4_gemm_q4_f32(pl_ctx *ctx, const float *V, int N, int Cin, int H, int W, const float *uq, int Cout, float *M);
+int pl_wino4_output_q4_f32(pl_ctx *ctx, const float *M, int N, int C, int H, int W, const float *bias,
+                           const float *scale, const float *shift, const float *resq, int act, double alpha,
+                           float *yq);
+int pl_wino4_chain_q4_f32(pl_ctx *ctx, const float *M, int N, int C, int H, int W, const float *bias,
+                          const float *scale, const float *shift, const float *resq, int act, double alpha,
+                          float *yq, float *Vnext);
+
 /* Fused 1-D Winograd F(2,3) along W on Q4 tensors (3x3 / stride 1 / pad 1 / group 1, Cin %% 4 == 0):
  * 1.5x fewer multiplies than the direct conv with NO extra HBM traffic -- the input transform
  * happens between the global load and LDS, the output transform in registers (conv_w1d_kernel.h).

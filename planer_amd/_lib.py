@@ -67,6 +67,12 @@ SIGNATURES = {
     "pl_conv2d_winograd4_q4_filter_elems": [_I, _I, POINTER(c_size_t)],
     "pl_conv2d_prepare_winograd4_q4_f32": [_P, _P, _I, _I, _P],
     "pl_conv2d_winograd4_q4_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, c_double],
+    "pl_wino4_elems": [_I, _I, _I, _I, POINTER(c_size_t)],
+    "pl_wino4_chain_supported": [_P, _I, _I, _I, _I, POINTER(c_int)],
+    "pl_wino4_input_q4_f32": [_P, _P, _I, _I, _I, _I, _P],
+    "pl_wino4_gemm_q4_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _P],
+    "pl_wino4_output_q4_f32": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, c_double, _P],
+    "pl_wino4_chain_q4_f32": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, c_double, _P, _P],
     "pl_conv2d_rowpack_filter_elems": [_I, _I, _I, _I, POINTER(c_size_t)],
     "pl_conv2d_prepare_rowpack_f32": [_P, _P, _I, _I, _I, _I, _P],
     "pl_conv2d_rowpack_q4_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, c_double],

@@ -1945,56 +1945,151 @@ __global__ void __launch_bounds__(256) wino4_output_rows_q4_kernel(const float4 
     }
 }
 
-int winograd4_q4_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const float *Uq, int Cout,
-                        const float *bias, float *yq, const float *scale, const float *shift, const float *resq,
-                        int act, double alpha) {
-    WinoArgs p;
-    p.N = N; p.C = Cin; p.H = H; p.W = W; p.Cout = Cout; p.Ho = H; p.Wo = W;
+#include "wino4_chain_kernel.h"
+
+// ---- F(4x4,3x3) stage by stage.  winograd4_q4_launch below runs the three stages of ONE conv; the plan
+//      compiler (planer_amd/plan.py chain_winograd) calls the stages itself so that consecutive
+//      Winograd convs share a transform kernel. ----
+int wino4_geometry(WinoArgs &p, int N, int C, int H, int W, int Cout) {
+    p.N = N; p.C = C; p.H = H; p.W = W; p.Cout = Cout; p.Ho = H; p.Wo = W;
     p.th = (H + 3) / 4; p.tw = (W + 3) / 4; p.T = N * p.th * p.tw;
-    const int Cq = Cin / 4, Coq = Cout / 4;
-    const size_t vin = (size_t)36 * Cin * p.T, vout = (size_t)36 * Cout * p.T;
-    PL_REQUIRE(vin < (1ull << 29) && vout < (1ull << 31) && (size_t)Cin * p.T < (1ull << 32) &&
-                   (size_t)Cout * p.T < (1ull << 32) && (size_t)N * Cin * H * W < (1ull << 29) &&
+    const size_t vin = (size_t)36 * C * p.T, vout = (size_t)36 * Cout * p.T;
+    PL_REQUIRE(vin < (1ull << 29) && vout < (1ull << 31) && (size_t)C * p.T < (1ull << 32) &&
+                   (size_t)Cout * p.T < (1ull << 32) && (size_t)N * C * H * W < (1ull << 29) &&
                    (size_t)N * Cout * H * W < (1ull << 29), PL_EUNSUPPORTED, "winograd F(4,3): tensor too large");
     p.divT = FastDiv(p.T); p.divTw = FastDiv(p.tw); p.divTh = FastDiv(p.th);
+    return PL_OK;
+}
+
+// Workgroup shape of the LDS transform kernel for planes of th x tw tiles: channel quads per workgroup (0: the
+// plane does not fit) -- the largest divisor of Cq that keeps the workgroup in `budget` bytes of LDS and the grid
+// at one workgroup per CU or more, preferring full waves (G x tiles close to a multiple of 64).
+size_t wino4_chain_lds(int G, int th, int tw, bool from_m) {
+    const size_t plane = (size_t)(4 * th + 2) * 4 * (tw + 1);
+    return ((size_t)G * plane + (from_m ? (size_t)36 * G * th * tw + 3 * (size_t)G : 0)) * 16;
+}
+int wino4_chain_pick_g(pl_ctx *ctx, int N, int Cq, int th, int tw, bool from_m) {
+    static const char *g_env = getenv("PLANER_HIP_WINO_G");
+    const size_t one_max = 96 * 1024, many_max = 80 * 1024;
+    if (wino4_chain_lds(1, th, tw, from_m) > one_max) return 0;
+    if (g_env && atoi(g_env) > 0 && Cq % atoi(g_env) == 0 && wino4_chain_lds(atoi(g_env), th, tw, from_m) <= 150 * 1024)
+        return atoi(g_env);
+    const int cus = ctx && ctx->cu_count > 0 ? ctx->cu_count : 256, tiles = th * tw;
+    int best = 1;
+    double best_eff = (double)tiles / ((tiles + 63) / 64 * 64);
+    for (int G = 2; G <= Cq; ++G) {
+        if (Cq % G) continue;
+        if (wino4_chain_lds(G, th, tw, from_m) > many_max || (long)N * (Cq / G) < cus) break;
+        const double eff = (double)(G * tiles) / ((G * tiles + 63) / 64 * 64);
+        if (eff >= best_eff) best = G, best_eff = eff;
+    }
+    return best;
+}
+
+// M (FROM_M) or x -> y and / or V through LDS (wino4_chain_kernel.h); `p` carries the tail for FROM_M
+int wino4_chain_launch(pl_ctx *ctx, const float *M, const float *x, const WinoArgs &p, int C, float *y, float *V) {
+    const bool from_m = M != nullptr;
+    const int Cq = C / 4;
+    const int G = wino4_chain_pick_g(ctx, p.N, Cq, p.th, p.tw, from_m);
+    PL_REQUIRE(G > 0, PL_EUNSUPPORTED, "winograd F(4,3) LDS transforms: a %d x %d map does not fit the workgroup's LDS", p.H, p.W);
+    const size_t src_bytes = from_m ? (size_t)36 * C * p.T * 4 : (size_t)p.N * C * p.H * p.W * 4;
+    PL_REQUIRE(src_bytes < (1ull << 31), PL_EUNSUPPORTED, "winograd F(4,3) LDS transforms: tensor above 2 GiB");
+    Wino4ChainArgs a;
+    a.M = M; a.x = x; a.y = (float4 *)y; a.V = (float4 *)V;
+    a.N = p.N; a.Cq = Cq; a.H = p.H; a.W = p.W; a.th = p.th; a.tw = p.tw; a.tiles = p.th * p.tw; a.T = p.T;
+    a.G = G; a.gt = G * a.tiles; a.per = (a.gt + 63) / 64 * 64;
+    a.R = 4 * p.th + 2; a.XP = 4 * p.tw + 2; a.S = p.tw + 1; a.plane = a.R * 4 * a.S;
+    a.src_bytes = (unsigned)src_bytes;
+    a.res_bytes = (from_m && p.ep.res) ? (unsigned)((size_t)p.N * C * p.H * p.W * 4) : 0u;
+    a.divGt = FastDiv(a.gt); a.divTiles = FastDiv(a.tiles); a.divTw = FastDiv(a.tw); a.divPer = FastDiv(a.per);
+    a.divPlane = FastDiv(a.plane); a.div4S = FastDiv(4 * a.S); a.divS = FastDiv(a.S);
+    a.divHW = FastDiv(p.H * p.W); a.divW = FastDiv(p.W);
+    a.ep = p.ep;
+    static const char *bd_env = getenv("PLANER_HIP_WINO_BD");
+    int bd = bd_env ? atoi(bd_env) : 384;
+    bd = std::max(64, std::min(512, bd / 64 * 64));
+    const size_t lds = wino4_chain_lds(G, p.th, p.tw, from_m);
+    auto kern = from_m ? wino4_chain_kernel<true> : wino4_chain_kernel<false>;
+    if (lds > 48 * 1024) {
+        int rc = ensure_lds_attr((const void *)kern, 150 * 1024);
+        if (rc != PL_OK) return rc;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(Cq / G), (unsigned)p.N), dim3((unsigned)bd), lds, ctx->stream, a);
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
+
+bool wino4_lds_enabled() {
+    static const bool on = !getenv("PLANER_HIP_WINO_LDS") || atoi(getenv("PLANER_HIP_WINO_LDS")) != 0;
+    return on;
+}
+
+int wino4_input_launch(pl_ctx *ctx, const float *xq, float *V, const WinoArgs &p, int lds_ok) {
+    const int Cq = p.C / 4;
+    if (lds_ok && wino4_lds_enabled() && wino4_chain_pick_g(ctx, p.N, Cq, p.th, p.tw, false) > 0)
+        return wino4_chain_launch(ctx, nullptr, xq, p, p.C, nullptr, V);
+    const unsigned cap = (unsigned)(ctx->cu_count > 0 ? ctx->cu_count : 256) * 8;
+    const unsigned tin = (unsigned)((size_t)p.C * p.T);
+    // small maps: one transformed row per thread (see the row-split kernels); PLANER_HIP_WINO_ROWS=0/1 forces
+    static const char *rows_env = getenv("PLANER_HIP_WINO_ROWS");
+    const unsigned cus = (unsigned)(ctx->cu_count > 0 ? ctx->cu_count : 256);
+    const bool in_rows = rows_env ? atoi(rows_env) != 0 : (tin + 255) / 256 < cus;
+    if (in_rows)
+        wino4_input_rows_q4_kernel<<<dim3(std::min(cap, (tin + 255) / 256), 6), 256, 0, ctx->stream>>>(xq, V, p, Cq, tin);
+    else
+        wino4_input_q4_kernel<<<std::min(cap, (tin + 255) / 256), 256, 0, ctx->stream>>>(xq, V, p, Cq, tin);
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
+
+int wino4_gemm_launch(pl_ctx *ctx, const float *V, const float *Uq, float *M, const WinoArgs &p) {
+    int rc = conv_launch(ctx, V, 1, 36 * p.C, p.N * p.th, p.tw, Uq, 36 * p.Cout, 1, 1, nullptr, M, 1, 1, 1, 1, 0, 0, 0, 0, 36,
+                         nullptr, nullptr, nullptr, PL_ACT_NONE, 0.0, 2);
+    ctx->last_plan = "wino4[" + ctx->last_plan + "]";
+    return rc;
+}
+
+int wino4_output_launch(pl_ctx *ctx, const float *M, float *yq, const WinoArgs &p, int lds_ok) {
+    const int Coq = p.Cout / 4;
+    if (lds_ok && wino4_lds_enabled() && wino4_chain_pick_g(ctx, p.N, Coq, p.th, p.tw, true) > 0)
+        return wino4_chain_launch(ctx, M, nullptr, p, p.Cout, yq, nullptr);
+    const unsigned cap = (unsigned)(ctx->cu_count > 0 ? ctx->cu_count : 256) * 8;
+    const unsigned tout = (unsigned)((size_t)Coq * p.T);
+    static const char *rows_env = getenv("PLANER_HIP_WINO_ROWS");
+    const unsigned cus = (unsigned)(ctx->cu_count > 0 ? ctx->cu_count : 256);
+    const bool out_rows = rows_env ? atoi(rows_env) != 0 : (tout + 255) / 256 < cus / 2;
+    if (out_rows)
+        wino4_output_rows_q4_kernel<<<dim3(std::min(cap, (tout + 255) / 256), 4), 256, 0, ctx->stream>>>(
+            (const float4 *)M, (float4 *)yq, p, Coq, tout);
+    else
+        wino4_output_q4_kernel<<<std::min(cap, (tout + 255) / 256), 256, 0, ctx->stream>>>((const float4 *)M, (float4 *)yq, p,
+                                                                                           Coq, tout);
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
+
+// lds_mode: 0 = the register transform kernels (round 2), 1 = the LDS transform kernel where the plane fits
+int winograd4_q4_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const float *Uq, int Cout,
+                        const float *bias, float *yq, const float *scale, const float *shift, const float *resq,
+                        int act, double alpha, int lds_mode) {
+    WinoArgs p;
+    int rc = wino4_geometry(p, N, Cin, H, W, Cout);
+    if (rc != PL_OK) return rc;
     p.ep = make_epilogue(bias, scale, shift, resq, act, alpha);
+    const size_t vin = (size_t)36 * Cin * p.T, vout = (size_t)36 * Cout * p.T;
     float *V = nullptr, *M = nullptr;
-    int rc = pl_alloc(ctx, vin * sizeof(float), (void **)&V);
+    rc = pl_alloc(ctx, vin * sizeof(float), (void **)&V);
     if (rc != PL_OK) return rc;
     rc = pl_alloc(ctx, vout * sizeof(float), (void **)&M);
     if (rc != PL_OK) {
         pl_free(ctx, V);
         return rc;
     }
-    const unsigned cap = (unsigned)(ctx->cu_count > 0 ? ctx->cu_count : 256) * 8;
-    const unsigned tin = (unsigned)((size_t)Cin * p.T), tout = (unsigned)((size_t)Coq * p.T);
-    // small maps: one transformed row per thread (see the row-split kernels); PLANER_HIP_WINO_ROWS=0/1 forces
-    static const char *rows_env = getenv("PLANER_HIP_WINO_ROWS");
-    const unsigned cus = (unsigned)(ctx->cu_count > 0 ? ctx->cu_count : 256);
-    const bool in_rows = rows_env ? atoi(rows_env) != 0 : (tin + 255) / 256 < cus;
-    const bool out_rows = rows_env ? atoi(rows_env) != 0 : (tout + 255) / 256 < cus / 2;
-    if (in_rows)
-        wino4_input_rows_q4_kernel<<<dim3(std::min(cap, (tin + 255) / 256), 6), 256, 0, ctx->stream>>>(xq, V, p, Cq, tin);
-    else
-        wino4_input_q4_kernel<<<std::min(cap, (tin + 255) / 256), 256, 0, ctx->stream>>>(xq, V, p, Cq, tin);
-    rc = conv_launch(ctx, V, 1, 36 * Cin, N * p.th, p.tw, Uq, 36 * Cout, 1, 1, nullptr, M, 1, 1, 1, 1, 0, 0, 0, 0, 36,
-                     nullptr, nullptr, nullptr, PL_ACT_NONE, 0.0, 2);
-    if (rc == PL_OK) {
-        if (out_rows)
-            wino4_output_rows_q4_kernel<<<dim3(std::min(cap, (tout + 255) / 256), 4), 256, 0, ctx->stream>>>(
-                (const float4 *)M, (float4 *)yq, p, Coq, tout);
-        else
-            wino4_output_q4_kernel<<<std::min(cap, (tout + 255) / 256), 256, 0, ctx->stream>>>((const float4 *)M, (float4 *)yq, p,
-                                                                                               Coq, tout);
-        hipError_t le = hipGetLastError();
-        if (le != hipSuccess) {
-            pl_set_error("winograd F(4,3) transform launch: %s", hipGetErrorString(le));
-            rc = PL_EHIP;
-        }
-    }
+    rc = wino4_input_launch(ctx, xq, V, p, lds_mode);
+    if (rc == PL_OK) rc = wino4_gemm_launch(ctx, V, Uq, M, p);
+    if (rc == PL_OK) rc = wino4_output_launch(ctx, M, yq, p, lds_mode);
     pl_free(ctx, M);
     pl_free(ctx, V);
-    ctx->last_plan = "wino4[" + ctx->last_plan + "]";
     return rc;
 }
 
@@ -2340,7 +2435,87 @@ int pl_conv2d_winograd4_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int
                  reinterpret_cast<uintptr_t>(resq)) & 15u) == 0, PL_EINVAL, "Q4 tensors must be 16-byte aligned");
     if (N == 0) return PL_OK;
     CtxGuard guard(ctx);
-    return winograd4_q4_launch(ctx, xq, N, Cin, H, W, uq, Cout, bias, yq, scale, shift, resq, act, alpha);
+    // which transform kernels: the register ones (round 2) unless PLANER_HIP_WINO_MONO_LDS=1
+    static const int mono_lds = getenv("PLANER_HIP_WINO_MONO_LDS") ? atoi(getenv("PLANER_HIP_WINO_MONO_LDS")) : 0;
+    return winograd4_q4_launch(ctx, xq, N, Cin, H, W, uq, Cout, bias, yq, scale, shift, resq, act, alpha, mono_lds);
+}
+
+// ---- the F(4x4,3x3) pipeline stage by stage (V / M: [36][C/4][T][4], T = N * ceil(H/4) * ceil(W/4)) ----
+int pl_wino4_elems(int N, int C, int H, int W, size_t *elems) {
+    PL_REQUIRE(elems && N >= 0 && C > 0 && H > 0 && W > 0 && C % 4 == 0, PL_EINVAL, "pl_wino4_elems: bad argument");
+    *elems = (size_t)36 * C * N * ((H + 3) / 4) * ((W + 3) / 4);
+    return PL_OK;
+}
+
+int pl_wino4_chain_supported(pl_ctx *ctx, int N, int C, int H, int W, int *ok) {
+    PL_REQUIRE(ok && C > 0 && H > 0 && W > 0 && C % 4 == 0, PL_EINVAL, "pl_wino4_chain_supported: bad argument");
+    *ok = wino4_lds_enabled() && wino4_chain_pick_g(ctx, N, C / 4, (H + 3) / 4, (W + 3) / 4, true) > 0 &&
+          (size_t)36 * C * N * ((H + 3) / 4) * ((W + 3) / 4) * 4 < (1ull << 31);
+    return PL_OK;
+}
+
+static int wino4_stage_check(const char *fn, pl_ctx *ctx, int N, int C, int H, int W, const void *a, const void *b,
+                             const void *c, const void *d) {
+    PL_REQUIRE(ctx, PL_EINVAL, "%s: null context", fn);
+    PL_REQUIRE(N >= 0 && C > 0 && H > 0 && W > 0 && C % 4 == 0, PL_EINVAL, "%s: bad shape (C must be a multiple of 4)", fn);
+    PL_REQUIRE(((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
+                 reinterpret_cast<uintptr_t>(d)) & 15u) == 0, PL_EINVAL, "%s: Q4 tensors must be 16-byte aligned", fn);
+    return PL_OK;
+}
+
+int pl_wino4_input_q4_f32(pl_ctx *ctx, const float *xq, int N, int C, int H, int W, float *V) {
+    int rc = wino4_stage_check("pl_wino4_input_q4_f32", ctx, N, C, H, W, xq, V, nullptr, nullptr);
+    if (rc != PL_OK) return rc;
+    PL_REQUIRE(xq && V, PL_EINVAL, "pl_wino4_input_q4_f32: null pointer");
+    if (N == 0) return PL_OK;
+    CtxGuard guard(ctx);
+    WinoArgs p;
+    rc = wino4_geometry(p, N, C, H, W, C);
+    if (rc != PL_OK) return rc;
+    p.ep = make_epilogue(nullptr, nullptr, nullptr, nullptr, PL_ACT_NONE, 0.0);
+    return wino4_input_launch(ctx, xq, V, p, 1);
+}
+
+int pl_wino4_gemm_q4_f32(pl_ctx *ctx, const float *V, int N, int Cin, int H, int W, const float *uq, int Cout, float *M) {
+    int rc = wino4_stage_check("pl_wino4_gemm_q4_f32", ctx, N, Cin, H, W, V, uq, M, nullptr);
+    if (rc != PL_OK) return rc;
+    PL_REQUIRE(V && uq && M && Cout > 0 && Cout % 4 == 0, PL_EINVAL, "pl_wino4_gemm_q4_f32: bad argument");
+    if (N == 0) return PL_OK;
+    CtxGuard guard(ctx);
+    WinoArgs p;
+    rc = wino4_geometry(p, N, Cin, H, W, Cout);
+    if (rc != PL_OK) return rc;
+    return wino4_gemm_launch(ctx, V, uq, M, p);
+}
+
+int pl_wino4_output_q4_f32(pl_ctx *ctx, const float *M, int N, int C, int H, int W, const float *bias, const float *scale,
+                           const float *shift, const float *resq, int act, double alpha, float *yq) {
+    int rc = wino4_stage_check("pl_wino4_output_q4_f32", ctx, N, C, H, W, M, yq, resq, nullptr);
+    if (rc != PL_OK) return rc;
+    PL_REQUIRE(M && yq, PL_EINVAL, "pl_wino4_output_q4_f32: null pointer");
+    PL_REQUIRE(act >= 0 && (act & 15) <= 2 && (act & ~31) == 0, PL_EINVAL, "pl_wino4_output_q4_f32: bad activation code");
+    if (N == 0) return PL_OK;
+    CtxGuard guard(ctx);
+    WinoArgs p;
+    rc = wino4_geometry(p, N, C, H, W, C);
+    if (rc != PL_OK) return rc;
+    p.ep = make_epilogue(bias, scale, shift, resq, act, alpha);
+    return wino4_output_launch(ctx, M, yq, p, 1);
+}
+
+int pl_wino4_chain_q4_f32(pl_ctx *ctx, const float *M, int N, int C, int H, int W, const float *bias, const float *scale,
+                          const float *shift, const float *resq, int act, double alpha, float *yq, float *Vnext) {
+    int rc = wino4_stage_check("pl_wino4_chain_q4_f32", ctx, N, C, H, W, M, yq, resq, Vnext);
+    if (rc != PL_OK) return rc;
+    PL_REQUIRE(M && Vnext, PL_EINVAL, "pl_wino4_chain_q4_f32: null pointer");
+    PL_REQUIRE(act >= 0 && (act & 15) <= 2 && (act & ~31) == 0, PL_EINVAL, "pl_wino4_chain_q4_f32: bad activation code");
+    if (N == 0) return PL_OK;
+    CtxGuard guard(ctx);
+    WinoArgs p;
+    rc = wino4_geometry(p, N, C, H, W, C);
+    if (rc != PL_OK) return rc;
+    p.ep = make_epilogue(bias, scale, shift, resq, act, alpha);
+    return wino4_chain_launch(ctx, M, nullptr, p, C, yq, Vnext);
 }
 
 int pl_conv2d_winograd_q4_filter_elems(int Cout, int Cin, size_t *elems) {

@@ -148,7 +148,7 @@ class DeviceArray:
     context pool when it is garbage collected, which is what implements the
     reference's liveness-based freeing of intermediates (net.py:51-53)."""
 
-    __slots__ = ("shape", "dtype", "ptr", "ctx", "base", "host", "chan", "_owned", "__weakref__")
+    __slots__ = ("shape", "dtype", "ptr", "ctx", "base", "host", "chan", "meta", "_owned", "__weakref__")
 
     def __init__(self, shape, dtype=numpy.float32, ctx=None, ptr=None, base=None, host=None):
         self.shape = tuple(int(s) for s in shape)
@@ -156,6 +156,7 @@ class DeviceArray:
         self.ctx = ctx or (base.ctx if base is not None else context())
         self.base, self.host, self._owned = base, host, False
         self.chan = None      # channel-quad (Q4) tensors: logical channel count (planer_amd/q4.py)
+        self.meta = None      # Winograd-domain tensors: the (N, C, H, W) of the activation they stand for
         if ptr is None:
             p = c_void_p()
             _lib.call("pl_alloc", self.ctx.handle, max(self.nbytes, 1), byref(p))

@@ -28,7 +28,7 @@ from . import hip
 from .hip import DeviceArray
 from . import q4 as _q4
 from .layer import layer_map, wrap
-from .plan import assign_layouts, fuse_flow
+from .plan import assign_layouts, chain_winograd, fuse_flow
 
 _q4.register(layer_map)
 
@@ -212,6 +212,7 @@ class Net:
         self._plans = {}
         self._extra = {}             # derived constant tensors (tap-major / Winograd filters)
         self._algo = {}              # conv shape signature -> chosen w_layout
+        self.wino_chains = 0         # F(4x4,3x3) output / input transform pairs the last plan runs as one kernel
         # force_algo: w_layout (int) every eligible 3x3/s1/p1 conv must use, or None = pick by timing
         fa = os.environ.get("PLANER_HIP_CONV_ALGO")
         self.force_algo = int(fa) if fa else None
@@ -306,12 +307,17 @@ class Net:
                 val = obj(*args)
                 if profile:
                     events.append((name, obj.name, e0, hip.Event(self.ctx).record()))
-                if record is not None and obj.name in ("conv", "conv_fused", "conv_q4", "dense", "matmul"):
+                if record is not None and obj.name in ("conv", "conv_fused", "conv_q4", "dense", "matmul", "wino4_gemm"):
                     lay = obj.para().get("w_layout", 0) if obj.name != "conv" else 0
+                    lname = name
+                    if obj.name == "wino4_gemm":               # the GEMM stage of a staged F(4x4,3x3) conv
+                        lay, lname = 7, name[:-len("@gemm")]
                     ctx_ = args[0].ctx if isinstance(args[0], DeviceArray) else self.ctx
-                    record.append({"layer": name, "kind": obj.name, "w_layout": lay,
+                    xshape = (args[0].meta if args[0].meta is not None else
+                              _q4.logical_shape(args[0]) if _q4.is_q4(args[0]) else args[0].shape)
+                    record.append({"layer": lname, "kind": obj.name, "w_layout": lay,
                                    "algo": W_LAYOUT_NAMES.get(lay, str(lay)), "plan": ctx_.last_conv_plan(),
-                                   "x": list(_q4.logical_shape(args[0]) if _q4.is_q4(args[0]) else args[0].shape)})
+                                   "x": list(xshape)})
                 del args
                 if isinstance(dst, str):
                     env[dst] = val
@@ -416,7 +422,16 @@ class Net:
             out_flow = self._fuse_conv_maxpool(out_body, out_flow)
         out_flow = self._fuse_upsample_concat(out_body, out_flow)
         used = {n for _, names, _ in out_flow for n in names}
-        return [out_body[b[0]] for b in body if b[0] in used], out_flow
+        out_list = [out_body[b[0]] for b in body if b[0] in used]
+        # F(4x4,3x3) convs as explicit stages, consecutive ones sharing a transform kernel (plan.chain_winograd);
+        # PLANER_HIP_WINO_CHAIN: "1" chain (default), "stages" explicit stages without chaining, "0" one call per conv
+        mode = os.environ.get("PLANER_HIP_WINO_CHAIN", "1")
+        if mode != "0":
+            def fits(key):
+                shp = shapes.get(key.split("@")[0])
+                return shp is not None and len(shp) == 4 and _q4.wino4_chain_supported(tuple(shp), self.ctx)
+            out_list, out_flow, self.wino_chains = chain_winograd(out_list, out_flow, fits, chain=mode != "stages")
+        return out_list, out_flow
 
     @staticmethod
     def _fuse_upsample_concat(body, flow):

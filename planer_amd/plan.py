@@ -272,3 +272,63 @@ def assign_layouts(body, flow, init_names, shapes, force=False):
     if not force and est["cost"] > est["gain"]:
         return [list(b) for b in body], [[list(srcs), [name], dst] for srcs, name, dst in steps], 0
     return out_body, out_flow, nq4
+
+
+# ---- Winograd chaining ------------------------------------------------------------------------------
+# A conv_q4 step that runs F(4x4,3x3) (w_layout 7) is three kernels: input transform (x -> V), the 36
+# grouped GEMMs (V, U -> M) and output transform + fused tail (M -> y).  When the y of one such conv
+# feeds another, "M -> y -> V'" can be ONE kernel that keeps y on chip (csrc/wino4_chain_kernel.h), and
+# when nothing else reads y it is never written at all.  `chain_winograd` makes the stages explicit plan
+# steps and merges the out / in pairs.  Kinds that only read their inputs (no in-place update): a
+# Winograd input transform may be hoisted over them.
+_PURE_READERS = ("conv_q4", "wino4_in", "wino4_gemm", "wino4_out", "wino4_chain", "add_q4", "maxpool_q4",
+                 "averagepool_q4", "gap_q4", "upsample_q4", "concat_q4", "upconcat_q4", "batchnorm_q4",
+                 "leakyrelu_q4", "sigmoid_q4", "from_q4")
+WINO4_LAYOUT = 7
+
+
+def chain_winograd(body, flow, supported=lambda key: True, chain=True):
+    """-> (body', flow', number of chained pairs).  `flow` holds one layer per step (as made by
+    assign_layouts / Net._prepare_filters); `supported(key)` says whether the LDS transform kernel
+    can take the activation `key` (whole planes must fit a workgroup's LDS)."""
+    kinds = {b[0]: b for b in body}
+    steps = []                      # [srcs, name, kind, para, dst]
+    for src, names, dst in flow:
+        name = names[0] if isinstance(names, (list, tuple)) else names
+        srcs = list(src) if isinstance(src, (list, tuple)) else [src]
+        _, kind, para = kinds[name]
+        if kind == "conv_q4" and para.get("w_layout") == WINO4_LAYOUT and isinstance(dst, str):
+            full = srcs + ["None"] * (6 - len(srcs))
+            tail = {k: para[k] for k in ("act", "alpha") if k in para}
+            steps.append([[full[0]], name + "@in", "wino4_in", {}, name + "@V"])
+            steps.append([[name + "@V", full[1]], name + "@gemm", "wino4_gemm", {}, name + "@M"])
+            steps.append([[name + "@M"] + full[2:6], name + "@out", "wino4_out", tail, dst])
+        else:
+            steps.append([srcs, name, kind, para, dst])
+    nchained = 0
+    if chain:
+        last_dsts = set(_as_list(steps[-1][4])) if steps else set()
+        i = 0
+        while i < len(steps):
+            srcs, name, kind, para, dst = steps[i]
+            if kind == "wino4_out" and supported(dst):
+                readers = [j for j in range(i + 1, len(steps)) if dst in steps[j][0]]
+                # overwritten later under the same key?  then only readers before that point count
+                rewrite = [j for j in range(i + 1, len(steps)) if dst in _as_list(steps[j][4])]
+                stop = rewrite[0] if rewrite else len(steps)
+                readers = [j for j in readers if j <= stop]
+                j = next((j for j in readers if steps[j][2] == "wino4_in" and steps[j][0] == [dst]), None)
+                if j is not None and all(steps[k][2] in _PURE_READERS for k in readers if k < j):
+                    vkey = steps[j][4]
+                    keep = len(readers) > 1 or dst in last_dsts
+                    base = name[:-len("@out")]
+                    steps[i] = [srcs, base + "@chain", "wino4_chain", dict(para, keep_y=keep), [dst, vkey] if keep else vkey]
+                    del steps[j]
+                    nchained += 1
+            i += 1
+    out_body, seen = [], set()
+    for srcs, name, kind, para, dst in steps:
+        if name not in seen:
+            seen.add(name)
+            out_body.append([name, kind, para])
+    return out_body, [[srcs, [name], dst] for srcs, name, kind, para, dst in steps], nchained

@@ -237,6 +237,77 @@ def ConvQ4(xq, Kq, B=None, scale=None, shift=None, resq=None, group=1, strides=(
     return y
 
 
+# ---- Winograd F(4x4,3x3) stage by stage (plan-internal; plan.chain_winograd emits these) -----------
+def _wino_tensor(n, c, h, w, ctx):
+    """V or M of an (n, c, h, w) activation: [36][c/4][T][4], T = n * ceil(h/4) * ceil(w/4)."""
+    e = ctypes.c_size_t()
+    _lib.call("pl_wino4_elems", n, c, h, w, ctypes.byref(e))
+    t = empty((max(e.value, 1),), ctx=ctx)
+    t.meta = (n, c, h, w)
+    return t
+
+
+def wino4_chain_supported(shape, ctx):
+    """Can the LDS transform kernel (whole planes per workgroup) take an (N, C, H, W) activation?"""
+    n, c, h, w = shape
+    if c % 4:
+        return False
+    ok = ctypes.c_int()
+    _lib.call("pl_wino4_chain_supported", ctx.handle, n, c, h, w, ctypes.byref(ok))
+    return bool(ok.value)
+
+
+def Wino4In(xq):
+    """B^T d B of every 6x6 tile of a Q4 activation -> V."""
+    _f32(xq)
+    if not is_q4(xq):
+        raise TypeError("Wino4In needs a Q4 activation")
+    n, c, h, w = logical_shape(xq)
+    v = _wino_tensor(n, c, h, w, xq.ctx)
+    _lib.call("pl_wino4_input_q4_f32", xq.ctx.handle, xq.ptr, n, c, h, w, v.ptr)
+    return v
+
+
+def Wino4Gemm(v, Kq, **_):
+    """The 36 per-frequency GEMMs: V (Cin) x Winograd-domain filters -> M (Cout)."""
+    n, cin, h, w = v.meta
+    cout, cin_k, kh, kw = Kq.shape
+    if cin_k != cin or (kh, kw) != (3, 3):
+        raise ValueError("conv: weight %s does not match input %s" % (Kq.shape, (n, cin, h, w)))
+    m = _wino_tensor(n, cout, h, w, v.ctx)
+    _lib.call("pl_wino4_gemm_q4_f32", v.ctx.handle, v.ptr, n, cin, h, w, Kq.ptr, cout, m.ptr)
+    return m
+
+
+def _wino_tail_check(m, resq):
+    n, c, h, w = m.meta
+    if resq is not None and (not is_q4(resq) or logical_shape(resq) != (n, c, h, w)):
+        raise ValueError("fused residual %s != conv output %s" % (getattr(resq, "shape", None), (n, c, h, w)))
+    return n, c, h, w
+
+
+def Wino4Out(m, B=None, scale=None, shift=None, resq=None, act=ACT_NONE, alpha=0.0, **_):
+    """A^T m A + the conv's fused tail -> y (Q4)."""
+    _f32(B, scale, shift, resq)
+    n, c, h, w = _wino_tail_check(m, resq)
+    y = _new_q4(n, c, h, w, m.ctx)
+    _lib.call("pl_wino4_output_q4_f32", m.ctx.handle, m.ptr, n, c, h, w, _ptr(B), _ptr(scale), _ptr(shift), _ptr(resq),
+              int(act), float(alpha), y.ptr)
+    return y
+
+
+def Wino4Chain(m, B=None, scale=None, shift=None, resq=None, act=ACT_NONE, alpha=0.0, keep_y=True, **_):
+    """Wino4Out and the Wino4In of the next 3x3 conv in one kernel: -> (y, V) or, with keep_y=False
+    (nothing else reads y), V alone -- y then never exists in memory."""
+    _f32(B, scale, shift, resq)
+    n, c, h, w = _wino_tail_check(m, resq)
+    y = _new_q4(n, c, h, w, m.ctx) if keep_y else None
+    v = _wino_tensor(n, c, h, w, m.ctx)
+    _lib.call("pl_wino4_chain_q4_f32", m.ctx.handle, m.ptr, n, c, h, w, _ptr(B), _ptr(scale), _ptr(shift), _ptr(resq),
+              int(act), float(alpha), _ptr(y), v.ptr)
+    return (y, v) if keep_y else v
+
+
 # ---- HBM-bound layers on Q4 tensors ---------------------------------------------------------
 def _like(x, shape=None):
     y = empty(shape or x.shape, ctx=x.ctx)
@@ -381,5 +452,6 @@ Q4_LAYERS = {"maxpool": MaxpoolQ4, "averagepool": AveragePoolQ4, "gap": GlobalAv
 
 def register(layer_map):
     """Plan-internal kinds (never present in a user's IR)."""
-    layer_map.update({"to_q4": to_q4, "from_q4": from_q4, "conv_q4": ConvQ4, "upconcat_q4": UpConcatQ4})
+    layer_map.update({"to_q4": to_q4, "from_q4": from_q4, "conv_q4": ConvQ4, "upconcat_q4": UpConcatQ4,
+                      "wino4_in": Wino4In, "wino4_gemm": Wino4Gemm, "wino4_out": Wino4Out, "wino4_chain": Wino4Chain})
     layer_map.update({k + "_q4": f for k, f in Q4_LAYERS.items()})
