@@ -41,7 +41,7 @@ import numpy as np  # noqa: E402
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0
 PER_GPU_BATCH = 32                 # BASELINE.json configs[2] / configs[3]: 32 images per GPU
-PROFILE_TAG = "r02"                # profiles/<tag>_* files this build's numbers are cross-checked against
+PROFILE_TAG = "r03"                # profiles/<tag>_* files this build's numbers are cross-checked against
 
 
 def cdiv(a, b):
@@ -68,40 +68,47 @@ def conv_table(g, shapes):
     return out
 
 
-def executed_flops(rec, c):
-    """MFMA FLOPs the chosen kernel really issues for conv `c` (tile, K-chunk and Winograd-tile padding
-    included), from the launch plan the library reported (`rec["plan"]`, e.g. "wino4[q64x64x16 tiles=..]").
-    None when the plan string is not understood."""
-    m = re.search(r"[qt]?(\d+)x(\d+)(?:x(\d+))?", rec["plan"])
-    if not m:
+def executed_flops(rec):
+    """MFMA FLOPs the chosen kernel really issues (tile, K-chunk and Winograd-tile padding included): the library
+    reports the GEMM it executed -- (groups, rows, columns, K) rounded up to whole tiles and chunks
+    (pl_conv2d_last_extents) -- for every conv / dense step of the plan."""
+    ext = rec.get("extents") if rec else None
+    if not ext or min(ext) <= 0:
         return None
-    bm, bn, bk = int(m.group(1)), int(m.group(2)), int(m.group(3) or 16)
-    n, cin, cout, h, w, ho, wo = c["n"], c["cin"], c["cout"], c["h"], c["w"], c["ho"], c["wo"]
-    kh, kw = c["k"]
-    lay = rec["w_layout"]
+    g, rows, cols, k = ext
+    return 2.0 * g * rows * cols * k
 
-    def gemm(rows, cols, kquads, groups=1):
-        return 2.0 * groups * cdiv(rows, bm) * bm * cdiv(cols, bn) * bn * cdiv(kquads * 4, bk) * bk
-    pooled = re.search(r"\+maxpool .*tiles=(\d+)", rec["plan"])
-    if pooled:                         # conv + max-pool kernel: whole tiles, halo pixels computed twice
-        kq = kh * cdiv(kw * cin, 4) if lay == 6 else kh * kw * cdiv(cin // c["group"], 4)
-        return 2.0 * int(pooled.group(1)) * bm * bn * cdiv(kq * 4, bk) * bk
-    if lay == 2:
-        grp = c["group"]
-        return gemm(cout // grp, n * ho * wo, kh * kw * cdiv(cin // grp, 4), grp)
-    if lay == 6:
-        return gemm(cout, n * ho * wo, kh * cdiv(kw * cin, 4))
-    if lay == 5:
-        return 4 * gemm(cout, n * h * cdiv(w, 2), 3 * cin // 4)
-    if lay == 8:
-        return 6 * gemm(cout, n * h * cdiv(w, 4), 3 * cin // 4)
-    if lay == 4:
-        return gemm(cout, n * cdiv(h, 2) * cdiv(w, 2), cin // 4, 16)
-    if lay == 7:
-        return gemm(cout, n * cdiv(h, 4) * cdiv(w, 4), cin // 4, 36)
-    if lay in (0, 1) and rec["kind"] in ("dense", "conv", "conv_fused"):
-        return 2.0 * cdiv(cout, bm) * bm * cdiv(n * ho * wo, bn) * bn * cdiv(cin // c["group"] * kh * kw, bk) * bk
-    return None
+
+def split_step(name):
+    """Plan step name -> (layer of the user's graph, stage): "l20b_conv+@chain" -> ("l20b_conv", "chain")."""
+    base, _, stage = name.partition("@")
+    return base.rstrip("+"), stage
+
+
+def transform_bytes(prog, convs):
+    """Algorithmic HBM bytes of the Winograd F(4x4,3x3) transform steps of a fused program (each tensor read or
+    written once): x + V for an input transform, M (+ residual) + y for an output transform, M (+ residual)
+    (+ y when something else reads it) + V for a chained one.  V / M hold 36 values per 4x4 tile and channel."""
+    out = {}
+    for src, names, dst in prog.flow:
+        name = names[0]
+        obj = prog.objs[name]
+        base, stage = split_step(name)
+        c = convs.get(base)
+        if c is None or stage not in ("in", "out", "chain"):
+            continue
+        tiles = c["n"] * cdiv(c["h"], 4) * cdiv(c["w"], 4)
+        act_in, act_out = 4.0 * c["n"] * c["cin"] * c["h"] * c["w"], 4.0 * c["n"] * c["cout"] * c["ho"] * c["wo"]
+        v_in, m_out = 4.0 * 36 * c["cin"] * tiles, 4.0 * 36 * c["cout"] * tiles
+        if stage == "in":
+            out[name] = act_in + v_in
+        else:
+            res = act_out if (len(src) > 4 and src[4] != "None") else 0.0
+            if stage == "out":
+                out[name] = m_out + res + act_out
+            else:
+                out[name] = m_out + res + (act_out if obj.para().get("keep_y", True) else 0.0) + m_out
+    return out
 
 
 def sample_sclk(ctx, step, sync, samples=5):
@@ -210,6 +217,8 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive net(x_host) leg")
     ap.add_argument("--no-sclk", action="store_true", help="skip the rocm-smi shader-clock samples (profiling runs)")
     ap.add_argument("--per-layer-csv", help="write the per-layer table (HIP events) to this file")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="timed regions of K steps each, back to back; `value` is the median repeat (config.repeat_values)")
     ap.add_argument("--settle-ms", type=float, default=300.0,
                     help="run the step loop untimed for this long before the W warm-up steps, so the timed region sees "
                          "steady-state clocks (DVFS ramps over ~100 ms; the K timed steps last ~15-35 ms)")
@@ -249,10 +258,12 @@ def main():
     g, blob = build() if (rank == 0 or not comm.device_transport) else (build()[0], None)
     net = planer_amd.Net(ctx)
     net.load_json(g["input"], g["inits"], g["layers"], g["flow"])
-    t0 = time.perf_counter()
-    comm.load_weights(net, blob)
+    comm.load_weights(net, blob)                # rank 0 uploads; ONE ncclBroadcast; timed between barriers (comm.bcast_ms)
     ctx.synchronize()
-    bcast_ms = (time.perf_counter() - t0) * 1e3
+    bcast_ms = comm.bcast_ms or 0.0
+    rccl_ranks = comm.transport_ranks()
+    if world > 1 and comm.device_transport and rccl_ranks != world:
+        sys.exit("RCCL counts %d ranks in the communicator, the launcher started %d" % (rccl_ranks, world))
 
     # ---- data: this rank's shard of the global synthetic batch, resident in HBM ---
     n = args.batch
@@ -263,6 +274,7 @@ def main():
     xs = [planer_amd.asarray(a, ctx=ctx) for a in xs_host]
     # fuse + pick algorithms + tune + warm the pool + capture the hipGraph(s)
     plan = net.compile(xs[0], mode="throughput")
+    tune_src, wino_chains = net.tune_source(), net.wino_chains      # where the TIMED plan's kernel choices came from
     ctx.save_tune_cache()                       # no-op unless PLANER_HIP_TUNE_CACHE is set
     net.save_algo_cache()
     state = {"i": 0}
@@ -281,9 +293,20 @@ def main():
         for _ in range(10):
             step()
         sync()
-    elapsed = dist.timed_steps(comm, step, sync, args.steps, args.warmup)
+    # `repeats` timed regions of exactly K steps each (barrier + device sync on both sides, MAX over ranks);
+    # the line reports the MEDIAN repeat, with the spread next to it (median and best)
+    spans, own = dist.timed_repeats(comm, step, sync, args.steps, args.warmup, args.repeats)
+    order = sorted(range(len(spans)), key=lambda i: spans[i])
+    mid = order[len(order) // 2]
+    elapsed = spans[mid]
     ms_per_step = elapsed / args.steps * 1e3
     value = global_batch * args.steps / elapsed
+    repeat_values = {"repeats": len(spans), "min": round(global_batch * args.steps / max(spans), 1),
+                     "median": round(value, 1), "max": round(global_batch * args.steps / min(spans), 1),
+                     "all": [round(global_batch * args.steps / t, 1) for t in spans]}
+    # every rank's own rate over the median repeat (no barrier wait inside): min / max over ranks
+    my_rate = (hi - lo) * args.steps / own[mid]
+    rank_rates = {"min": round(comm.min_over_ranks(my_rate), 1), "max": round(comm.max_over_ranks(my_rate), 1)}
     # clock state (untimed): the shader clock sysfs reports while the same loop keeps running
     sclk_mhz = sample_sclk(ctx, step, sync) if rank == 0 and not args.no_sclk else None
 
@@ -304,8 +327,10 @@ def main():
     if rank != 0:
         return
 
+    # rank 0 alone from here (the other ranks are done: no collective follows): the CPU baseline and the
+    # full-batch parity check run at every world size, on rank 0's shard
     cpu_rep, want = None, None
-    if args.workload == "resnet18" and world == 1 and not args.no_cpu_baseline:
+    if args.workload == "resnet18" and not args.no_cpu_baseline:
         cpu_rep, want = cpu_baseline(g, blob, xs_host[0], args.cpu_iters)
         want, checked = [want], xs_host[0].shape[0]
     else:                                      # bounded: the first images of the batch only
@@ -327,6 +352,7 @@ def main():
     net._interpret(net._program, [xs[0].copy()], shapes=shapes)
     convs = conv_table(g, shapes)
     prog, _ = net._fuse(shapes)
+    tbytes = transform_bytes(prog, convs)
     per_layer = {}
     prof_steps = min(max(args.steps, 5), 20)
     for it in range(prof_steps + 2):
@@ -334,35 +360,38 @@ def main():
         if it >= 2:
             for name, kind, ms in net.last_events:
                 per_layer.setdefault((name, kind), []).append(ms)
-    algos = {a["layer"].rstrip("+"): a for a in plan.algos}
+    algos = {split_step(a["layer"])[0]: a for a in plan.algos}
     rows, classes, families = [], {}, {}
     for (name, kind), v in per_layer.items():
         ms = float(np.median(v))                 # median: one pool-growth hiccup must not skew a layer
-        base = name.rstrip("+")
+        base, stage = split_step(name)
         c, rec = convs.get(base), algos.get(base)
-        alg = c["flops"] if c else 0.0
-        exe = executed_flops(rec, c) if (c and rec) else None
+        mfma_step = c is not None and stage in ("", "gemm")          # the step of a conv that runs its GEMM(s)
+        alg = c["flops"] if mfma_step else 0.0
+        exe = executed_flops(rec) if mfma_step else None
         cls = c["cls"] if c else kind
-        fam = (rec["algo"] if rec else kind)
-        rows.append({"layer": name, "class": cls, "kernel": fam, "plan": rec["plan"] if rec else "", "ms": ms,
-                     "algorithmic_flops": alg, "executed_flops": exe})
+        fam = (rec["algo"] if (rec and c) else kind)
+        rows.append({"layer": name, "class": cls, "kernel": fam, "stage": stage, "kind": kind,
+                     "plan": rec["plan"] if (rec and mfma_step) else "", "ms": ms,
+                     "algorithmic_flops": alg, "executed_flops": exe, "hbm_bytes": tbytes.get(name)})
         for key, table in ((cls, classes), (fam, families)):
-            t = table.setdefault(key, {"ms": 0.0, "flops": 0.0, "executed": 0.0, "launches": 0})
+            t = table.setdefault(key, {"ms": 0.0, "flops": 0.0, "executed": 0.0, "launches": 0, "steps": 0})
             t["ms"] += ms
             t["flops"] += alg
             t["executed"] += exe or 0.0
-            t["launches"] += 1
+            t["launches"] += 1 if (mfma_step or not c) else 0            # convs (not their transform steps)
+            t["steps"] += 1
         if args.detail:
-            print("%-14s %-10s %8.3f ms  %7.2f TFLOP/s algorithmic  %7.2f executed  %s"
+            print("%-18s %-10s %8.3f ms  %7.2f TFLOP/s algorithmic  %7.2f executed  %s"
                   % (name, cls, ms, alg / ms / 1e9 if ms else 0, (exe or 0) / ms / 1e9 if ms else 0, fam), file=sys.stderr)
     if args.per_layer_csv:
         with open(args.per_layer_csv, "w") as f:
-            f.write("layer,class,kernel,plan,us_hip_events,algorithmic_flops,executed_flops,algorithmic_tflops,executed_tflops\n")
+            f.write("layer,class,kernel,plan,us_hip_events,algorithmic_flops,executed_flops,algorithmic_tflops,executed_tflops,hbm_bytes\n")
             for r in rows:
-                f.write("%s,%s,\"%s\",\"%s\",%.2f,%.0f,%.0f,%.2f,%.2f\n"
+                f.write("%s,%s,\"%s\",\"%s\",%.2f,%.0f,%.0f,%.2f,%.2f,%.0f\n"
                         % (r["layer"], r["class"], r["kernel"], r["plan"], r["ms"] * 1e3, r["algorithmic_flops"],
                            r["executed_flops"] or 0, r["algorithmic_flops"] / r["ms"] / 1e9,
-                           (r["executed_flops"] or 0) / r["ms"] / 1e9))
+                           (r["executed_flops"] or 0) / r["ms"] / 1e9, r["hbm_bytes"] or 0))
 
     e2e = None
     if not args.no_e2e:                        # PCIe-inclusive: host batch in, host logits out
@@ -381,7 +410,8 @@ def main():
                           "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "dtype": "f32",
                           "parity_rel_err": parity, "parity_checked_images": checked,
                           "config": {"workload": args.workload, "per_gpu_batch": n, "fused_steps": plan.fused_steps,
-                                     "streams": plan.streams, "algos": algo_list},
+                                     "streams": plan.streams, "repeat_values": repeat_values, "tune_source": tune_src,
+                                     "wino_chains": wino_chains, "algos": algo_list},
                           "conv_tflops_whole_step": round(tot / (ms_per_step * 1e-3) / 1e12, 2),
                           "by_class_ms": {k: round(v["ms"], 4) for k, v in sorted(classes.items())},
                           "pcie_inclusive_images_per_sec": e2e}))
@@ -395,21 +425,25 @@ def main():
     c3 = classes["conv3x3"]
     total_alg = sum(c["flops"] for c in convs.values())
     total_exe = sum(r["executed_flops"] or 0.0 for r in rows)
-    # HBM traffic of the dominant kernel comes from the committed rocprofv3 PMC passes of this same
-    # command (tools/profile_bench.sh; FETCH_SIZE doubled per the MI355X guide) -- it cannot be counted
-    # from inside the process, so it describes the profiled run of this build, not this very run
+    # HBM traffic of the dominant family comes from the committed rocprofv3 PMC passes of this same command
+    # (tools/profile_bench.sh: FETCH_SIZE doubled per the MI355X guide, WRITE_SIZE as reported, matched kernel by
+    # kernel to the plan's steps) -- it cannot be counted from inside the process, so it describes the profiled
+    # run of this build with the shipped tuning database, i.e. the same kernels as this run when tune_source is "shipped"
     traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", PROFILE_TAG + "_hbm_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", PROFILE_TAG + "_per_layer.csv")
     if os.path.exists(tpath):
         try:
-            tok = re.findall(r"(\w+_kernel)", dom_name)[-1]            # the family's MFMA kernel
-            fam = [r for r in json.load(open(tpath)) if tok in r["kernel"] and "reduce" not in r["kernel"]]
-            n_l = sum(r["launches"] for r in fam)
-            if n_l:
-                traffic = round(sum((r["read_mb_per_launch_corrected"] * 1e6 + r["write_kb_per_launch"] * 1e3) * r["launches"]
-                                    for r in fam) / n_l)
-                traffic_src = ("profiles/%s_hbm_traffic.json: HBM bytes per launch of %s (launch-weighted mean over its %d "
-                               "tile configurations, %d launches in the PMC run of this command)" % (PROFILE_TAG, tok, len(fam), n_l))
+            import csv
+            fam_of = {split_step(r["layer"])[0]: r["kernel"] for r in rows if r["class"].startswith("conv")}
+            tot, nk = 0.0, 0
+            for r in csv.DictReader(open(tpath)):
+                if fam_of.get(split_step(r["layer"])[0]) == dom_name and r.get("hbm_read_bytes") not in (None, ""):
+                    tot += float(r["hbm_read_bytes"]) + float(r["hbm_write_bytes"])
+                    nk += 1
+            if nk and dom["launches"]:
+                traffic = round(tot / dom["launches"])
+                traffic_src = ("profiles/%s_per_layer.csv: HBM bytes (FETCH_SIZE x 2 + WRITE_SIZE) of ALL %d kernels of the family "
+                               "in one forward / its %d convs" % (PROFILE_TAG, nk, dom["launches"]))
         except Exception:
             pass
     roofline = {
@@ -418,7 +452,8 @@ def main():
         "definition": "dominant = the conv kernel family with the largest summed device time in one forward (HIP events, "
                       "single stream, %d passes); achieved/frac count the MFMA FLOPs the kernel EXECUTES (tile, K-chunk and "
                       "Winograd-tile padding included), effective_* count the direct algorithm's FLOPs" % prof_steps,
-        "launches_per_forward": dom["launches"],
+        "launches_per_forward": dom["launches"], "kernel_steps_per_forward": dom["steps"],
+        "unit_of_a_launch": "one convolution of the family = all of its kernels (Winograd: transforms + 36 grouped GEMMs)",
         "avg_launch_ms": round(dom["ms"] / dom["launches"], 5),
         "executed_flops_per_launch": dom["executed"] / dom["launches"],
         "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
@@ -441,14 +476,23 @@ def main():
         "by_class_ms": {k: round(v["ms"], 4) for k, v in sorted(classes.items())}}
     # HBM-bound single-kernel layers: algorithmic bytes = input read once + output written once
     hbm = []
+
+    def hbm_row(name, kind, nbytes, ms):
+        return {"layer": name, "kernel": kind, "bytes": nbytes, "ms": round(ms, 5),
+                "achieved": round(nbytes / (ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": round(nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
     for (name, kind), v in per_layer.items():
         if kind in ("maxpool_q4", "maxpool", "gap_q4", "gap"):
             src = [f for f in g["flow"] if f[1][0] == name][0]
             nbytes = 4.0 * (np.prod(shapes[src[0] if isinstance(src[0], str) else src[0][0]]) + np.prod(shapes[src[2]]))
-            ms = float(np.mean(v))
-            hbm.append({"layer": name, "kernel": kind, "bytes": nbytes, "ms": round(ms, 5),
-                        "achieved": round(nbytes / (ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": round(nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)})
+            hbm.append(hbm_row(name, kind, nbytes, float(np.mean(v))))
+    # the Winograd transform kernels (each its own plan step now): tensors read / written once
+    tr = [r for r in rows if r["hbm_bytes"]]
+    for r in tr:
+        hbm.append(hbm_row(r["layer"], r["kind"], r["hbm_bytes"], r["ms"]))
+    if tr:
+        hbm.append(dict(hbm_row("all F(4x4,3x3) transform steps of one forward", "wino4_in + wino4_out + wino4_chain",
+                                sum(r["hbm_bytes"] for r in tr), sum(r["ms"] for r in tr)), steps=len(tr)))
 
     out = {"metric": "images/sec ResNet-18 fp32 forward", "value": round(value, 1), "unit": "images/sec",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -458,7 +502,10 @@ def main():
            "config": {"workload": "ResNet-18 planer IR (70 layers), forward, batch %d per GPU, 224x224, fp32, "
                                   "channel-quad activations, fused conv epilogues, hipGraph replay" % n,
                       "global_batch": global_batch, "per_gpu_batch": n, "parallelism": "batch-shard x%d" % world,
-                      "weight_bcast_ms": round(bcast_ms, 2),
+                      "weight_bcast_ms": round(bcast_ms, 3), "rccl_ranks": rccl_ranks,
+                      "rank_images_per_sec": rank_rates, "repeat_values": repeat_values,
+                      "tune_source": tune_src, "wino_chains": wino_chains,
+                      "plan_steps": [[names[0], prog.objs[names[0]].name] for _, names, _ in prog.flow],
                       "weight_exchange": ("single process" if world == 1 else "one ncclBroadcast of the uint8 blob (RCCL)"
                                           if comm.device_transport else "local upload per rank -- " + getattr(comm, "why", "")),
                       "fused_steps": plan.fused_steps,
@@ -471,7 +518,8 @@ def main():
                       "algos": algo_list},
            "roofline": roofline, "roofline_hbm": hbm,
            "per_layer": [{"layer": r["layer"], "kernel": r["kernel"].split(" ")[0], "us": round(r["ms"] * 1e3, 2),
-                          "algorithmic_flops": r["algorithmic_flops"], "executed_flops": r["executed_flops"]} for r in rows]}
+                          "algorithmic_flops": r["algorithmic_flops"], "executed_flops": r["executed_flops"],
+                          "hbm_bytes": r["hbm_bytes"]} for r in rows]}
     if cpu_rep is not None:
         out["cpu_baseline"] = cpu_rep
         out["gpu_over_cpu"] = round(value / cpu_rep["value"], 1)

@@ -277,6 +277,13 @@ int pl_conv2d_num_configs(void);
  * configuration, data-parallel tiles / split-K slices / occupancy pin, e.g.
  * "wino4[q64x64x16 dp=1800 split=1 occ=0]".  For run reports (bench.py config.algos). */
 int pl_conv2d_last_plan(pl_ctx *ctx, char *buf, size_t len);
+/* The GEMM that launch executed on the matrix cores, padding included: ext4 = {groups (Winograd: frequencies),
+ * rows, columns, K} with rows / columns rounded up to whole tiles and K to whole chunks; executed FLOPs =
+ * 2 * ext4[0] * ext4[1] * ext4[2] * ext4[3] (bench.py roofline.frac). */
+int pl_conv2d_last_extents(pl_ctx *ctx, long long *ext4);
+/* Launch-plan cache of this context's device: entries held, and how many conv shapes had to be timed
+ * (autotuned) by this context because no entry existed (0 = every launch plan came from a loaded cache). */
+int pl_tune_stats(pl_ctx *ctx, int *entries, int *misses);
 int pl_conv2d_config_name(int cfg, char *buf, size_t len);
 
 /* layer.Dense (layer.py:15-18): y[M,N] = x[M,K] @ w[N,K]^T + bias[N]  (trans_b=1)
@@ -406,6 +413,8 @@ int pl_comm_init_rank(pl_ctx *ctx, int world, int rank, const void *id);
 int pl_comm_bcast(pl_ctx *ctx, void *buf, size_t bytes, int root);
 int pl_comm_allreduce_max_f32(pl_ctx *ctx, float *buf, size_t n); /* in place, device */
 int pl_comm_allgather(pl_ctx *ctx, const void *send, void *recv, size_t bytes_per_rank);
+/* what RCCL itself says about the communicator: ncclCommCount / ncclCommUserRank (run reports: config.rccl_ranks) */
+int pl_comm_info(pl_ctx *ctx, int *ranks, int *rank);
 int pl_comm_destroy(pl_ctx *ctx);
 
 #ifdef __cplusplus

@@ -97,6 +97,8 @@ SIGNATURES = {
     "pl_conv2d_num_configs": [],
     "pl_conv2d_config_name": [_I, c_char_p, _Z],
     "pl_conv2d_last_plan": [_P, c_char_p, _Z],
+    "pl_conv2d_last_extents": [_P, POINTER(c_longlong)],
+    "pl_tune_stats": [_P, POINTER(c_int), POINTER(c_int)],
     "pl_gemm_f32": [_P, _P, _I, _I, _P, _I, _I, _P, _P],
     "pl_scale_shift_f32": [_P, _P, _P, _P, _P, _I, _I, _I],
     "pl_relu_f32": [_P, _P, _P, _Z],
@@ -135,6 +137,7 @@ SIGNATURES = {
     "pl_comm_bcast": [_P, _P, _Z, _I],
     "pl_comm_allreduce_max_f32": [_P, _P, _Z],
     "pl_comm_allgather": [_P, _P, _P, _Z],
+    "pl_comm_info": [_P, POINTER(c_int), POINTER(c_int)],
     "pl_comm_destroy": [_P],
 }
 _RESTYPE = {"pl_last_error": c_char_p}

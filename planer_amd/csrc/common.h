@@ -74,6 +74,8 @@ struct pl_ctx {
     int conv_t1 = 0, conv_occ = 0;
     void *sync_event = nullptr;      // hipEvent_t used by pl_stream_wait
     std::string last_plan;           // how the last conv on this context was launched (pl_conv2d_last_plan)
+    long long last_gemm[4] = {0, 0, 0, 0};   // executed GEMM extents of that conv: groups, padded rows, cols, K (pl_conv2d_last_extents)
+    int tune_misses = 0;             // conv shapes this context had to time because no cached launch plan existed
 
     // RCCL (dlopen'ed on first use)
     void *comm = nullptr;

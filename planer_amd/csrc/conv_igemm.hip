@@ -881,6 +881,12 @@ int run_plan(pl_ctx *ctx, const ConvArgs &a0, const Plan &pl, bool avec, float *
         char buf[96];
         snprintf(buf, sizeof buf, "%s tiles=%d dp=%d split=%d occ=%d", ci.name, T, t1, s2, pl.occ);
         ctx->last_plan = buf;
+        // what the matrix cores execute: whole tiles and whole K chunks
+        const int kq = ci.tap == 2 ? a.Qtot * 4 : a.K;
+        ctx->last_gemm[0] = a.groups;
+        ctx->last_gemm[1] = (long long)a.mtiles * ci.bm;
+        ctx->last_gemm[2] = (long long)a.ntiles * ci.bn;
+        ctx->last_gemm[3] = (long long)(kq + ci.bk - 1) / ci.bk * ci.bk;
     }
     int used = 0;
     int rc = launch_pass(ctx, a, ci, avec, 0, t1, 1, pl.occ, y, &used);
@@ -1186,6 +1192,8 @@ int conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const
                                    lds_pc(t7), ctx->stream, sa);
                 PL_LAUNCH_CHECK();
                 ctx->last_plan = "smallcin3x3pc " + std::to_string(t7) + "x256px x 64co";
+                ctx->last_gemm[0] = 1; ctx->last_gemm[1] = (long long)co_blocks * SC_CO;
+                ctx->last_gemm[2] = (long long)N * tiles_img * SC_PIX; ctx->last_gemm[3] = (long long)sa.steps * 2;
                 return PL_OK;
             }
         }
@@ -1209,6 +1217,8 @@ int conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const
                                dim3(256), lds, ctx->stream, sa);
             PL_LAUNCH_CHECK();
             ctx->last_plan = "smallcin3x3 " + std::to_string(tpw) + "x256px x 64co";
+            ctx->last_gemm[0] = 1; ctx->last_gemm[1] = (long long)co_blocks * SC_CO;
+            ctx->last_gemm[2] = (long long)N * tiles_img * SC_PIX; ctx->last_gemm[3] = (long long)sa.steps * 2;
             return PL_OK;
         }
     }
@@ -1259,7 +1269,10 @@ int conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const
         plan = choose_plan(ctx, layout, a);
         PL_REQUIRE(plan.cfg >= 0, PL_EUNSUPPORTED, "conv2d: no kernel configuration applies");
         const bool tune = ctx->autotune && !ctx->capturing && res != y && x != y;
-        if (tune) plan = tune_plan(ctx, layout, a, avec, y, plan);
+        if (tune) {
+            plan = tune_plan(ctx, layout, a, avec, y, plan);
+            ++ctx->tune_misses;
+        }
         if (tune || !ctx->autotune) {
             std::lock_guard<std::mutex> lk(g_tune_mu);
             g_tune[{ctx->device, key}] = plan;
@@ -1311,6 +1324,8 @@ int conv_pool_run(pl_ctx *ctx, ConvArgs a) {
     char buf[96];
     snprintf(buf, sizeof buf, "q64x256x16+maxpool patch=%dx%d tiles=%d", ph, pw, a.tiles * a.groups);
     ctx->last_plan = buf;
+    ctx->last_gemm[0] = a.groups; ctx->last_gemm[1] = (long long)a.mtiles * C::BM; ctx->last_gemm[2] = (long long)a.ntiles * C::BN;
+    ctx->last_gemm[3] = (long long)total_chunks * C::BK;
     return PL_OK;
 }
 
@@ -2151,6 +2166,12 @@ int w1d_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const
         if (pc) snprintf(buf, sizeof buf, "w1d4pc 64x64x8 tiles=%d grid=%d", a.tiles, pc_grid);
         else snprintf(buf, sizeof buf, "%s tiles=%d", f43 ? "w1d4 64x64x8" : "w1d 64x64x16", a.tiles);
         ctx->last_plan = buf;
+        // 6 (F(4,3)) or 4 (F(2,3)) frequency GEMMs of (Cout x 3 Cin) . (3 Cin x column tiles), 64 x 64 tiles, whole chunks
+        const int bk = f43 ? 8 : 16;
+        ctx->last_gemm[0] = f43 ? 6 : 4;
+        ctx->last_gemm[1] = (long long)(Cout + 63) / 64 * 64;
+        ctx->last_gemm[2] = (long long)(a.cols + 63) / 64 * 64;
+        ctx->last_gemm[3] = (long long)(a.Qtot * 4 + bk - 1) / bk * bk;
     }
     return PL_OK;
 }
@@ -2657,6 +2678,24 @@ int pl_tune_cache_load(pl_ctx *ctx, const char *path, int *entries) {
     return PL_OK;
 }
 
+int pl_tune_stats(pl_ctx *ctx, int *entries, int *misses) {
+    PL_REQUIRE(ctx, PL_EINVAL, "pl_tune_stats: null context");
+    if (entries) {
+        std::lock_guard<std::mutex> lk(g_tune_mu);
+        int n = 0;
+        for (auto &kv : g_tune) n += kv.first.first == ctx->device;
+        *entries = n;
+    }
+    if (misses) *misses = ctx->tune_misses;
+    return PL_OK;
+}
+
+int pl_conv2d_last_extents(pl_ctx *ctx, long long *ext4) {
+    PL_REQUIRE(ctx && ext4, PL_EINVAL, "pl_conv2d_last_extents: null argument");
+    for (int i = 0; i < 4; ++i) ext4[i] = ctx->last_gemm[i];
+    return PL_OK;
+}
+
 int pl_set_autotune(pl_ctx *ctx, int enabled) {
     PL_REQUIRE(ctx, PL_EINVAL, "null ctx");
     ctx->autotune = enabled != 0;
@@ -2716,6 +2755,8 @@ int pl_gemm_f32(pl_ctx *ctx, const float *a, int M, int K, const float *b, int N
             a, b, bias, y, M, K, N, (unsigned)((size_t)M * K * 4), (unsigned)((size_t)N * K * 4));
         PL_LAUNCH_CHECK();
         ctx->last_plan = "dense32x32 tiles=" + std::to_string(((N + 31) / 32) * ((M + 31) / 32)) + " kwaves=4";
+        ctx->last_gemm[0] = 1; ctx->last_gemm[1] = (long long)(N + 31) / 32 * 32;
+        ctx->last_gemm[2] = (long long)(M + 31) / 32 * 32; ctx->last_gemm[3] = (long long)(K + 7) / 8 * 8;
         return PL_OK;
     }
     if (trans_b)

@@ -25,7 +25,7 @@ void pl_set_error(const char *fmt, ...) {
 extern "C" {
 
 const char *pl_last_error(void) { return g_err.c_str(); }
-int pl_version(void) { return 100; }
+int pl_version(void) { return 300; }
 
 int pl_device_count(int *count) {
     PL_REQUIRE(count, PL_EINVAL, "pl_device_count: null out");
@@ -369,6 +369,8 @@ struct RcclApi {
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t,
                               hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
 };
 
 static RcclApi *rccl() {
@@ -389,6 +391,8 @@ static RcclApi *rccl() {
         SYM(AllReduce, "ncclAllReduce");
         SYM(AllGather, "ncclAllGather");
         SYM(GetErrorString, "ncclGetErrorString");
+        SYM(CommCount, "ncclCommCount");
+        SYM(CommUserRank, "ncclCommUserRank");
 #undef SYM
     });
     if (!api.lib || !api.GetUniqueId || !api.CommInitRank || !api.Broadcast || !api.AllReduce ||
@@ -458,6 +462,15 @@ int pl_comm_allgather(pl_ctx *ctx, const void *send, void *recv, size_t bytes_pe
     RcclApi *api = rccl();
     CtxGuard g(ctx);
     PL_RCCL(api, api->AllGather(send, recv, bytes_per_rank, ncclUint8, (ncclComm_t)ctx->comm, ctx->stream));
+    return PL_OK;
+}
+
+int pl_comm_info(pl_ctx *ctx, int *ranks, int *rank) {
+    PL_REQUIRE(ctx && ctx->comm, PL_EINVAL, "pl_comm_info: no communicator");
+    RcclApi *api = rccl();
+    PL_REQUIRE(api && api->CommCount && api->CommUserRank, PL_ERCCL, "librccl has no ncclCommCount / ncclCommUserRank");
+    if (ranks) PL_RCCL(api, api->CommCount((ncclComm_t)ctx->comm, ranks));
+    if (rank) PL_RCCL(api, api->CommUserRank((ncclComm_t)ctx->comm, rank));
     return PL_OK;
 }
 

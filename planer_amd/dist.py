@@ -83,13 +83,26 @@ class Communicator:
     def max_over_ranks(self, value):
         raise NotImplementedError
 
+    def min_over_ranks(self, value):
+        return -self.max_over_ranks(-float(value))
+
+    bcast_ms = None      # device time of the last weight broadcast, max over ranks (load_weights)
+
     def load_weights(self, net, blob, root=0):
         """Rank `root` uploads the blob; everyone else receives the device
         copy by broadcast, then refreshes the host mirror of the small
-        parameter tensors (UpSample scales are read on the host)."""
+        parameter tensors (UpSample scales are read on the host).  The
+        broadcast alone is timed: barrier + device sync on both sides, the
+        maximum over ranks lands in `bcast_ms`."""
+        sync = getattr(getattr(net, "ctx", None), "synchronize", lambda: None)
         if self.rank == root:
             net.load_weights(blob)
+        sync()
+        self.barrier()
+        t0 = time.perf_counter()
         self.bcast_device(net.weight_blob(), root)
+        sync()
+        self.bcast_ms = self.max_over_ranks((time.perf_counter() - t0) * 1e3)
         if self.rank != root:
             net.refresh_host_mirror()
         self.barrier()
@@ -98,6 +111,12 @@ class Communicator:
 class SingleProcess(Communicator):
     def bcast_device(self, arr, root=0):
         return arr
+
+    def min_over_ranks(self, value):
+        return float(value)
+
+    def transport_ranks(self):
+        return 1
 
     def barrier(self):
         pass
@@ -128,6 +147,17 @@ class RcclCommunicator(Communicator):
         self._scratch.set(numpy.full(4, value, numpy.float32))
         _lib.call("pl_comm_allreduce_max_f32", self.ctx.handle, self._scratch.ptr, 4)
         return float(self._scratch.get()[0])
+
+    def min_over_ranks(self, value):
+        return -self.max_over_ranks(-float(value))
+
+    def transport_ranks(self):
+        """How many ranks RCCL itself counts in the communicator (ncclCommCount)."""
+        n, r = _lib.c_int(), _lib.c_int()
+        _lib.call("pl_comm_info", self.ctx.handle, _lib.byref(n), _lib.byref(r))
+        if r.value != self.rank:
+            raise RuntimeError("RCCL says this is rank %d, the launcher said %d" % (r.value, self.rank))
+        return n.value
 
     def barrier(self):
         self.max_over_ranks(0.0)           # an all-reduce is a barrier; .get() syncs the stream
@@ -192,6 +222,12 @@ class FileCommunicator(Communicator):
 
     def max_over_ranks(self, value):
         return max(self._gather(value))
+
+    def min_over_ranks(self, value):
+        return min(self._gather(value))
+
+    def transport_ranks(self):
+        return 0                               # no RCCL communicator behind this transport
 
     def load_weights(self, net, blob, root=0):
         if blob is None:
@@ -291,3 +327,26 @@ def timed_steps(comm, step, sync, steps, warmup):
     comm.barrier()
     sync()
     return comm.max_over_ranks(elapsed)
+
+
+def timed_repeats(comm, step, sync, steps, warmup, repeats=5):
+    """`repeats` back-to-back timed regions of exactly `steps` steps each (timed_steps; the warm-up runs before
+    the first one only) -> (per-repeat MAX-over-ranks seconds, this rank's own seconds per repeat).  The bench
+    reports the median repeat and the spread (median and best)."""
+    spans, own = [], []
+    for r in range(max(1, int(repeats))):
+        for _ in range(warmup if r == 0 else 0):
+            step()
+        sync()
+        comm.barrier()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        sync()
+        mine = time.perf_counter() - t0
+        comm.barrier()
+        sync()
+        own.append(mine)
+        spans.append(comm.max_over_ranks(mine))
+    return spans, own

@@ -33,7 +33,17 @@ class Context:
         _lib.check(lib.pl_ctx_info(h, byref(dev), byref(cus), byref(hbm), name, 64))
         self.cu_count, self.hbm_bytes, self.arch = cus.value, hbm.value, name.value.decode()
         self.comm = None
-        # PLANER_HIP_TUNE_CACHE=<file>: reuse conv launch plans found by earlier runs
+        # Launch plans (tile configuration, split-K, occupancy pin per conv shape) are found by timing on first use
+        # (pl_conv2d_*: MIOpen-find style).  Two sources spare a run that search and make its kernels repeatable:
+        #   * the database shipped with the package for this (architecture, CU count) -- planer_amd/tuned/,
+        #     loaded by default (PLANER_HIP_TUNED=0 turns it off);
+        #   * PLANER_HIP_TUNE_CACHE=<file>: plans found by earlier runs of this user, loaded on top and saved back.
+        self.tuned_db = tuned_db_path(self.arch, self.cu_count) if os.environ.get("PLANER_HIP_TUNED", "1") != "0" else None
+        self.tuned_entries = 0
+        if self.tuned_db and os.path.exists(self.tuned_db + ".plans"):
+            self.tuned_entries = self.load_tune_cache(self.tuned_db + ".plans")
+        else:
+            self.tuned_db = None
         self.tune_cache = os.environ.get("PLANER_HIP_TUNE_CACHE")
         if self.tune_cache:
             self.load_tune_cache(self.tune_cache)
@@ -76,6 +86,18 @@ class Context:
         """Force a full launch plan: `dp_tiles` data-parallel tiles + the rest split `split_k` ways."""
         _lib.call("pl_conv2d_set_plan", self.handle, int(cfg), int(dp_tiles), int(split_k), int(occupancy))
 
+    def tune_stats(self):
+        """(launch plans held for this device, conv shapes this context had to time itself)."""
+        n, m = c_int(), c_int()
+        _lib.call("pl_tune_stats", self.handle, byref(n), byref(m))
+        return n.value, m.value
+
+    def last_conv_extents(self):
+        """(groups, rows, columns, K) of the GEMM the last conv / dense launch executed, tile and chunk padding included."""
+        ext = (ctypes.c_longlong * 4)()
+        _lib.call("pl_conv2d_last_extents", self.handle, ext)
+        return tuple(int(v) for v in ext)
+
     def last_conv_plan(self):
         """How the last convolution on this context was launched (kernel family, tile plan)."""
         buf = ctypes.create_string_buffer(160)
@@ -86,6 +108,12 @@ class Context:
         if self.handle is not None:
             _lib.load().pl_ctx_destroy(self.handle)
             self.handle = None
+
+
+def tuned_db_path(arch, cu_count):
+    """Stem of the shipped tuning database for a device: planer_amd/tuned/<arch>_cu<CUs> (+ ".plans": launch plans in
+    pl_tune_cache_save's format, + ".algo.json": conv algorithm and stream-plan picks of planer_amd.net)."""
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "%s_cu%d" % (arch.split(":")[0], cu_count))
 
 
 def device_count():
@@ -148,7 +176,7 @@ class DeviceArray:
     context pool when it is garbage collected, which is what implements the
     reference's liveness-based freeing of intermediates (net.py:51-53)."""
 
-    __slots__ = ("shape", "dtype", "ptr", "ctx", "base", "host", "chan", "meta", "_owned", "__weakref__")
+    __slots__ = ("shape", "dtype", "_p", "ctx", "base", "host", "chan", "meta", "_owned", "__weakref__")
 
     def __init__(self, shape, dtype=numpy.float32, ctx=None, ptr=None, base=None, host=None):
         self.shape = tuple(int(s) for s in shape)
@@ -158,11 +186,27 @@ class DeviceArray:
         self.chan = None      # channel-quad (Q4) tensors: logical channel count (planer_amd/q4.py)
         self.meta = None      # Winograd-domain tensors: the (N, C, H, W) of the activation they stand for
         if ptr is None:
-            p = c_void_p()
-            _lib.call("pl_alloc", self.ctx.handle, max(self.nbytes, 1), byref(p))
-            self.ptr, self._owned = p.value, True
+            self._p = None
+            if host is None or base is not None:
+                self._allocate()
+            # else: a host-mirrored tensor (shape-domain values, layer._mirrored) gets its device copy on first use of
+            # `.ptr` -- values that only steer views never touch the stream
         else:
-            self.ptr = int(ptr)
+            self._p = int(ptr)
+
+    def _allocate(self):
+        p = c_void_p()
+        _lib.call("pl_alloc", self.ctx.handle, max(self.nbytes, 1), byref(p))
+        self._p, self._owned = p.value, True
+
+    @property
+    def ptr(self):
+        if self._p is None:
+            self._allocate()
+            if self.host is not None and self.nbytes:
+                h = numpy.require(self.host, dtype=self.dtype, requirements="C")
+                _lib.call("pl_h2d", self.ctx.handle, self._p, h.ctypes.data, h.nbytes)
+        return self._p
 
     # -- numpy-like metadata ------------------------------------------------
     @property
@@ -208,6 +252,8 @@ class DeviceArray:
             n *= s
         if n != self.size:
             raise ValueError("cannot reshape array of size %d into shape %s" % (self.size, tuple(shape)))
+        if self._p is None:                        # host-mirrored, not on the device yet: stay lazy
+            return DeviceArray(shape, self.dtype, self.ctx, host=self.host.reshape(shape))
         v = self._view(shape)
         if self.host is not None:
             v.host = self.host.reshape(shape)
@@ -237,6 +283,8 @@ class DeviceArray:
     # -- transfers ----------------------------------------------------------------
     def get(self):
         """Device -> host copy (synchronises the stream), cupy's `.get()`."""
+        if self._p is None:                        # host-mirrored tensor that never went to the device
+            return numpy.array(self.host, dtype=self.dtype).reshape(self.shape)
         out = numpy.empty(self.shape, self.dtype)
         if out.nbytes:
             _lib.call("pl_d2h", self.ctx.handle, out.ctypes.data, self.ptr, out.nbytes)
@@ -250,14 +298,19 @@ class DeviceArray:
         host = numpy.require(host, dtype=self.dtype, requirements="C")      # (ascontiguousarray lifts 0-d to 1-d)
         if host.shape != self.shape:
             raise ValueError("shape mismatch %s vs %s" % (host.shape, self.shape))
+        if self._p is None:
+            self._allocate()
         if host.nbytes:
-            _lib.call("pl_h2d", self.ctx.handle, self.ptr, host.ctypes.data, host.nbytes)
+            _lib.call("pl_h2d", self.ctx.handle, self._p, host.ctypes.data, host.nbytes)
+        if self.host is not None:                  # keep a host mirror in step with the device copy
+            self.host = host.copy()
         return self
 
     def copy_from(self, other):
         if other.nbytes != self.nbytes:
             raise ValueError("size mismatch")
         _lib.call("pl_d2d", self.ctx.handle, self.ptr, other.ptr, self.nbytes)
+        self.host = None                           # a mirror would be stale now
         return self
 
     def copy(self):
@@ -265,8 +318,8 @@ class DeviceArray:
 
     def __del__(self):
         try:
-            if self._owned and self.ptr and self.ctx.handle is not None:
-                _lib.load().pl_free(self.ctx.handle, self.ptr)
+            if self._owned and self._p and self.ctx.handle is not None:
+                _lib.load().pl_free(self.ctx.handle, self._p)
         except Exception:
             pass
 

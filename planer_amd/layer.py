@@ -670,11 +670,7 @@ def ConvTranspose2d(x, K, B=None, strides=[2, 2], dilations=[1, 1], pads=[0, 0, 
 # stream synchronisation.  float32 activations never take this route.
 def _mirrored(host, ctx=None):
     host = numpy.require(host, requirements="C")
-    d = DeviceArray(host.shape, host.dtype, ctx)
-    if host.nbytes:
-        d.set(host)
-    d.host = host
-    return d
+    return DeviceArray(host.shape, host.dtype, ctx, host=host)      # uploaded on first use of `.ptr`, if ever
 
 
 def _shape_domain(args):

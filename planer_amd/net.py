@@ -209,6 +209,7 @@ class Net:
         self._blob = None
         self._slots = []             # (offset, nbytes) per weight inside the blob
         self._program = None
+        self._eager_prog = None      # fused program for nets whose flow cannot be captured (Net.__call__)
         self._plans = {}
         self._extra = {}             # derived constant tensors (tap-major / Winograd filters)
         self._algo = {}              # conv shape signature -> chosen w_layout
@@ -217,10 +218,14 @@ class Net:
         fa = os.environ.get("PLANER_HIP_CONV_ALGO")
         self.force_algo = int(fa) if fa else None
         # choices persist next to the C library's launch-plan cache, so a second run (profiling!)
-        # launches no trial kernels and reproduces the first run's kernels exactly
+        # launches no trial kernels and reproduces the first run's kernels exactly; the database shipped in
+        # planer_amd/tuned/ (hip.Context.tuned_db) holds the picks for the BASELINE workloads on this device
         tc = os.environ.get("PLANER_HIP_TUNE_CACHE")
         self.algo_cache = tc + ".algo.json" if tc else None
         self._algo_loaded = False
+        self._streams_pick = {}      # compile key -> stream plan ("pipe3", "2x2", ...) chosen by measurement
+        self.algo_misses = 0         # conv algorithm picks that had to be measured (no cached choice)
+        self.stream_misses = 0       # stream-plan picks that had to be measured
 
     # ---- loading ----------------------------------------------------------------
     def load_json(self, inputs, inits, body, flow, debug=False):
@@ -259,7 +264,7 @@ class Net:
             self._host[o:o + n] = raw[pos:pos + n]
             pos += n
         self._blob.set(self._host)
-        self._plans, self._extra = {}, {}
+        self._plans, self._extra, self._eager_prog = {}, {}, None
 
     def weight_blob(self):
         """The single device allocation holding all weights (RCCL broadcast unit)."""
@@ -317,7 +322,7 @@ class Net:
                               _q4.logical_shape(args[0]) if _q4.is_q4(args[0]) else args[0].shape)
                     record.append({"layer": lname, "kind": obj.name, "w_layout": lay,
                                    "algo": W_LAYOUT_NAMES.get(lay, str(lay)), "plan": ctx_.last_conv_plan(),
-                                   "x": list(xshape)})
+                                   "extents": list(ctx_.last_conv_extents()), "x": list(xshape)})
                 del args
                 if isinstance(dst, str):
                     env[dst] = val
@@ -508,8 +513,9 @@ class Net:
                 raise ValueError("force_algo=%r does not apply to conv %s k%s" % (self.force_algo, xs, tuple(K.shape)))
             return self.force_algo
         self._load_algo_cache()
-        if sig in self._algo:
+        if sig in self._algo and self._algo[sig] in [c[0] for c in cands]:      # (a stored pick this run's switches exclude is ignored)
             return self._algo[sig]
+        self.algo_misses += 1
         ctx = self.ctx
         # random operands: zero tensors clock ~19 % higher (DVFS) and would bias the pick towards
         # the MFMA-heavy candidates (MI355X guide, "DVFS give-back")
@@ -555,31 +561,69 @@ class Net:
     def _sig_key(sig):
         return repr(sig)
 
+    def _device_tag(self):
+        ctx = self.ctx or hip.context()
+        return "%s cu%d lib%d" % (ctx.arch.split(":")[0], ctx.cu_count, _lib.load().pl_version())
+
     def _load_algo_cache(self):
-        if self._algo_loaded or not self.algo_cache:
+        """Shipped database first (planer_amd/tuned/<arch>_cu<N>.algo.json), then the user's cache on top.  A file
+        written for another device or library version is ignored."""
+        if self._algo_loaded:
             return
         self._algo_loaded = True
-        try:
-            import json
-            with open(self.algo_cache) as f:
-                stored = json.load(f)
-        except (OSError, ValueError):
-            return
         import ast
-        for k, v in stored.items():
+        import json
+        ctx = self.ctx or hip.context()
+        shipped = ctx.tuned_db + ".algo.json" if getattr(ctx, "tuned_db", None) else None
+        for path in (shipped, self.algo_cache):
+            if not path:
+                continue
             try:
-                self._algo.setdefault(ast.literal_eval(k), int(v))
-            except (ValueError, SyntaxError):
-                pass
+                with open(path) as f:
+                    stored = json.load(f)
+            except (OSError, ValueError):
+                continue
+            if "algo" not in stored:                       # round-2 files: a flat {signature: layout} table
+                stored = {"device": None, "algo": stored, "streams": {}}
+            if stored.get("device") not in (None, self._device_tag()):
+                continue
+            for k, v in stored.get("algo", {}).items():
+                try:
+                    self._algo[ast.literal_eval(k)] = int(v)
+                except (ValueError, SyntaxError):
+                    pass
+            self._streams_pick.update({str(k): str(v) for k, v in stored.get("streams", {}).items()})
 
     def save_algo_cache(self, path=None):
-        """Persist the per-shape conv algorithm choices (next to PLANER_HIP_TUNE_CACHE by default)."""
+        """Persist the per-shape conv algorithm choices and the stream-plan choices (next to PLANER_HIP_TUNE_CACHE
+        by default): written to a temporary file and renamed, by rank 0 only."""
         path = path or self.algo_cache
-        if not path:
+        if not path or os.environ.get("RANK", "0") != "0":
             return
         import json
-        with open(path, "w") as f:
-            json.dump({self._sig_key(k): v for k, v in sorted(self._algo.items(), key=repr)}, f, indent=1)
+        data = {"device": self._device_tag(),
+                "algo": {self._sig_key(k): v for k, v in sorted(self._algo.items(), key=repr)},
+                "streams": dict(sorted(self._streams_pick.items()))}
+        tmp = "%s.%d.tmp" % (path, os.getpid())
+        with open(tmp, "w") as f:
+            json.dump(data, f, indent=1)
+        os.replace(tmp, path)
+
+    def tune_source(self):
+        """Where this net's kernel choices came from, for run reports: "shipped" (every launch plan, algorithm and
+        stream plan was in the database shipped for this device), "cache", or what had to be measured."""
+        ctx = self.ctx
+        _, plan_misses = ctx.tune_stats()
+        for c in self._side:
+            plan_misses += c.tune_stats()[1]
+        base = "shipped" if getattr(ctx, "tuned_db", None) else None
+        if ctx.tune_cache and os.path.exists(ctx.tune_cache):
+            base = (base + " + cache") if base else "cache"
+        miss = plan_misses + self.algo_misses + self.stream_misses
+        if not miss:
+            return base or "static heuristics (autotune off)"
+        what = "autotuned: %d launch plans, %d conv algorithms, %d stream plans" % (plan_misses, self.algo_misses, self.stream_misses)
+        return "%s; %s" % (base, what) if base else what
 
     def compile(self, *xs, mode="latency"):
         """Build (or fetch) the captured plan for these device inputs.  `mode` only affects how
@@ -618,6 +662,17 @@ class Net:
             cands = [(1, 1)]
         if want.startswith("pipe"):
             cands, pipes = [], [int(want[4:] or 2)]
+        # a stream plan chosen for this (mode, inputs, graph) before -- shipped database or the user's cache -- is taken
+        # without measuring, so that consecutive runs time the same thing
+        self._load_algo_cache()
+        pick_key = repr((mode, [tuple(a.shape) for a in xs], len(self.flow), want))
+        stored = self._streams_pick.get(pick_key) if want == "auto" else None
+        if stored and stored.startswith("pipe") and mode == "throughput":
+            cands, pipes = [], [int(stored[4:])]
+        elif stored and "x" in stored:
+            q, _, p_ = stored.partition("x")
+            if (int(q), int(p_)) in cands:
+                cands, pipes = [(int(q), int(p_))], []
         progs = {}
 
         def program_for(P):
@@ -641,6 +696,10 @@ class Net:
                     cand = self._build_plan(prog, xs, Q, P, nfused)
                 except _NotSplittable:
                     continue
+                except _lib.NotCapturable:
+                    self._eager_prog = program_for(1)[0]      # Net.__call__ runs this one eagerly
+                    self.timer = timer
+                    raise
             else:
                 prog, nfused = program_for(1)
                 reps = []
@@ -662,19 +721,24 @@ class Net:
                 ctx.synchronize()
             burst(5)
             cand.ms = None
-            for _ in range(5):                 # best of five short bursts: a noisy pick costs up to 7 % of
-                t0 = time.perf_counter()       # throughput; deeper bursts overflow rocprofv3's queue interception
-                burst(10)
-                ms = (time.perf_counter() - t0) / 10 * 1e3
+            # latency plans: best of five bursts of 10 passes.  Pipelined (throughput) plans are judged in steady
+            # state -- best of three runs of 100 passes -- because a 10-pass burst is mostly pipeline fill and drain
+            # and under-rates the deeper pipeline (host run-ahead is bounded by _Plan.max_in_flight)
+            reps, depth = (3, 100) if how == "pipe" else (5, 10)
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                burst(depth)
+                ms = (time.perf_counter() - t0) / depth * 1e3
                 cand.ms = ms if cand.ms is None else min(cand.ms, ms)
             if os.environ.get("PLANER_PLAN_LOG"):
                 import sys
                 print("[planer_amd] plan candidate %s: %.4f ms/pass" % (cand.streams, cand.ms), file=sys.stderr)
-            # short bursts (fill + drain every 10 passes) under-represent a deeper pipeline's steady
-            # state: in long runs pipe3 is ~4 % ahead of pipe2 where the bursts show ~2 %
-            cand.score = cand.ms * (1.0 - 0.02 * (len(cand.replicas) - 2)) if how == "pipe" else cand.ms
-            if best is None or cand.score < best.score:
+            if best is None or cand.ms < best.ms:
                 best = cand
+        if len(todo) > 1 and want == "auto":
+            self.stream_misses += 1
+            self._streams_pick[pick_key] = best.streams
+            self._algo_dirty = True
         self.timer = timer
         self._plans[key] = best
         if getattr(self, "_algo_dirty", False):
@@ -772,9 +836,15 @@ class Net:
 
     def _replay(self, xs, private=True):
         plan = self.compile(*xs)
-        for s, a in zip(plan.inputs, xs):          # on the main stream; launch() forks behind it
-            if a is not s:
-                s.copy_from(a)
+        if isinstance(plan, _PipelinePlan):
+            # the replica whose turn it is gets the inputs (plan.inputs are those of the replica launched LAST);
+            # its stream first waits for the main stream, where the caller produced xs
+            plan.replicas[plan.turn].ctx.wait_for(self.ctx)
+            plan.feed(xs)
+        else:
+            for s, a in zip(plan.inputs, xs):      # on the main stream; launch() forks behind it
+                if a is not s:
+                    s.copy_from(a)
         plan.launch()
         out = plan.outputs
         if not private:                            # the caller copies to the host right away
@@ -799,11 +869,16 @@ class Net:
             try:
                 rst = self._replay(list(x), private=not need)          # host in -> host out: .get() reads the plan's buffers
             except _lib.NotCapturable:
-                # post-processing graphs (Shape / NonZero / index uploads) need the host between kernels: same
-                # kernels, launched one by one from here on
+                # post-processing graphs (NonZero, uploads of host-computed index lists) need the host between
+                # kernels: the FUSED program (same kernels, layouts and algorithm picks as the plan) is launched
+                # step by step from here on
                 self.use_graph = graphable = False
         if not graphable:
-            rst = self.forward(*x, **key)
+            eager = getattr(self, "_eager_prog", None)
+            if eager is not None and not key.get("debug") and not self.profile and all(isinstance(i, DeviceArray) for i in x):
+                rst = self._interpret(eager, list(x))
+            else:
+                rst = self.forward(*x, **key)
         if need:
             rst = tuple(i.get() for i in rst) if isinstance(rst, tuple) else rst.get()
         return rst[0] if len(rst) == 1 else rst

@@ -74,6 +74,8 @@ WORKER = textwrap.dedent("""
     hn = HostNet(g)
     comm.load_weights(hn, b if rank == 0 else None)
     assert np.array_equal(hn.blob, b), "rank %%d did not receive the weights" %% rank
+    assert comm.bcast_ms is not None and comm.bcast_ms >= 0.0      # the broadcast alone, max over ranks
+    assert comm.min_over_ranks(rank + 1.0) == 1.0 and comm.max_over_ranks(rank + 1.0) == float(world)
     assert hn.refreshed == (rank != 0)
     hn.net.load_weights(hn.blob)
     # 3) batch sharding: each rank runs its slice, results equal the full-batch run
@@ -92,6 +94,11 @@ WORKER = textwrap.dedent("""
     assert el >= 0.03 * world * 0.9, el          # slowest rank (rank world-1) sets the time
     t = torch.tensor([el], dtype=torch.float64); td.all_reduce(t, op=td.ReduceOp.MAX)
     assert abs(float(t[0]) - el) < 1e-12
+    # 5) repeated timed regions (what bench.py reports the median of): warm-up once, K steps per repeat
+    calls.clear()
+    spans, own = dist.timed_repeats(comm, step, lambda: None, steps=2, warmup=1, repeats=3)
+    assert len(calls) == 1 + 3 * 2 and len(spans) == len(own) == 3
+    assert all(s >= o - 1e-12 for s, o in zip(spans, own)) and min(spans) >= 0.02 * world * 0.9
     print("rank", rank, "ok", got[:4].hex())
     td.destroy_process_group()
 """)

@@ -51,3 +51,45 @@ def test_bench_default_command_prints_one_contract_line():
     assert len([a for a in algos if a["layer"].endswith("conv+") or "conv" in a["layer"]]) >= 20 and all(a["plan"] for a in algos)
     for h in d["roofline_hbm"]:
         assert h["unit"] == "GB/s" and h["peak"] == 8000.0 and 0 < h["frac"] < 1
+    # round 3: spread of the repeated timed region, where the kernel choices came from, executed FLOPs from the library
+    rv = d["config"]["repeat_values"]
+    assert rv["repeats"] == 5 and rv["min"] <= rv["median"] <= rv["max"] and abs(rv["median"] - d["value"]) <= 0.01 * d["value"]
+    assert d["config"]["rccl_ranks"] == 1 and d["config"]["tune_source"]
+    assert all(r["executed_flops"] for r in d["per_layer"] if r["algorithmic_flops"])
+    steps = d["config"]["plan_steps"]
+    assert len(steps) >= 30 and all(len(s) == 2 for s in steps)
+    if d["config"]["wino_chains"]:
+        kinds = [k for _, k in steps]
+        assert kinds.count("wino4_chain") == d["config"]["wino_chains"]
+        assert any("transform" in h["layer"] for h in d["roofline_hbm"])
+
+
+def test_bench_two_gpus_under_the_launcher():
+    """`bench.py --gpus 2` exactly as the driver launches it (one rank per GPU, RCCL weight broadcast, no collective in
+    the forward pass).  Skipped unless two devices are visible.  The N=2 line must carry what makes it creditable:
+    cpu_baseline, full-shard parity, the rank count RCCL itself reports, and per-GPU rates within 5 % of the N=1 run."""
+    import planer_amd
+    if planer_amd.hip.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("PLANER_HIP_STREAMS", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline"],
+                         capture_output=True, text=True, env=env, timeout=900)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = json.loads(one.stdout.strip().splitlines()[-1])
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "20", "--warmup", "5", "--cpu-iters", "1"],
+                         capture_output=True, text=True, env=env, timeout=1500)
+    assert two.returncode == 0, two.stderr[-3000:]
+    lines = [ln for ln in two.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    d2 = json.loads(lines[0])
+    assert d2["n_gpus"] == 2 and d2["config"]["rccl_ranks"] == 2 and d2["config"]["global_batch"] == 64
+    assert "RCCL" in d2["config"]["weight_exchange"] and d2["config"]["weight_bcast_ms"] > 0
+    assert d2["parity_rel_err"] <= 1e-4 and d2["parity_checked_images"] == 32 and "cpu_baseline" in d2
+    per_gpu = d2["value"] / 2
+    assert abs(per_gpu - d1["value"]) <= 0.05 * d1["value"], (per_gpu, d1["value"])
+    rr = d2["config"]["rank_images_per_sec"]
+    assert rr["min"] <= rr["max"] and rr["min"] >= 0.9 * per_gpu

@@ -110,6 +110,23 @@ def test_sub_batch_streams_give_identical_results(pa, streams):
             assert_close(a, c, RTOL)
 
 
+@pytest.mark.parametrize("streams", ["pipe2", "pipe3"])
+def test_call_on_a_pipelined_plan_sees_each_new_input(pa, streams, monkeypatch):
+    """`net(x)` with PLANER_HIP_STREAMS=pipeR: consecutive calls run on different replicas, and every call must run on
+    the input it was given (not on what an older call left in that replica's static buffers)."""
+    g, b = resnet18.build()
+    ref = onp.OracleNet()
+    ref.load_json(g["input"], g["inits"], g["layers"], g["flow"])
+    ref.load_weights(b)
+    net = pa.from_graph(g, b)
+    net.streams = streams
+    for seed in range(5):
+        x = resnet18.make_input(2, seed=40 + seed, size=64)
+        got = net(pa.asarray(x))
+        assert_close(got.get(), ref(x.copy()), RTOL, "device call %d" % seed)
+        assert_close(net(x), ref(x.copy()), RTOL, "host call %d" % seed)
+
+
 @pytest.mark.parametrize("streams", ["pipe2", "pipe3", "auto"])
 def test_pipelined_batches_keep_their_own_results(pa, streams):
     """Throughput plans pipeline consecutive batches over several streams (one full-batch graph per

@@ -158,7 +158,7 @@ def test_forced_chain_at_the_real_resnet18_layer_shapes(pa, shape, monkeypatch):
     for mode in ("1", "stages", "0"):
         monkeypatch.setenv("PLANER_HIP_WINO_CHAIN", mode)
         net = planer_amd.from_graph(g, blob)
-        net.force_algo, net.streams = 7, "1x1"
+        net.force_algo, net.streams, net.use_q4 = 7, "1x1", "force"      # (a lone 56x56 block would stay NCHW by the cost estimate)
         got = net(planer_amd.asarray(x.copy()))
         got = got[0] if isinstance(got, tuple) else got
         outs[mode] = got.get()

@@ -273,3 +273,73 @@ def test_upsample_concat_peephole_and_its_guards():
     for kw in ({"extra_reader": True}, {"first": False}, {"touch": True}):
         body, flow = prog(**kw)
         assert Net._fuse_upsample_concat(body, flow) == flow and body["cat"][1] == "concat_q4", kw
+
+
+# ---- Winograd chaining (plan.chain_winograd): pure host logic ------------------------------------------
+def _wino_prog():
+    """Two BasicBlocks' worth of F(4x4,3x3) convs: c1 -> c2 (+ identity x) -> c3 -> c4 (+ identity y2), then a pool."""
+    w7 = {"w_layout": 7, "act": 1, "alpha": 0.0, "pads": [1, 1, 1, 1]}
+    body = [["c%d" % i, "conv_q4", dict(w7)] for i in (1, 2, 3, 4)] + [["pool", "maxpool_q4", {}], ["out", "from_q4", {}]]
+    flow = [[["x", "U1", "None", "s1", "t1", "None"], ["c1"], "y1"],
+            [["y1", "U2", "None", "s2", "t2", "x"], ["c2"], "y2"],
+            [["y2", "U3", "None", "s3", "t3", "None"], ["c3"], "y3"],
+            [["y3", "U4", "None", "s4", "t4", "y2"], ["c4"], "y4"],
+            [["y4"], ["pool"], "p"],
+            [["p"], ["out"], "o"]]
+    return body, flow
+
+
+def test_chain_winograd_merges_output_and_input_transforms():
+    from planer_amd.plan import chain_winograd
+    body, flow = _wino_prog()
+    b, f, n = chain_winograd(body, flow)
+    kinds = {e[0]: e for e in b}
+    assert n == 3
+    seq = [(names[0], kinds[names[0]][1]) for _, names, _ in f]
+    assert seq == [("c1@in", "wino4_in"), ("c1@gemm", "wino4_gemm"), ("c1@chain", "wino4_chain"),
+                   ("c2@gemm", "wino4_gemm"), ("c2@chain", "wino4_chain"), ("c3@gemm", "wino4_gemm"),
+                   ("c3@chain", "wino4_chain"), ("c4@gemm", "wino4_gemm"), ("c4@out", "wino4_out"),
+                   ("pool", "maxpool_q4"), ("out", "from_q4")]
+    # y1 and y3 feed only the next conv: never written; y2 is also c4's residual: written AND transformed
+    assert kinds["c1@chain"][2]["keep_y"] is False and f[2][2] == "c2@V"
+    assert kinds["c2@chain"][2]["keep_y"] is True and f[4][2] == ["y2", "c3@V"]
+    assert kinds["c3@chain"][2]["keep_y"] is False
+    assert f[4][0] == ["c2@M", "None", "s2", "t2", "x"]            # the tail's operands travel with the chain step
+    assert f[8][0] == ["c4@M", "None", "s4", "t4", "y2"] and kinds["c4@out"][2]["act"] == 1
+    # every key is produced before it is read
+    have = {"x", "None"} | {"U%d" % i for i in range(1, 5)} | {"s%d" % i for i in range(1, 5)} | {"t%d" % i for i in range(1, 5)}
+    for src, _, dst in f:
+        assert all(k in have for k in src), (src, sorted(have))
+        have |= set(dst if isinstance(dst, list) else [dst])
+
+
+def test_chain_winograd_stages_only_and_unsupported_maps():
+    from planer_amd.plan import chain_winograd
+    body, flow = _wino_prog()
+    b, f, n = chain_winograd(body, flow, chain=False)
+    assert n == 0 and [e[1] for e in b].count("wino4_in") == 4 and [e[1] for e in b].count("wino4_out") == 4
+    b, f, n = chain_winograd(body, flow, supported=lambda key: key != "y2")
+    assert n == 2 and any(e[0] == "c2@out" for e in b) and any(e[0] == "c3@in" for e in b)
+
+
+def test_chain_winograd_keeps_an_input_transform_behind_an_in_place_reader():
+    """relu_q4 rewrites its input in place (layer.py:46): a conv that reads the tensor AFTER such a step must see the
+    rewritten values, so its input transform is not hoisted over it."""
+    from planer_amd.plan import chain_winograd
+    w7 = {"w_layout": 7, "act": 0, "alpha": 0.0}
+    body = [["c1", "conv_q4", dict(w7)], ["r", "relu_q4", {}], ["c2", "conv_q4", dict(w7)], ["a", "add_q4", {}]]
+    flow = [[["x", "U1"], ["c1"], "y1"], [["y1"], ["r"], "z"], [["y1", "U2"], ["c2"], "y2"], [["y2", "z"], ["a"], "o"]]
+    b, f, n = chain_winograd(body, flow)
+    assert n == 0 and [names[0] for _, names, _ in f] == ["c1@in", "c1@gemm", "c1@out", "r", "c2@in", "c2@gemm", "c2@out", "a"]
+    # a pure reader in between is fine
+    body[1] = ["r", "leakyrelu_q4", {}]
+    b, f, n = chain_winograd(body, flow)
+    assert n == 1 and f[2][2] == ["y1", "c2@V"]
+
+
+def test_chain_winograd_leaves_other_convs_alone():
+    from planer_amd.plan import chain_winograd
+    body = [["c1", "conv_q4", {"w_layout": 8}], ["c2", "conv_q4", {"w_layout": 2}]]
+    flow = [[["x", "U1"], ["c1"], "y1"], [["y1", "U2"], ["c2"], "y2"]]
+    b, f, n = chain_winograd(body, flow)
+    assert n == 0 and b == body and f == [[["x", "U1"], ["c1"], "y1"], [["y1", "U2"], ["c2"], "y2"]]

@@ -1,7 +1,6 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun): rocprofv3 evidence for the default bench.py command, trial-free.
-#   0. untraced fill run: picks conv algorithms + launch plans and persists them (PLANER_HIP_TUNE_CACHE
-#      and <cache>.algo.json); every later pass replays exactly those kernels, no tuning launches.
+#   0. untraced run of the default command (kernel choices: the shipped tuning database, planer_amd/tuned/).
 #   1. --kernel-trace --stats of the DEFAULT command (pipelined: three streams)      -> <tag>_bench_kernel_stats.csv
 #   2. the same with ONE stream (every launch is one full-batch layer)               -> <tag>_bench_1stream_*  + per-layer table
 #   3. --pmc passes, one stream, each in its own run (guide: FETCH_SIZE and WRITE_SIZE cannot share a pass):
@@ -10,12 +9,15 @@
 # Copy what should be judged from gpurun_out/prof into profiles/ afterwards (tools/profile_digest.py --install).
 # usage: tools/profile_bench.sh <tag> [bench.py args...]
 R=${GRAFT_REPO_ROOT:-/root/repo}
-tag=${1:-r02}; shift
+tag=${1:-r03}; shift
 out=$R/gpurun_out/prof
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-export PLANER_HIP_TUNE_CACHE=$out/${tag}_tune_cache.txt
-[ -f $R/profiles/${tag}_tune_cache.txt ] && cp $R/profiles/${tag}_tune_cache.txt $R/profiles/${tag}_tune_cache.txt.algo.json $out/ 2>/dev/null
+# Kernel choices come from the database shipped in planer_amd/tuned/ (loaded by default): every pass below, and the
+# driver's own run of bench.py, launch the same kernels -- each line's config.tune_source says so ("shipped").  Only
+# when that database does not cover this device does a run fall back to timing, and then a private cache keeps the
+# passes consistent with one another.
+if ! ls $R/planer_amd/tuned/*.plans > /dev/null 2>&1; then export PLANER_HIP_TUNE_CACHE=$out/${tag}_tune_cache.txt; fi
 python $R/bench.py --steps 50 --warmup 10 "$@" > $out/${tag}_bench_line.json 2> $out/${tag}_fill.err      # fills the caches; the untraced line
 # (rocprofv3's dispatch interception segfaults now and then when three graphs are in flight on three
 #  streams -- never without the tool -- so the pass is retried until its summary exists)

@@ -100,6 +100,7 @@ def expected_kernels(a):
     plan, algo = a["plan"], a["algo"]
     if plan.startswith("dense32x32"):
         return ["dense_small_kernel"]
+    plan = re.sub(r"^wino\d\[(.*)\]$", r"\1", plan) if algo == "direct" else plan
     gemm = ["conv_ks_kernel" if "[k" in plan or plan.startswith("k") else "conv_q4_kernel" if "[q" in plan or plan.startswith("q") else "conv_pc_kernel" if "p" in plan.split()[0] else "conv_igemm_kernel"]
     if re.search(r"split=([2-9]|\d\d)", plan):
         gemm.append("reduce_tiles")
@@ -116,39 +117,80 @@ def expected_kernels(a):
     return gemm
 
 
+def step_kernels(step, kind, algos):
+    """Kernel-name fragments a plan step launches, in order (config.plan_steps of the bench line); None = unknown kind."""
+    a = algos.get(step.split("@")[0])
+    if kind in ("conv_q4", "conv_fused", "conv", "dense", "matmul"):
+        return expected_kernels(a) if a else None
+    if kind in ("wino4_in", "wino4_out", "wino4_chain"):
+        return ["wino4_"]                    # wino4_chain_kernel<..> (LDS) or wino4_input_ / wino4_output_ (register kernels)
+    if kind == "wino4_gemm":
+        return expected_kernels(dict(a, algo="direct")) if a else None
+    return {"maxpool_q4": ["pool"], "gap_q4": ["gap_q4_kernel"], "to_q4": ["nchw_to_q4"], "from_q4": ["q4_to_nchw"],
+            "flatten": [], "return": [], "identity": []}.get(kind)
+
+
+def matched_forwards(names, seq):
+    """Start indices of every run of `names` that launches exactly the plan's kernel sequence."""
+    first = seq[0][1]
+    ok = []
+    for s in (i for i, n in enumerate(names) if first in n):
+        if s + len(seq) <= len(names) and all(frag in names[s + i] for i, (_, frag) in enumerate(seq)):
+            ok.append(s)
+    return ok
+
+
+def pmc_dispatches(out, tag, idx):
+    """[(kernel, {counter: value})] in dispatch order for one --pmc pass."""
+    f = glob.glob(os.path.join(out, "%s_pmc%d_counter_collection.csv" % (tag, idx)))
+    disp = collections.OrderedDict()
+    for r in csv.DictReader(open(f[0])) if f else []:
+        if "rocclr" in r["Kernel_Name"]:
+            continue
+        d = disp.setdefault(int(r["Dispatch_Id"]), [short(r["Kernel_Name"]), {}])
+        d[1][r["Counter_Name"]] = d[1].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    return [disp[k] for k in sorted(disp)]
+
+
 def per_layer(out, tag, trace, bench):
-    algos = bench["config"]["algos"]
-    seq = []                                  # (layer, kernel fragment)
-    for a in algos:
-        for frag in expected_kernels(a):
-            seq.append((a["layer"], frag))
-        if a["layer"].startswith("stem"):
-            seq.append(("maxpool", "pool"))          # pool2d_q4_kernel or maxpool_q4_k3s2p1_2x1
-        if a["layer"].startswith("l41b"):
-            seq.append(("gap", "gap_q4_kernel"))
+    algos = {a["layer"]: a for a in bench["config"]["algos"]}
+    seq = []                                  # (plan step, kernel fragment)
+    for step, kind in bench["config"]["plan_steps"]:
+        frags = step_kernels(step, kind, algos)
+        if frags is None:
+            print("per-layer table: no kernel list for step %s (%s)" % (step, kind))
+            return
+        seq += [(step, f) for f in frags]
     rows = [r for r in csv.DictReader(open(trace)) if "rocclr" not in r["Kernel_Name"]]
     names = [short(r["Kernel_Name"]) for r in rows]
-    first = seq[0][1]
-    starts = [i for i, n in enumerate(names) if first in n]
     acc = collections.OrderedDict()
-    nfw = 0
+    starts = matched_forwards(names, seq)
     for s in starts:
-        if s + len(seq) > len(names) or not all(frag in names[s + i] for i, (_, frag) in enumerate(seq)):
-            continue                          # a tuning / eager pass with another kernel mix
-        nfw += 1
         for i, (layer, frag) in enumerate(seq):
             r = rows[s + i]
-            key = (layer, names[s + i])
-            acc.setdefault(key, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+            acc.setdefault((i, layer, names[s + i]), []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    # HBM bytes of the same kernels from the FETCH_SIZE / WRITE_SIZE passes (their own runs of the same command)
+    hbm = {}
+    for idx, counter, scale in ((1, "FETCH_SIZE", 2.0 * 1e3), (2, "WRITE_SIZE", 1e3)):     # KB; FETCH doubled (gfx950, MI355X guide)
+        d = pmc_dispatches(out, tag, idx)
+        dn = [k for k, _ in d]
+        for s in matched_forwards(dn, seq) if d else []:
+            for i, (layer, frag) in enumerate(seq):
+                hbm.setdefault((i, counter), []).append(d[s + i][1].get(counter, 0.0) * scale)
     per = {r["layer"]: r for r in bench.get("per_layer", [])}
+    nfw = len(starts)
     with open(os.path.join(out, tag + "_per_layer.csv"), "w") as f:
-        f.write("layer,kernel,us_rocprof_avg,us_rocprof_min,forwards_matched,layer_algorithmic_flops,layer_executed_flops,layer_us_hip_events\n")
-        for (layer, kern), v in acc.items():
+        f.write("layer,kernel,us_rocprof_avg,us_rocprof_min,forwards_matched,layer_algorithmic_flops,layer_executed_flops,"
+                "layer_us_hip_events,hbm_read_bytes,hbm_write_bytes,algorithmic_hbm_bytes\n")
+        for (i, layer, kern), v in acc.items():
             if len(v) * 10 < nfw:
                 continue                      # a handful of eager passes launch a layer's kernels in another order
             p = per.get(layer, {})
-            f.write("%s,\"%s\",%.2f,%.2f,%d,%s,%s,%s\n" % (layer, kern, sum(v) / len(v), min(v), len(v),
-                    p.get("algorithmic_flops", ""), p.get("executed_flops", ""), p.get("us", "")))
+            rd, wr = hbm.get((i, "FETCH_SIZE")), hbm.get((i, "WRITE_SIZE"))
+            f.write("%s,\"%s\",%.2f,%.2f,%d,%s,%s,%s,%s,%s,%s\n" % (
+                layer, kern, sum(v) / len(v), min(v), len(v), p.get("algorithmic_flops", ""), p.get("executed_flops", ""),
+                p.get("us", ""), "%.0f" % (sum(rd) / len(rd)) if rd else "", "%.0f" % (sum(wr) / len(wr)) if wr else "",
+                "%.0f" % p["hbm_bytes"] if p.get("hbm_bytes") else ""))
     print("per-layer table: %d forwards of %d kernels matched" % (nfw, len(seq)))
 
 
@@ -157,7 +199,7 @@ def install(out, tag):
     dst = os.path.join(root, "profiles")
     for name in ("_bench_kernel_stats.csv", "_bench_1stream_kernel_stats.csv", "_hbm_traffic.json", "_hbm_traffic.md",
                  "_mfma_util.json", "_mfma_util.md", "_per_layer.csv", "_bench_line.json", "_bench_line_under_rocprof.json",
-                 "_bench_1stream_line.json", "_tune_cache.txt", "_tune_cache.txt.algo.json"):
+                 "_bench_1stream_line.json", "_tune_cache.txt", "_tune_cache.txt.algo.json", "_other_workloads.jsonl"):
         src = os.path.join(out, tag + name)
         if os.path.exists(src):
             shutil.copy(src, os.path.join(dst, tag + name))
