@@ -2034,14 +2034,18 @@ int wino4_chain_launch(pl_ctx *ctx, const float *M, const float *x, const WinoAr
     return PL_OK;
 }
 
-bool wino4_lds_enabled() {
-    static const bool on = !getenv("PLANER_HIP_WINO_LDS") || atoi(getenv("PLANER_HIP_WINO_LDS")) != 0;
-    return on;
+// PLANER_HIP_WINO_LDS: 0 = register transform kernels only (no chaining), 1 (default) = the LDS kernel for chained
+// transforms, the register kernels for lone input / output transforms (measured at ResNet-18's layer2-4 shapes, batch
+// 32: lone LDS transforms 12.1 / 14.9 us against 10.1 / 13.4 us), 2 = the LDS kernel for lone transforms too
+int wino4_lds_mode() {
+    const char *e = getenv("PLANER_HIP_WINO_LDS");       // read per call: tests switch it at run time
+    return e ? atoi(e) : 1;
 }
+bool wino4_lds_enabled() { return wino4_lds_mode() != 0; }
 
 int wino4_input_launch(pl_ctx *ctx, const float *xq, float *V, const WinoArgs &p, int lds_ok) {
     const int Cq = p.C / 4;
-    if (lds_ok && wino4_lds_enabled() && wino4_chain_pick_g(ctx, p.N, Cq, p.th, p.tw, false) > 0)
+    if (lds_ok && wino4_lds_mode() >= 2 && wino4_chain_pick_g(ctx, p.N, Cq, p.th, p.tw, false) > 0)
         return wino4_chain_launch(ctx, nullptr, xq, p, p.C, nullptr, V);
     const unsigned cap = (unsigned)(ctx->cu_count > 0 ? ctx->cu_count : 256) * 8;
     const unsigned tin = (unsigned)((size_t)p.C * p.T);
@@ -2066,7 +2070,7 @@ int wino4_gemm_launch(pl_ctx *ctx, const float *V, const float *Uq, float *M, co
 
 int wino4_output_launch(pl_ctx *ctx, const float *M, float *yq, const WinoArgs &p, int lds_ok) {
     const int Coq = p.Cout / 4;
-    if (lds_ok && wino4_lds_enabled() && wino4_chain_pick_g(ctx, p.N, Coq, p.th, p.tw, true) > 0)
+    if (lds_ok && wino4_lds_mode() >= 2 && wino4_chain_pick_g(ctx, p.N, Coq, p.th, p.tw, true) > 0)
         return wino4_chain_launch(ctx, M, nullptr, p, p.Cout, yq, nullptr);
     const unsigned cap = (unsigned)(ctx->cu_count > 0 ? ctx->cu_count : 256) * 8;
     const unsigned tout = (unsigned)((size_t)Coq * p.T);

@@ -433,8 +433,11 @@ class Net:
         mode = os.environ.get("PLANER_HIP_WINO_CHAIN", "1")
         if mode != "0":
             def fits(key):
+                # whole planes per workgroup: the plane must fit the LDS kernel, and there must be enough (image,
+                # channel quad) planes to fill the chip (a batch-1 detection net has 32-256 of them: not worth it)
                 shp = shapes.get(key.split("@")[0])
-                return shp is not None and len(shp) == 4 and _q4.wino4_chain_supported(tuple(shp), self.ctx)
+                return (shp is not None and len(shp) == 4 and shp[0] * (shp[1] // 4) >= self.ctx.cu_count // 2
+                        and _q4.wino4_chain_supported(tuple(shp), self.ctx))
             out_list, out_flow, self.wino_chains = chain_winograd(out_list, out_flow, fits, chain=mode != "stages")
         return out_list, out_flow
 

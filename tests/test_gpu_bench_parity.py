@@ -57,7 +57,7 @@ def test_throughput_plan_batch32_full_size(pa, r18, streams):
     plan = net.compile(dev[0], mode="throughput")
     assert plan.streams == streams and len(plan.replicas) == R
     # what ran is on record: one entry per conv / dense step with its kernel family and tile plan
-    convs = [a for a in plan.algos if a["kind"] == "conv_q4"]
+    convs = [a for a in plan.algos if a["kind"] in ("conv_q4", "wino4_gemm")]      # (wino4_gemm: a staged F(4x4,3x3) conv)
     assert len(convs) == 20 and all(a["plan"] for a in convs), plan.algos
     for rnd in range(2):
         held = []

@@ -72,8 +72,11 @@ TAILS = [(), ("b",), ("bn", "relu"), ("bn", "res", "relu"), ("b", "bn", "leaky",
 
 
 @pytest.mark.parametrize("shape", SHAPES, ids=["x".join(map(str, s)) for s in SHAPES])
-def test_stages_equal_the_one_call_pipeline_bit_for_bit(pa, shape):
+@pytest.mark.parametrize("lds", ["1", "2"], ids=["register-transforms", "lds-transforms"])
+def test_stages_equal_the_one_call_pipeline_bit_for_bit(pa, shape, lds, monkeypatch):
+    """PLANER_HIP_WINO_LDS=2 sends lone input / output transforms through the LDS kernel too (default: chained ones only)."""
     from planer_amd import q4
+    monkeypatch.setenv("PLANER_HIP_WINO_LDS", lds)
     n, cin, h, w, cout = shape
     rng = np.random.default_rng(sum(shape))
     for tail in TAILS:
