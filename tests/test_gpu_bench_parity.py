@@ -116,7 +116,7 @@ def test_whole_net_with_one_forced_algorithm_batch32(pa, r18, lay):
     net.streams = "1x1"
     d = pa.asarray(x)
     y = net(d).get()
-    used = [a["w_layout"] for a in net.compile(d).algos if a["kind"] == "conv_q4"]
+    used = [a["w_layout"] for a in net.compile(d).algos if a["kind"] in ("conv_q4", "wino4_gemm")]
     # 13 stride-1 3x3 convs; the 3 stride-2 3x3 and the 3 1x1 convs are always direct (w_layout 2)
     assert used.count(lay) == (13 if lay != 2 else 19), used
     want = ref(x.copy())

@@ -27,8 +27,12 @@ for attempt in 1 2 3 4 5 6; do
   [ -s $out/${tag}_bench_kernel_stats.csv ] && break
   echo "stats pass: attempt $attempt failed, retrying"
 done
-PLANER_HIP_STREAMS=1x1 rocprofv3 --kernel-trace --stats -d $out -o ${tag}_bench_1stream --output-format csv -- \
-    python $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-e2e "$@" > $out/${tag}_bench_1stream_line.json 2> /dev/null
+for attempt in 1 2 3 4; do
+  PLANER_HIP_STREAMS=1x1 rocprofv3 --kernel-trace --stats -d $out -o ${tag}_bench_1stream --output-format csv -- \
+      python $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-e2e "$@" > $out/${tag}_bench_1stream_line.json 2> $out/${tag}_1stream.err
+  [ -s $out/${tag}_bench_1stream_line.json ] && [ -s $out/${tag}_bench_1stream_kernel_trace.csv ] && break
+  echo "one-stream pass: attempt $attempt failed, retrying"; tail -3 $out/${tag}_1stream.err
+done
 i=0
 for pm in "FETCH_SIZE" "WRITE_SIZE" \
           "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"; do
