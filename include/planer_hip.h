@@ -221,6 +221,19 @@ int pl_wino4_chain_q4_f32(pl_ctx *ctx, const float *M, int N, int C, int H, int 
                           const float *scale, const float *shift, const float *resq, int act, double alpha,
                           float *yq, float *Vnext);
 
+/* Fully fused Winograd F(4x4,3x3) on Q4 tensors (3x3 / stride 1 / pad 1 / group 1, Cin %% 4 == 0, Cout %% 4 == 0;
+ * replaces util.conv_for, util.py:17-44, + the fused tail): one workgroup carries 32 tiles x 64 output channels
+ * through all 36 frequencies -- input transform into LDS, v_mfma_f32_16x16x4_f32 with the 36 accumulator blocks in
+ * registers, lane-local output transform -- so neither the transformed input nor the products ever reach memory.
+ * u = filters laid out [Cout/64][Cin/4][36][4][4][16] by pl_conv2d_prepare_wf4_f32.  bias / scale / shift must be
+ * 16-byte aligned (read as one 16-byte load per channel quad). */
+int pl_conv2d_wf4_filter_elems(int Cout, int Cin, size_t *elems);
+int pl_conv2d_prepare_wf4_f32(pl_ctx *ctx, const float *w, int Cout, int Cin, float *out);
+int pl_conv2d_wf4_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W,
+                         const float *u, int Cout, const float *bias, float *yq,
+                         const float *scale, const float *shift, const float *resq,
+                         int act, double alpha);
+
 /* Fused 1-D Winograd F(2,3) along W on Q4 tensors (3x3 / stride 1 / pad 1 / group 1, Cin %% 4 == 0):
  * 1.5x fewer multiplies than the direct conv with NO extra HBM traffic -- the input transform
  * happens between the global load and LDS, the output transform in registers (conv_w1d_kernel.h).

@@ -67,6 +67,9 @@ SIGNATURES = {
     "pl_conv2d_winograd4_q4_filter_elems": [_I, _I, POINTER(c_size_t)],
     "pl_conv2d_prepare_winograd4_q4_f32": [_P, _P, _I, _I, _P],
     "pl_conv2d_winograd4_q4_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, c_double],
+    "pl_conv2d_wf4_filter_elems": [_I, _I, POINTER(c_size_t)],
+    "pl_conv2d_prepare_wf4_f32": [_P, _P, _I, _I, _P],
+    "pl_conv2d_wf4_q4_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, c_double],
     "pl_wino4_elems": [_I, _I, _I, _I, POINTER(c_size_t)],
     "pl_wino4_chain_supported": [_P, _I, _I, _I, _I, POINTER(c_int)],
     "pl_wino4_input_q4_f32": [_P, _P, _I, _I, _I, _I, _P],

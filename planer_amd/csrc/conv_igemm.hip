@@ -2180,6 +2180,55 @@ int w1d_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const
     return PL_OK;
 }
 
+#include "conv_wf4_kernel.h"
+
+int wf4_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const float *u, int Cout, const float *bias,
+               float *yq, const float *scale, const float *shift, const float *resq, int act, double alpha) {
+    Wf4Args a;
+    memset(&a, 0, sizeof a);
+    a.x = xq; a.u = u; a.y = yq;
+    a.N = N; a.Cq = Cin / 4; a.Coq = Cout / 4; a.H = H; a.W = W;
+    a.th = (H + 3) / 4; a.tw = (W + 3) / 4;
+    a.nchunks = Cin / 4;
+    int BC = 1, BR = 1, lBC = 0, lBR = 0;
+    while (BC < a.tw && BC < 16) BC *= 2, ++lBC;
+    while (BR < a.th && BR * BC < 32) BR *= 2, ++lBR;
+    const int NB = 32 / (BR * BC);
+    a.lBR = lBR; a.lBC = lBC;
+    a.R = 4 * BR + 2; a.S = BC + 1;
+    a.cells = NB * a.R * 4 * a.S;
+    a.rblocks = (a.th + BR - 1) / BR; a.cblocks = (a.tw + BC - 1) / BC; a.cout_blocks = (Cout + 63) / 64;
+    const long long groups = (N + NB - 1) / NB;
+    const long long blocks = groups * a.rblocks * a.cblocks * a.cout_blocks;
+    const size_t xb = (size_t)N * Cin * H * W * 4, yb = (size_t)N * Cout * H * W * 4;
+    const size_t ub = (size_t)a.cout_blocks * a.nchunks * WF4_A_FLOATS * 4;
+    PL_REQUIRE(a.cells <= WF4_P_CELLS && blocks < (1ll << 31) && xb < (1ull << 31) && yb < (1ull << 31) && ub < (1ull << 31),
+               PL_EUNSUPPORTED, "fused winograd F(4x4,3x3): tensor too large");
+    a.x_bytes = (unsigned)xb; a.y_bytes = (unsigned)yb; a.u_bytes = (unsigned)ub;
+    a.divPlane = FastDiv(a.R * 4 * a.S); a.div4S = FastDiv(4 * a.S); a.divS = FastDiv(a.S);
+    a.divCoB = FastDiv(a.cout_blocks); a.divCb = FastDiv(a.cblocks); a.divRb = FastDiv(a.rblocks);
+    a.ep = make_epilogue(bias, scale, shift, resq, act, alpha);
+    // LDS-DMA operands, waves 4-7 transform before their MFMAs and waves 0-3 after (the variant that measured fastest: 48.5 us
+    // against 51.4 us for register-staged operands with the waves in step, layer1 of ResNet-18 at batch 32); one instantiation
+    // per block width, so that every patch read is base + immediate
+    void (*kern)(const Wf4Args) = nullptr;
+    switch (lBC) {
+    case 4: kern = conv_wf4_kernel<true, false, true, 4>; break;
+    case 3: kern = conv_wf4_kernel<true, false, true, 3>; break;
+    case 2: kern = conv_wf4_kernel<true, false, true, 2>; break;
+    case 1: kern = conv_wf4_kernel<true, false, true, 1>; break;
+    default: kern = conv_wf4_kernel<true, false, true, 0>; break;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), 0, ctx->stream, a);      // LDS: static (WF4_LDS_BYTES)
+    PL_LAUNCH_CHECK();
+    char buf[96];
+    snprintf(buf, sizeof buf, "wf4 64co x 32tiles (%dx%dx%d) blocks=%lld", NB, BR, BC, blocks);
+    ctx->last_plan = buf;
+    ctx->last_gemm[0] = 36; ctx->last_gemm[1] = (long long)a.cout_blocks * 64;
+    ctx->last_gemm[2] = groups * a.rblocks * a.cblocks * 32; ctx->last_gemm[3] = Cin;
+    return PL_OK;
+}
+
 }  // namespace
 
 
@@ -2463,6 +2512,44 @@ int pl_conv2d_winograd4_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int
     // which transform kernels: the register ones (round 2) unless PLANER_HIP_WINO_MONO_LDS=1
     static const int mono_lds = getenv("PLANER_HIP_WINO_MONO_LDS") ? atoi(getenv("PLANER_HIP_WINO_MONO_LDS")) : 0;
     return winograd4_q4_launch(ctx, xq, N, Cin, H, W, uq, Cout, bias, yq, scale, shift, resq, act, alpha, mono_lds);
+}
+
+// ---- fully fused F(4x4,3x3): conv_wf4_kernel.h ----
+int pl_conv2d_wf4_filter_elems(int Cout, int Cin, size_t *elems) {
+    PL_REQUIRE(elems && Cout > 0 && Cin > 0 && Cin % 4 == 0, PL_EINVAL, "pl_conv2d_wf4_filter_elems: bad argument");
+    *elems = (size_t)((Cout + 63) / 64) * (Cin / 4) * WF4_A_FLOATS;
+    return PL_OK;
+}
+
+int pl_conv2d_prepare_wf4_f32(pl_ctx *ctx, const float *w, int Cout, int Cin, float *out) {
+    PL_REQUIRE(ctx && w && out, PL_EINVAL, "pl_conv2d_prepare_wf4_f32: null pointer");
+    PL_REQUIRE(Cout > 0 && Cin > 0 && Cin % 4 == 0 && Cout % 4 == 0, PL_EINVAL,
+               "fused winograd F(4x4,3x3) filters need Cin %% 4 == 0 and Cout %% 4 == 0");
+    size_t elems = 0;
+    pl_conv2d_wf4_filter_elems(Cout, Cin, &elems);
+    PL_REQUIRE(elems < (1ull << 29), PL_EUNSUPPORTED, "filter too large");
+    CtxGuard g(ctx);
+    PL_HIP(hipMemsetAsync(out, 0, elems * sizeof(float), ctx->stream));       // channel padding of the last 64-block
+    const size_t pairs = (size_t)Cout * Cin;
+    wf4_filter_kernel<<<(unsigned)((pairs + 255) / 256), 256, 0, ctx->stream>>>(w, out, (unsigned)pairs, Cin, Cout);
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
+
+int pl_conv2d_wf4_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const float *u, int Cout,
+                         const float *bias, float *yq, const float *scale, const float *shift, const float *resq,
+                         int act, double alpha) {
+    PL_REQUIRE(ctx && xq && u && yq, PL_EINVAL, "pl_conv2d_wf4_q4_f32: null pointer");
+    PL_REQUIRE(N >= 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0 && Cin % 4 == 0 && Cout % 4 == 0, PL_EINVAL,
+               "pl_conv2d_wf4_q4_f32: bad shape (Cin, Cout must be multiples of 4)");
+    PL_REQUIRE(H < 16384 && W < 16384, PL_EUNSUPPORTED, "pl_conv2d_wf4_q4_f32: spatial extent above 16383");
+    PL_REQUIRE(act >= 0 && (act & 15) <= 2 && (act & ~31) == 0, PL_EINVAL, "pl_conv2d_wf4_q4_f32: bad activation code");
+    PL_REQUIRE(((reinterpret_cast<uintptr_t>(xq) | reinterpret_cast<uintptr_t>(yq) | reinterpret_cast<uintptr_t>(u) |
+                 reinterpret_cast<uintptr_t>(resq) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(scale) |
+                 reinterpret_cast<uintptr_t>(shift)) & 15u) == 0, PL_EINVAL, "Q4 tensors and per-channel parameters must be 16-byte aligned");
+    if (N == 0) return PL_OK;
+    CtxGuard guard(ctx);
+    return wf4_launch(ctx, xq, N, Cin, H, W, u, Cout, bias, yq, scale, shift, resq, act, alpha);
 }
 
 // ---- the F(4x4,3x3) pipeline stage by stage (V / M: [36][C/4][T][4], T = N * ceil(H/4) * ceil(W/4)) ----

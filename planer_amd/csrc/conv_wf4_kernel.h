@@ -1,0 +1,396 @@
+// Fully fused Winograd F(4x4,3x3) convolution on channel-quad tensors -- included by conv_igemm.hip inside its
+// anonymous namespace (uses Epilogue, FastDiv, apply_epilogue4, w4_at4).
+//
+// For 3x3 / stride 1 / pad 1 / group 1 convs (util.conv_for, util.py:17-44, with the fused tail of layer.py:125-127,
+// 93-95, 44-51).  The staged pipeline (input transform -> 36 grouped GEMMs -> output transform) needs 4x fewer
+// multiplies than the direct conv but moves V and M -- 2.25x the activation each, written and read -- through
+// memory; the fused 1-D kernel (conv_w1d4_kernel) moves nothing extra but only halves the multiplies.  Here ONE
+// workgroup carries a block of 32 tiles x 64 output channels through all 36 frequencies:
+//   * 4 waves, one per SIMD, 512 registers each (amdgpu_waves_per_eu(1,1)).  Wave (wm, wn) owns output channels
+//     [32 wm, 32 wm + 32) x tiles [16 wn, 16 wn + 16) as 2 x 36 accumulator blocks of v_mfma_f32_16x16x4_f32
+//     (288 registers): lane (i = lane % 16, rg = lane / 16) ends up holding, for ITS tile i and ITS channel quad
+//     4 rg .. 4 rg + 3, all 36 frequencies -- so the output transform A^T m A, the fused tail and the sixteen
+//     16-byte stores of the 4x4 output pixels are lane-local.  M never exists.
+//   * K runs over input channel quads (one quad = one chunk = one MFMA K step of 4).  Per chunk the workgroup
+//     holds in LDS: the filter slice A[36][4 cout blocks][4 k][16] (36.9 KB, straight from a filter laid out in
+//     exactly that order), the input patch P of the block's tiles -- (4 BR + 2) x (4 BC + 2) pixels per image,
+//     halo shared between neighbouring tiles, stored [row][x mod 4][x div 4] so that consecutive tiles are
+//     consecutive 16-byte cells -- and the transformed patch V[2 wn][36][4 k][16 tiles] (18.4 KB) that the same
+//     four waves compute from P (thread = (row a of B^T d B, tile, channel), 3 items each): V never leaves the CU.
+//   * One barrier per chunk.  In iteration c a wave requests chunk c+1's filter slice and chunk c+2's patch from
+//     L2 into registers, runs the 72 MFMAs of chunk c out of A[c&1] / V[c&1], transforms P[(c+1)&1] into
+//     V[(c+1)&1], then parks the requested registers in A[(c+1)&1] / P[c&1]: every buffer written in an interval
+//     was last read in the previous one.
+//   * Fragment reads are conflict free by layout: lane (i, kk) reads dword (kk*16 + i) of a [k][16] panel.
+// Executed MFMA work = 36/16 of a GEMM per output pixel = 4x fewer multiplies than the direct conv (tile and
+// channel padding aside); HBM traffic = x + y (+ residual) + the filter.
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct Wf4Args {
+    const float *x;        // [N][Cq][H][W][4]
+    const float *u;        // [cout block of 64][chunk = cin/4][36][4 blocks of 16][4 k][16]   (pl_conv2d_prepare_wf4_f32)
+    float *y;              // [N][Coq][H][W][4]
+    int N, Cq, Coq, H, W, th, tw;
+    int nchunks;           // Cin / 4
+    int lBR, lBC;          // log2(tile rows), log2(tile columns) of a block; images per block NB = 32 >> (lBR + lBC)
+    int R, S;              // patch rows 4 BR + 2; 16-byte cells per x phase BC + 1
+    int cells;             // NB * R * 4 * S cells of one patch
+    int rblocks, cblocks, cout_blocks;
+    unsigned x_bytes, u_bytes, y_bytes;
+    FastDiv divPlane, div4S, divS, divCoB, divCb, divRb;
+    Epilogue ep;
+};
+
+constexpr int WF4_A_FLOATS = 36 * 256, WF4_V_FLOATS = 2 * 36 * 64, WF4_P_PASSES = 2;      // patch passes of 512 cells
+constexpr int WF4_P_CELLS = 1024, WF4_P_FLOATS = WF4_P_CELLS * 4;
+constexpr int WF4_LDS_BYTES = (2 * WF4_A_FLOATS + 2 * WF4_V_FLOATS + 2 * WF4_P_FLOATS) * 4;
+
+__device__ __forceinline__ void wf4_bt(const float (&d)[6], float (&o)[6]) {      // o = B^T d, with fused multiply-adds
+    const float s = d[4] - d[2], t = d[3] - d[1];
+    o[0] = __builtin_fmaf(4.f, d[0], __builtin_fmaf(-5.f, d[2], d[4]));
+    o[1] = __builtin_fmaf(-4.f, d[1] + d[2], d[3] + d[4]);
+    o[2] = __builtin_fmaf(4.f, d[1] - d[2], d[4] - d[3]);
+    o[3] = __builtin_fmaf(2.f, t, s);
+    o[4] = __builtin_fmaf(-2.f, t, s);
+    o[5] = __builtin_fmaf(4.f, d[1], __builtin_fmaf(-5.f, d[3], d[5]));
+}
+template <int A>
+__device__ __forceinline__ float wf4_bt_row(const float (&d)[6]) {
+    if constexpr (A == 0) return __builtin_fmaf(4.f, d[0], __builtin_fmaf(-5.f, d[2], d[4]));
+    else if constexpr (A == 1) return __builtin_fmaf(-4.f, d[1] + d[2], d[3] + d[4]);
+    else if constexpr (A == 2) return __builtin_fmaf(4.f, d[1] - d[2], d[4] - d[3]);
+    else if constexpr (A == 3) return __builtin_fmaf(2.f, d[3] - d[1], d[4] - d[2]);
+    else if constexpr (A == 4) return __builtin_fmaf(-2.f, d[3] - d[1], d[4] - d[2]);
+    else return __builtin_fmaf(4.f, d[1], __builtin_fmaf(-5.f, d[3], d[5]));
+}
+
+// one transform wave-item: row A of B^T d B for (tile, channel), lanes = 16 tiles x 4 channels (tile fastest): 6 columns x
+// (the rows of d with a non-zero coefficient) out of the channel-planar patch, 6 consecutive values into
+// V[half][ch][i][6 A .. 6 A + 5].  pbase: float index of the tile's first patch cell in its channel plane; vbase: float index
+// of V[half][ch][i][0]; rs = cells per patch row (4 S), ps = cells per x phase (S).
+template <int A, int rs, int ps, int cst>
+__device__ __forceinline__ void wf4_transform_row(const float *P, float *V, int pbase, int vbase) {
+    // all the patch values this row needs are requested before the first is used (the rows of d with a zero coefficient in
+    // row A of B^T are never read: the compiler drops those loads)
+    float d[6][6];
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+        const float *col = P + pbase + (b & 3) * ps + (b >> 2) * cst;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            constexpr bool used[6][6] = {{1, 0, 1, 0, 1, 0}, {0, 1, 1, 1, 1, 0}, {0, 1, 1, 1, 1, 0},
+                                         {0, 1, 1, 1, 1, 0}, {0, 1, 1, 1, 1, 0}, {0, 1, 0, 1, 0, 1}};
+            d[b][k] = used[A][k] ? col[k * rs] : 0.f;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float m[6];
+#pragma unroll
+    for (int b = 0; b < 6; ++b) m[b] = wf4_bt_row<A>(d[b]);
+    float o[6];
+    wf4_bt(m, o);
+    float2 *dst = reinterpret_cast<float2 *>(V + vbase + A * 6);       // vbase is a multiple of 36, 6 A is even: 8-byte aligned
+    dst[0] = make_float2(o[0], o[1]);
+    dst[1] = make_float2(o[2], o[3]);
+    dst[2] = make_float2(o[4], o[5]);
+}
+
+// row A of the 4x4 output tile of one channel quad: A^T over the frequency rows for each of the 6 frequency columns, then A^T
+// over the columns, fused tail, four 16-byte stores
+template <int A>
+__device__ __forceinline__ void wf4_output_row(const Wf4Args &p, const f32x4 (&acc)[36], float4 bias, float4 scale, float4 shift,
+                                               const __amdgpu_buffer_rsrc_t yrsrc, const __amdgpu_buffer_rsrc_t rrsrc,
+                                               unsigned rowbase, bool cok, int h, int w0) {
+    constexpr int OOB = (int)0x80000000;
+    int off[4];
+    float4 rsd[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        off[b] = (cok && h < p.H && w0 + b < p.W) ? (int)((rowbase + b) << 4) : OOB;
+        rsd[b] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off[b], 0, 0));
+    }
+    float4 s[6];
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+        float4 m[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            const f32x4 v = acc[a * 6 + b];
+            m[a] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        s[b] = w4_at4_row<A>(m);
+    }
+    float4 o[4];
+    w4_at4(s, o);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const float4 v = apply_epilogue4(p.ep, bias, scale, shift, rsd[b], 4, o[b]);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
+                                               yrsrc, off[b], 0, PLANER_STORE_AUX);
+    }
+}
+
+// Variants (compile-time; the launcher picks one): DMA_A -- the filter slice goes global -> LDS by LDS-DMA instead of through
+// registers; PLANAR -- the patch is stored channel-planar (transform lanes = 16 tiles x 4 channels, tile fastest: conflict-free
+// patch reads AND 2-way instead of 4-way conflicts on the V writes) instead of as 16-byte cells (lanes channel fastest);
+// STAGGER -- waves 4-7 transform before their MFMAs and waves 0-3 after, so the two waves of a SIMD alternate on its matrix pipe.
+template <bool DMA_A, bool PLANAR, bool STAGGER, int LBC>
+__device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
+    constexpr int S = (1 << LBC) + 1;               // 16-byte cells per x phase: compile time, so every patch read is base + immediate
+    // six separate LDS objects (not one dynamic array): the compiler orders LDS-DMA against later LDS accesses object by
+    // object, so a DMA into A1 / P0 does not hold up the reads of A0 / P1 / V0 and the writes of V1
+    __shared__ __attribute__((aligned(16))) float As0[WF4_A_FLOATS], As1[WF4_A_FLOATS];      // [4 cb][4 k][16 i][36 f]
+    __shared__ __attribute__((aligned(16))) float Vs0[WF4_V_FLOATS], Vs1[WF4_V_FLOATS];      // [2 wn][4 k][16 i][36 f]
+    __shared__ __attribute__((aligned(16))) float Ps0[WF4_P_FLOATS], Ps1[WF4_P_FLOATS];      // [cells][4]  or  [4 ch][cells]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;       // 16 output channels x 16 tiles per wave
+    const int li = lane & 15, lk = lane >> 4;      // MFMA: operand row / column i, k index (A, B) or row group (C)
+
+    // ---- which block: cout block fastest (blocks that share input pixels are neighbours), then columns, rows, images ----
+    unsigned t1, coutblk, t2, colblk, ngrp, rowblk;
+    p.divCoB.divmod(blockIdx.x, t1, coutblk);
+    p.divCb.divmod(t1, t2, colblk);
+    p.divRb.divmod(t2, ngrp, rowblk);
+    const int BRm = (1 << p.lBR) - 1, BCm = (1 << LBC) - 1, lT = p.lBR + LBC;
+    const int n0 = (int)ngrp << (5 - lT), ty0 = (int)rowblk << p.lBR, tx0 = (int)colblk << LBC;
+    const int HW = p.H * p.W;
+
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.u), 0, p.u_bytes, 0x00020000);
+    constexpr int OOB = (int)0x80000000;
+    typedef __attribute__((address_space(3))) float lds_float;
+
+    // ---- patch cells this thread fetches every chunk (16 bytes = the 4 channels of a pixel; the channel quad rides in the
+    //      scalar offset) ----
+    int pvoff[WF4_P_PASSES];
+#pragma unroll
+    for (int ps = 0; ps < WF4_P_PASSES; ++ps) {
+        const unsigned ci = (unsigned)(ps * 512 + tid);
+        pvoff[ps] = OOB;
+        if (ci < (unsigned)p.cells) {
+            unsigned nb, rem, r_, rem2, m, s;
+            p.divPlane.divmod(ci, nb, rem);
+            p.div4S.divmod(rem, r_, rem2);
+            p.divS.divmod(rem2, m, s);
+            const int n = n0 + (int)nb, h = 4 * ty0 + (int)r_ - 1, w = 4 * tx0 + (int)(4 * s + m) - 1;
+            if (n < p.N && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W)
+                pvoff[ps] = (int)(((unsigned)(n * p.Cq) * (unsigned)HW + (unsigned)(h * p.W + w)) << 4);
+        }
+    }
+    float4 preg[WF4_P_PASSES], areg[5];
+    constexpr bool DMA_P = DMA_A && !PLANAR;            // 16-byte cells land lane-linear: LDS-DMA can write them directly
+    auto load_p = [&](int c, int buf) {
+        const int soff = (c * HW) << 4;
+        float *Pb = buf ? Ps1 : Ps0;
+#pragma unroll
+        for (int ps = 0; ps < WF4_P_PASSES; ++ps)
+            if (ps * 512 < p.cells) {
+                if constexpr (DMA_P) {
+                    if (ps * 512 + tid < p.cells)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_float *)(Pb + (ps * 512 + tid - lane) * 4), 16, pvoff[ps], soff, 0, 0);
+                } else {
+                    preg[ps] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, pvoff[ps], soff, 0));
+                }
+            }
+    };
+    auto store_p = [&](int buf) {
+        if constexpr (DMA_P) return;
+        float *Pb = buf ? Ps1 : Ps0;
+#pragma unroll
+        for (int ps = 0; ps < WF4_P_PASSES; ++ps)
+            if (ps * 512 < p.cells && ps * 512 + tid < p.cells) {
+                if constexpr (PLANAR) {
+                    float *d = Pb + ps * 512 + tid;
+                    d[0] = preg[ps].x;
+                    d[p.cells] = preg[ps].y;
+                    d[2 * p.cells] = preg[ps].z;
+                    d[3 * p.cells] = preg[ps].w;
+                } else {
+                    *reinterpret_cast<float4 *>(Pb + (ps * 512 + tid) * 4) = preg[ps];
+                }
+            }
+    };
+    // filter slice: 2304 x 16 bytes = four passes of 512 threads and one of 256 (waves 0-3)
+    auto load_a = [&](int c, int buf) {
+        const int soff = (int)(((unsigned)coutblk * (unsigned)p.nchunks + (unsigned)c) * (unsigned)(WF4_A_FLOATS * 4));
+        float *Ab = buf ? As1 : As0;
+#pragma unroll
+        for (int it = 0; it < 5; ++it)
+            if (it < 4 || wave < 4) {
+                if constexpr (DMA_A)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(ursrc, (lds_float *)(Ab + (it * 512 + tid - lane) * 4), 16, (it * 512 + tid) << 4, soff, 0, 0);
+                else
+                    areg[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ursrc, (it * 512 + tid) << 4, soff, 0));
+            }
+    };
+    auto store_a = [&](int buf) {
+        if constexpr (!DMA_A) {
+            float *Ab = buf ? As1 : As0;
+#pragma unroll
+            for (int it = 0; it < 5; ++it)
+                if (it < 4 || wave < 4) *reinterpret_cast<float4 *>(Ab + (it * 512 + tid) * 4) = areg[it];
+        }
+    };
+
+    // ---- transform: 12 wave-items = 6 rows of B^T d B x 2 halves of the block's tiles; a wave-item's 64 lanes are 16 tiles x
+    //      4 channels.  Waves 4-7 take rows 0-3 (both halves), waves 0-3 row 4 or 5 of one half ----
+    const int ti = PLANAR ? (lane & 15) : (lane >> 2), tch = PLANAR ? (lane >> 4) : (lane & 3);
+    constexpr int rs = PLANAR ? 4 * S : 16 * S, psz = PLANAR ? S : 4 * S, cst = PLANAR ? 1 : 4;
+    auto item_bases = [&](int half, int &pbase, int &vbase) {
+        const int tj = half * 16 + ti;
+        const int t_nb = tj >> lT, t_r = (tj >> LBC) & BRm, t_c = tj & BCm;
+        pbase = (PLANAR ? tch * p.cells : tch) + (((t_nb * p.R + 4 * t_r) * 4) * S + t_c) * cst;
+        vbase = (((half * 4 + tch) * 16) + ti) * 36;
+    };
+    int pb0, vb0, pb1, vb1;
+    item_bases(0, pb0, vb0);
+    item_bases(1, pb1, vb1);
+    auto transform_first = [&](int pbuf, int vbuf) {           // waves 4-7: a whole row (both halves)
+        const float *Pb = pbuf ? Ps1 : Ps0;
+        float *Vb = vbuf ? Vs1 : Vs0;
+        if (wave == 4) {
+            wf4_transform_row<0, rs, psz, cst>(Pb, Vb, pb0, vb0);
+            wf4_transform_row<0, rs, psz, cst>(Pb, Vb, pb1, vb1);
+        } else if (wave == 5) {
+            wf4_transform_row<1, rs, psz, cst>(Pb, Vb, pb0, vb0);
+            wf4_transform_row<1, rs, psz, cst>(Pb, Vb, pb1, vb1);
+        } else if (wave == 6) {
+            wf4_transform_row<2, rs, psz, cst>(Pb, Vb, pb0, vb0);
+            wf4_transform_row<2, rs, psz, cst>(Pb, Vb, pb1, vb1);
+        } else if (wave == 7) {
+            wf4_transform_row<3, rs, psz, cst>(Pb, Vb, pb0, vb0);
+            wf4_transform_row<3, rs, psz, cst>(Pb, Vb, pb1, vb1);
+        }
+    };
+    const int pbw = (wave & 1) ? pb1 : pb0, vbw = (wave & 1) ? vb1 : vb0;
+    auto transform_last = [&](int pbuf, int vbuf) {            // waves 0-3: row 4 or 5 of one half
+        const float *Pb = pbuf ? Ps1 : Ps0;
+        float *Vb = vbuf ? Vs1 : Vs0;
+        if (wave < 2) wf4_transform_row<4, rs, psz, cst>(Pb, Vb, pbw, vbw);
+        else if (wave < 4) wf4_transform_row<5, rs, psz, cst>(Pb, Vb, pbw, vbw);
+    };
+
+    f32x4 acc[36];
+#pragma unroll
+    for (int f = 0; f < 36; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int a_off = ((wm * 4 + lk) * 16 + li) * 36;      // this lane's 36 frequencies of A[k = lk][channel 16 wm + li]
+    const int b_off = ((wn * 4 + lk) * 16 + li) * 36;      // ... of V[k = lk][tile 16 wn + li]
+    auto mma = [&](int buf) {
+        const float4 *Ap = reinterpret_cast<const float4 *>((buf ? As1 : As0) + a_off);
+        const float4 *Vp = reinterpret_cast<const float4 *>((buf ? Vs1 : Vs0) + b_off);
+        // three rotating fragment slots, requested two groups (8 MFMAs) ahead; the scheduling barriers keep that distance
+        float4 fa[3], fb[3];
+        fa[0] = Ap[0]; fb[0] = Vp[0];
+        fa[1] = Ap[1]; fb[1] = Vp[1];
+#pragma unroll
+        for (int g = 0; g < 9; ++g) {
+            if (g + 2 < 9) {
+                fa[(g + 2) % 3] = Ap[g + 2];
+                fb[(g + 2) % 3] = Vp[g + 2];
+            }
+            const float4 a = fa[g % 3], b = fb[g % 3];
+            acc[4 * g + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[4 * g + 0], 0, 0, 0);
+            acc[4 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[4 * g + 1], 0, 0, 0);
+            acc[4 * g + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[4 * g + 2], 0, 0, 0);
+            acc[4 * g + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[4 * g + 3], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // ---- prologue: chunk 0 in LDS and transformed, chunk 1's patch in LDS ----
+    load_p(0, 0);
+    load_a(0, 0);
+    store_p(0);
+    store_a(0);
+    __syncthreads();
+    if (p.nchunks > 1) load_p(1, 1);
+    transform_first(0, 0);
+    transform_last(0, 0);
+    if (p.nchunks > 1) store_p(1);
+    __syncthreads();
+    // one K step; the buffer parity is a compile-time constant, so the compiler can tell the LDS-DMA destinations
+    // (A[nxt], P[cur]) from what the step reads and writes (A[cur], V[cur], P[nxt], V[nxt]) and lets the DMA fly
+    auto kstep = [&](auto parity, int c) {
+        constexpr int cur = decltype(parity)::value, nxt = cur ^ 1;
+        const bool more = c + 1 < p.nchunks, more2 = c + 2 < p.nchunks;
+        if (more) load_a(c + 1, nxt);                   // A[nxt] was last read by the MFMAs of chunk c - 1
+        if (more2) load_p(c + 2, cur);                  // P[cur] was last read by the transform of chunk c
+        if (STAGGER) {
+            if (more) transform_first(nxt, nxt);
+            mma(cur);
+            if (more) transform_last(nxt, nxt);
+        } else {
+            mma(cur);
+            if (more) {
+                transform_first(nxt, nxt);
+                transform_last(nxt, nxt);
+            }
+        }
+        if (more) store_a(nxt);
+        if (more2) store_p(cur);
+        __syncthreads();
+    };
+    for (int c = 0; c < p.nchunks; c += 2) {
+        kstep(std::integral_constant<int, 0>{}, c);
+        if (c + 1 < p.nchunks) kstep(std::integral_constant<int, 1>{}, c + 1);
+    }
+
+    // ---- lane-local output transform + fused tail: this lane's tile and channel quad ----
+    const int oj = wn * 16 + li;
+    const int o_nb = oj >> lT, o_r = (oj >> LBC) & BRm, o_c = oj & BCm;
+    const int n = n0 + o_nb, ty = ty0 + o_r, tx = tx0 + o_c;
+    const int coq = (int)coutblk * 16 + wm * 4 + lk;
+    const bool cok = n < p.N && ty < p.th && tx < p.tw && coq < p.Coq;
+    const int cqc = min(coq, p.Coq - 1);
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.ep.res), 0, p.ep.res ? p.y_bytes : 0u, 0x00020000);
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f), one4 = make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 bias = p.ep.bias ? reinterpret_cast<const float4 *>(p.ep.bias)[cqc] : z4;
+    const float4 scale = p.ep.scale ? reinterpret_cast<const float4 *>(p.ep.scale)[cqc] : one4;
+    const float4 shift = p.ep.shift ? reinterpret_cast<const float4 *>(p.ep.shift)[cqc] : z4;
+    const unsigned row0 = ((unsigned)(n * p.Coq + cqc) * (unsigned)p.H + (unsigned)(ty * 4)) * (unsigned)p.W + (unsigned)(tx * 4);
+    wf4_output_row<0>(p, acc, bias, scale, shift, yrsrc, rrsrc, row0, cok, ty * 4, tx * 4);
+    wf4_output_row<1>(p, acc, bias, scale, shift, yrsrc, rrsrc, row0 + (unsigned)p.W, cok, ty * 4 + 1, tx * 4);
+    wf4_output_row<2>(p, acc, bias, scale, shift, yrsrc, rrsrc, row0 + 2u * (unsigned)p.W, cok, ty * 4 + 2, tx * 4);
+    wf4_output_row<3>(p, acc, bias, scale, shift, yrsrc, rrsrc, row0 + 3u * (unsigned)p.W, cok, ty * 4 + 3, tx * 4);
+}
+
+template <bool DMA_A, bool PLANAR, bool STAGGER, int LBC>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) conv_wf4_kernel(const Wf4Args p) {
+    conv_wf4_body<DMA_A, PLANAR, STAGGER, LBC>(p);
+}
+
+// filter: OIHW 3x3 -> u[cout block][chunk][cb][kk][i][f] = (G g G^T)[f] of channel (64 blk + 16 cb + i, 4 chunk + kk); zero beyond Cout
+__global__ void __launch_bounds__(256) wf4_filter_kernel(const float *w, float *u, unsigned total, int Cin, int Cout) {
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;   // (co, c) pair
+    if (i >= total) return;
+    const int co = (int)(i / (unsigned)Cin), c = (int)(i - (unsigned)co * Cin);
+    const float *g = w + (size_t)i * 9;
+    float t[6][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float g0 = g[j], g1 = g[3 + j], g2 = g[6 + j];
+        t[0][j] = g0 * 0.25f;
+        t[1][j] = -(g0 + g1 + g2) * (1.f / 6.f);
+        t[2][j] = (-g0 + g1 - g2) * (1.f / 6.f);
+        t[3][j] = g0 * (1.f / 24.f) + g1 * (1.f / 12.f) + g2 * (1.f / 6.f);
+        t[4][j] = g0 * (1.f / 24.f) - g1 * (1.f / 12.f) + g2 * (1.f / 6.f);
+        t[5][j] = g2;
+    }
+    const int nchunks = Cin / 4;
+    float *up = u + ((size_t)(co >> 6) * nchunks + (c >> 2)) * WF4_A_FLOATS + (((((co >> 4) & 3) * 4 + (c & 3)) * 16) + (co & 15)) * 36;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        const float g0 = t[a][0], g1 = t[a][1], g2 = t[a][2];
+        up[a * 6 + 0] = g0 * 0.25f;
+        up[a * 6 + 1] = -(g0 + g1 + g2) * (1.f / 6.f);
+        up[a * 6 + 2] = (-g0 + g1 - g2) * (1.f / 6.f);
+        up[a * 6 + 3] = g0 * (1.f / 24.f) + g1 * (1.f / 12.f) + g2 * (1.f / 6.f);
+        up[a * 6 + 4] = g0 * (1.f / 24.f) - g1 * (1.f / 12.f) + g2 * (1.f / 6.f);
+        up[a * 6 + 5] = g2;
+    }
+}

@@ -38,7 +38,8 @@ _ALIGN = 256
 W_LAYOUT_NAMES = {0: "igemm-nchw", 1: "tap-nchw", 2: "direct-q4 (conv_q4_kernel)", 3: "wino2x2-nchw",
                   4: "wino2x2-q4 (transforms + grouped conv_q4_kernel)", 5: "w1d F(2,3) (conv_w1d_kernel)",
                   6: "rowpack-q4 (nchw_to_rowpack + conv_q4_kernel)",
-                  7: "wino4x4-q4 (transforms + grouped conv_q4_kernel)", 8: "w1d4 F(4,3) (conv_w1d4_kernel)"}
+                  7: "wino4x4-q4 (transforms + grouped conv_q4_kernel)", 8: "w1d4 F(4,3) (conv_w1d4_kernel)",
+                  9: "wf4 fused F(4x4,3x3) (conv_wf4_kernel)"}
 
 
 def _as_list(v):
@@ -399,14 +400,15 @@ class Net:
                         and shapes.get(srcs[0].split("@")[0]) is not None):
                     lay = self._pick_conv_algo(_q4.ConvQ4, K, srcs, entry[2], shapes, wmap, q4=True)
                 key = {2: "%s@q4g%d" % (srcs[1], group), 4: srcs[1] + "@winoq4", 5: srcs[1] + "@w1dq4",
-                       6: srcs[1] + "@rowpack", 7: srcs[1] + "@wino4q4", 8: srcs[1] + "@w1d4q4"}[lay]
+                       6: srcs[1] + "@rowpack", 7: srcs[1] + "@wino4q4", 8: srcs[1] + "@w1d4q4", 9: srcs[1] + "@wf4q4"}[lay]
                 if key not in self._extra:
                     self._extra[key] = {2: lambda: _q4.prepare_q4_weights(K, group),
                                         4: lambda: _q4.prepare_winograd_q4_weights(K),
                                         5: lambda: _q4.prepare_w1d_q4_weights(K),
                                         6: lambda: _q4.prepare_rowpack_weights(K),
                                         7: lambda: _q4.prepare_winograd4_q4_weights(K),
-                                        8: lambda: _q4.prepare_w1d4_q4_weights(K)}[lay]()
+                                        8: lambda: _q4.prepare_w1d4_q4_weights(K),
+                                        9: lambda: _q4.prepare_wf4_q4_weights(K)}[lay]()
                 srcs[1] = key
                 out_body[name] = [name, "conv_q4", dict(entry[2], w_layout=lay)]
             elif entry[1] in ("conv", "conv_fused") and len(srcs) >= 2 and srcs[1] in wmap:
@@ -510,7 +512,9 @@ class Net:
                                                    if k in ("group", "strides", "dilations", "pads")}):
                 cands.append((4, _q4.prepare_winograd_q4_weights))
                 if os.environ.get("PLANER_HIP_WINOGRAD4", "1") != "0":
-                    cands.append((7, _q4.prepare_winograd4_q4_weights))      # F(4x4,3x3)
+                    cands.append((7, _q4.prepare_winograd4_q4_weights))      # F(4x4,3x3), staged
+                if os.environ.get("PLANER_HIP_WF4", "1") != "0":
+                    cands.append((9, _q4.prepare_wf4_q4_weights))            # F(4x4,3x3), one fused kernel
         if self.force_algo is not None:
             if self.force_algo not in [c[0] for c in cands]:
                 raise ValueError("force_algo=%r does not apply to conv %s k%s" % (self.force_algo, xs, tuple(K.shape)))

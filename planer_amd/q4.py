@@ -111,6 +111,20 @@ def prepare_winograd4_q4_weights(K):
     return out
 
 
+def prepare_wf4_q4_weights(K):
+    """OIHW 3x3 filters -> fully fused F(4x4,3x3) filters [Cout/64][Cin/4][36][4][4][16] (ConvQ4 w_layout=9)."""
+    _f32(K)
+    cout, cin, kh, kw = K.shape
+    if (kh, kw) != (3, 3) or cin % 4 or cout % 4:
+        raise ValueError("winograd Q4 filters need 3x3 kernels, Cin % 4 == 0 and Cout % 4 == 0")
+    n = ctypes.c_size_t()
+    _lib.call("pl_conv2d_wf4_filter_elems", cout, cin, ctypes.byref(n))
+    out = empty((n.value,), ctx=K.ctx)
+    _lib.call("pl_conv2d_prepare_wf4_f32", K.ctx.handle, K.ptr, cout, cin, out.ptr)
+    out.shape = K.shape
+    return out
+
+
 def rowpack_eligible(k_shape, group=1, strides=(1, 1), dilations=(1, 1), pads=(0, 0, 0, 0), **_):
     """Convs on 1..3 input channels (the stem): group 1, no dilation, symmetric pads."""
     cout, cin_g, kh, kw = k_shape
@@ -224,10 +238,12 @@ def ConvQ4(xq, Kq, B=None, scale=None, shift=None, resq=None, group=1, strides=(
         _lib.call("pl_conv2d_w1d_q4_f32" if w_layout == 5 else "pl_conv2d_w1d4_q4_f32", xq.ctx.handle, xq.ptr, n, cin, h, w, Kq.ptr, cout, _ptr(B), y.ptr,
                   _ptr(scale), _ptr(shift), _ptr(resq), int(act), float(alpha))
         return y
-    if w_layout in (4, 7):
+    if w_layout in (4, 7, 9):
         if not winograd_q4_eligible(Kq.shape, group, strides, dilations, pads):
             raise ValueError("winograd Q4 filters serve 3x3 / stride 1 / pad 1 / group 1 convs only")
-        _lib.call("pl_conv2d_winograd_q4_f32" if w_layout == 4 else "pl_conv2d_winograd4_q4_f32", xq.ctx.handle, xq.ptr, n, cin, h, w, Kq.ptr, cout, _ptr(B), y.ptr,
+        if w_layout == 9 and any(a is not None and a.ptr % 16 for a in (B, scale, shift)):
+            raise ValueError("the fused F(4x4,3x3) kernel reads bias / scale / shift as 16-byte quads: misaligned parameter")
+        _lib.call({4: "pl_conv2d_winograd_q4_f32", 7: "pl_conv2d_winograd4_q4_f32", 9: "pl_conv2d_wf4_q4_f32"}[w_layout], xq.ctx.handle, xq.ptr, n, cin, h, w, Kq.ptr, cout, _ptr(B), y.ptr,
                   _ptr(scale), _ptr(shift), _ptr(resq), int(act), float(alpha))
         return y
     _lib.call("pl_conv2d_q4_f32", xq.ctx.handle, xq.ptr, n, cin, h, w, Kq.ptr, cout, kh, kw,

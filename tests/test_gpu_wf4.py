@@ -1,0 +1,93 @@
+"""The fully fused Winograd F(4x4,3x3) kernel (csrc/conv_wf4_kernel.h, ConvQ4 w_layout 9) on a real MI355X against the
+oracle (util.conv_for, util.py:17-44, + layer.BatchNorm / Add / ReLU / LeakyReLU) to 1e-4 of max|ref|, over every block
+geometry (56 / 28 / 14 / 7 / odd maps, several images per block), channel counts that do not fill the 64-channel
+block or the 4-channel quad chunk loop, and every fused tail."""
+import numpy as np
+import pytest
+
+from tests.conftest import RTOL, assert_close
+from tests.test_gpu_wino_chain import TAILS, _act, _operands, _oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pa():
+    import planer_amd
+    planer_amd.hip.context()
+    return planer_amd
+
+
+SHAPES = [(2, 64, 56, 56, 64), (3, 128, 28, 28, 128), (5, 64, 14, 14, 256), (9, 32, 7, 7, 512), (1, 4, 1, 1, 4),
+          (2, 8, 13, 13, 12), (3, 16, 26, 26, 32), (1, 16, 5, 9, 16), (2, 12, 4, 4, 72), (1, 32, 52, 52, 16),
+          (5, 20, 3, 17, 24), (1, 8, 70, 66, 8), (33, 4, 2, 2, 4)]
+
+
+def _patch_cells(h, w):
+    """16-byte cells of one block's input patch (wf4_launch's geometry: 32 tiles = NB images x BR x BC tiles)."""
+    th, tw = -(-h // 4), -(-w // 4)
+    bc = 1
+    while bc < tw and bc < 16:
+        bc *= 2
+    br = 1
+    while br < th and br * bc < 32:
+        br *= 2
+    return (32 // (br * bc)) * (4 * br + 2) * 4 * (bc + 1)
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=["x".join(map(str, s)) for s in SHAPES])
+def test_fused_f4x4_conv_vs_oracle(pa, shape):
+    from planer_amd import q4
+    n, cin, h, w, cout = shape
+    rng = np.random.default_rng(11 + sum(shape))
+    for tail in TAILS:
+        host, dev = _operands(pa, rng, n, cin, h, w, cout, tail)
+        u = q4.prepare_wf4_q4_weights(dev["k"])
+        kw = dict(pads=(1, 1, 1, 1), act=_act(tail), alpha=0.1, w_layout=9)
+        if _patch_cells(h, w) > 1024:
+            # one-tile maps put 32 images into a block: more patch cells than the kernel's LDS buffers hold -> refused
+            # (the plan compiler then keeps another algorithm), never computed wrongly
+            with pytest.raises(NotImplementedError):
+                q4.ConvQ4(dev["xq"], u, dev["b"], dev["scale"], dev["shift"], dev["resq"], **kw)
+            continue
+        yq = q4.ConvQ4(dev["xq"], u, dev["b"], dev["scale"], dev["shift"], dev["resq"], **kw)
+        assert q4.logical_shape(yq) == (n, cout, h, w)
+        assert_close(q4.from_q4(yq).get(), _oracle(host, tail), 3e-5, "%s %s [%s]" % (shape, tail, pa.hip.context().last_conv_plan()))
+
+
+def test_fused_f4x4_is_linear_and_shard_independent(pa):
+    """Size-independent properties at a real layer size (batch 32, 64 channels, 56x56): conv(a x1 + x2) = a conv(x1) + conv(x2),
+    and row i of the batch equals the same image run alone."""
+    from planer_amd import q4
+    rng = np.random.default_rng(5)
+    k = pa.asarray((rng.standard_normal((64, 64, 3, 3)) * (2.0 / 576) ** 0.5).astype(np.float32))
+    u = q4.prepare_wf4_q4_weights(k)
+    x1 = rng.standard_normal((32, 64, 56, 56)).astype(np.float32)
+    x2 = rng.standard_normal((32, 64, 56, 56)).astype(np.float32)
+
+    def conv(x):
+        return q4.from_q4(q4.ConvQ4(q4.to_q4(pa.asarray(x)), u, pads=(1, 1, 1, 1), w_layout=9)).get()
+    y1, y2, y3 = conv(x1), conv(x2), conv(2.0 * x1 + x2)
+    assert_close(y3, 2.0 * y1 + y2, 2e-5, "linearity")
+    np.testing.assert_array_equal(conv(x1[7:8]), y1[7:8])
+    # and against the staged pipeline (same algorithm, other kernels)
+    y7 = q4.from_q4(q4.ConvQ4(q4.to_q4(pa.asarray(x1)), q4.prepare_winograd4_q4_weights(k), pads=(1, 1, 1, 1), w_layout=7)).get()
+    assert_close(y1, y7, 2e-5, "fused vs staged F(4x4,3x3)")
+
+
+def test_fused_f4x4_through_the_plan_compiler(pa):
+    """ResNet-18 with every eligible conv forced onto the fused kernel: logits against the oracle."""
+    import planer_amd
+    from oracle import planer_np as onp
+    from planer_amd.irgen import resnet18
+    g, b = resnet18.build()
+    x = resnet18.make_input(4)
+    net = planer_amd.from_graph(g, b)
+    net.force_algo, net.streams = 9, "1x1"
+    y = net(planer_amd.asarray(x.copy())).get()
+    used = [a["w_layout"] for a in net.compile(planer_amd.asarray(x)).algos]
+    assert used.count(9) == 13, used
+    ref = onp.OracleNet()
+    ref.load_json(g["input"], g["inits"], g["layers"], g["flow"])
+    ref.load_weights(b)
+    assert_close(y, ref(x.copy()), RTOL, "resnet18 with the fused F(4x4,3x3) kernel")
