@@ -355,11 +355,19 @@ def main():
     tbytes = transform_bytes(prog, convs)
     per_layer = {}
     prof_steps = min(max(args.steps, 5), 20)
+    # Each profiled pass is enqueued BEHIND ~2 ms of memsets: the Python interpreter needs about as long to launch a step
+    # as the GPU needs to run it, and a GPU that waits for the host would bill the wait to the layer.  With the queue
+    # pre-filled the events bracket back-to-back kernels (what the captured graph replays).
+    blocker = planer_amd.hip.empty((256 << 20,), np.float32, ctx)          # 1 GiB
     for it in range(prof_steps + 2):
-        net._interpret(prog, [xs[it & 1].copy()], profile=True)
+        xin = xs[it & 1].copy()
+        for _ in range(8):
+            planer_amd._lib.call("pl_memset", ctx.handle, blocker.ptr, 0, blocker.nbytes)
+        net._interpret(prog, [xin], profile=True)
         if it >= 2:
             for name, kind, ms in net.last_events:
                 per_layer.setdefault((name, kind), []).append(ms)
+    del blocker
     algos = {split_step(a["layer"])[0]: a for a in plan.algos}
     rows, classes, families = [], {}, {}
     for (name, kind), v in per_layer.items():

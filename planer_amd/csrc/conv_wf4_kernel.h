@@ -97,19 +97,10 @@ __device__ __forceinline__ void wf4_transform_row(const float *P, float *V, int 
 }
 
 // row A of the 4x4 output tile of one channel quad: A^T over the frequency rows for each of the 6 frequency columns, then A^T
-// over the columns, fused tail, four 16-byte stores
+// over the columns, fused tail, four 16-byte stores (the residual quads were requested before the first row started)
 template <int A>
 __device__ __forceinline__ void wf4_output_row(const Wf4Args &p, const f32x4 (&acc)[36], float4 bias, float4 scale, float4 shift,
-                                               const __amdgpu_buffer_rsrc_t yrsrc, const __amdgpu_buffer_rsrc_t rrsrc,
-                                               unsigned rowbase, bool cok, int h, int w0) {
-    constexpr int OOB = (int)0x80000000;
-    int off[4];
-    float4 rsd[4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        off[b] = (cok && h < p.H && w0 + b < p.W) ? (int)((rowbase + b) << 4) : OOB;
-        rsd[b] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off[b], 0, 0));
-    }
+                                               const __amdgpu_buffer_rsrc_t yrsrc, const int (&off)[4], const float4 (&rsd)[4]) {
     float4 s[6];
 #pragma unroll
     for (int b = 0; b < 6; ++b) {
@@ -353,10 +344,24 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
     const float4 scale = p.ep.scale ? reinterpret_cast<const float4 *>(p.ep.scale)[cqc] : one4;
     const float4 shift = p.ep.shift ? reinterpret_cast<const float4 *>(p.ep.shift)[cqc] : z4;
     const unsigned row0 = ((unsigned)(n * p.Coq + cqc) * (unsigned)p.H + (unsigned)(ty * 4)) * (unsigned)p.W + (unsigned)(tx * 4);
-    wf4_output_row<0>(p, acc, bias, scale, shift, yrsrc, rrsrc, row0, cok, ty * 4, tx * 4);
-    wf4_output_row<1>(p, acc, bias, scale, shift, yrsrc, rrsrc, row0 + (unsigned)p.W, cok, ty * 4 + 1, tx * 4);
-    wf4_output_row<2>(p, acc, bias, scale, shift, yrsrc, rrsrc, row0 + 2u * (unsigned)p.W, cok, ty * 4 + 2, tx * 4);
-    wf4_output_row<3>(p, acc, bias, scale, shift, yrsrc, rrsrc, row0 + 3u * (unsigned)p.W, cok, ty * 4 + 3, tx * 4);
+    // the residual quads are requested two output rows at a time: two memory round trips per tile instead of four
+    // (all sixteen at once would not fit beside the 144 accumulator registers)
+    auto rows_pair = [&](auto first) {
+        constexpr int A0 = decltype(first)::value;
+        int off[2][4];
+        float4 rsd[2][4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                off[a][b] = (cok && ty * 4 + A0 + a < p.H && tx * 4 + b < p.W) ? (int)((row0 + (unsigned)((A0 + a) * p.W + b)) << 4) : OOB;
+                rsd[a][b] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off[a][b], 0, 0));
+            }
+        wf4_output_row<A0>(p, acc, bias, scale, shift, yrsrc, off[0], rsd[0]);
+        wf4_output_row<A0 + 1>(p, acc, bias, scale, shift, yrsrc, off[1], rsd[1]);
+    };
+    rows_pair(std::integral_constant<int, 0>{});
+    rows_pair(std::integral_constant<int, 2>{});
 }
 
 template <bool DMA_A, bool PLANAR, bool STAGGER, int LBC>

@@ -29,7 +29,7 @@ for attempt in 1 2 3 4 5 6; do
 done
 for attempt in 1 2 3 4; do
   PLANER_HIP_STREAMS=1x1 rocprofv3 --kernel-trace --stats -d $out -o ${tag}_bench_1stream --output-format csv -- \
-      python $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-e2e "$@" > $out/${tag}_bench_1stream_line.json 2> $out/${tag}_1stream.err
+      python $R/bench.py --steps 50 --warmup 10 --repeats 1 --settle-ms 50 --no-cpu-baseline --no-e2e "$@" > $out/${tag}_bench_1stream_line.json 2> $out/${tag}_1stream.err
   [ -s $out/${tag}_bench_1stream_line.json ] && [ -s $out/${tag}_bench_1stream_kernel_trace.csv ] && break
   echo "one-stream pass: attempt $attempt failed, retrying"; tail -3 $out/${tag}_1stream.err
 done

@@ -104,6 +104,8 @@ def expected_kernels(a):
     gemm = ["conv_ks_kernel" if "[k" in plan or plan.startswith("k") else "conv_q4_kernel" if "[q" in plan or plan.startswith("q") else "conv_pc_kernel" if "p" in plan.split()[0] else "conv_igemm_kernel"]
     if re.search(r"split=([2-9]|\d\d)", plan):
         gemm.append("reduce_tiles")
+    if algo.startswith("wf4"):
+        return ["conv_wf4_kernel"]
     if algo.startswith("rowpack"):
         return ["nchw_to_rowpack_kernel"] + gemm
     if algo.startswith("w1d4"):
