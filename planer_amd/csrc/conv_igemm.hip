@@ -1285,8 +1285,19 @@ int conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const
 // The patch (ph x pw pooled pixels) is the one that covers the pooled map with the fewest tiles -- 7 x 8 on
 // ResNet's 56 x 56: 15 x 17 = 255 of 256 columns used, 14 % of the conv pixels computed twice (the halo),
 // against the 103 MB write + 107 MB read of the full-resolution tensor that no longer happen.
+template <class C>
+int conv_pool_run_t(pl_ctx *ctx, ConvArgs a);
+
 int conv_pool_run(pl_ctx *ctx, ConvArgs a) {
-    using C = Q64x256x16;
+    // column tile = one patch of conv pixels: 256 columns (15 x 17 pixels -> 7 x 8 pooled, 14 % of the conv pixels computed
+    // twice, 183 registers) or 128 (PLANER_HIP_POOL_TILE=128: 7 x 17 patches, 24 % halo, the occupancy of the plain kernel --
+    // measured on ResNet-18's stem at batch 32: 143.9 us against 138.7 us for the 256-column tile and 103.5 + 22.6 us unfused)
+    static const int tile = getenv("PLANER_HIP_POOL_TILE") ? atoi(getenv("PLANER_HIP_POOL_TILE")) : 256;
+    return tile == 128 ? conv_pool_run_t<Q64x128x16>(ctx, a) : conv_pool_run_t<Q64x256x16>(ctx, a);
+}
+
+template <class C>
+int conv_pool_run_t(pl_ctx *ctx, ConvArgs a) {
     const int Hp = (a.Ho + 1) / 2, Wp = (a.Wo + 1) / 2;          // (H + 2 - 3 + 2) // 2, util.py:84-85
     int best_ph = 1, best_pw = 1;
     long best_tiles = -1, best_px = 0;
@@ -1322,7 +1333,7 @@ int conv_pool_run(pl_ctx *ctx, ConvArgs a) {
     hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles * a.groups)), dim3(256), lds, ctx->stream, a, pa);
     PL_LAUNCH_CHECK();
     char buf[96];
-    snprintf(buf, sizeof buf, "q64x256x16+maxpool patch=%dx%d tiles=%d", ph, pw, a.tiles * a.groups);
+    snprintf(buf, sizeof buf, "q64x%dx16+maxpool patch=%dx%d tiles=%d", C::BN, ph, pw, a.tiles * a.groups);
     ctx->last_plan = buf;
     ctx->last_gemm[0] = a.groups; ctx->last_gemm[1] = (long long)a.mtiles * C::BM; ctx->last_gemm[2] = (long long)a.ntiles * C::BN;
     ctx->last_gemm[3] = (long long)total_chunks * C::BK;
