@@ -80,9 +80,20 @@ def executed_flops(rec):
 
 
 def split_step(name):
-    """Plan step name -> (layer of the user's graph, stage): "l20b_conv+@chain" -> ("l20b_conv", "chain")."""
+    """Plan step name -> (layer of the user's graph, stage): "l20b_conv+@chain" -> ("l20b_conv", "chain"); a pair of
+    sibling convs in one launch, "l20a_conv+&l20d_conv+", keeps both names: "l20a_conv&l20d_conv"."""
     base, _, stage = name.partition("@")
-    return base.rstrip("+"), stage
+    return "&".join(part.rstrip("+") for part in base.split("&")), stage
+
+
+def conv_of(convs, base):
+    """Geometry / FLOPs of a plan step's conv(s): a paired step sums its two convs (class of the first)."""
+    if "&" not in base:
+        return convs.get(base)
+    parts = [convs.get(b) for b in base.split("&")]
+    if any(c is None for c in parts):
+        return None
+    return dict(parts[0], flops=sum(c["flops"] for c in parts))
 
 
 def transform_bytes(prog, convs):
@@ -94,7 +105,7 @@ def transform_bytes(prog, convs):
         name = names[0]
         obj = prog.objs[name]
         base, stage = split_step(name)
-        c = convs.get(base)
+        c = conv_of(convs, base)
         if c is None or stage not in ("in", "out", "chain"):
             continue
         tiles = c["n"] * cdiv(c["h"], 4) * cdiv(c["w"], 4)
@@ -373,7 +384,7 @@ def main():
     for (name, kind), v in per_layer.items():
         ms = float(np.median(v))                 # median: one pool-growth hiccup must not skew a layer
         base, stage = split_step(name)
-        c, rec = convs.get(base), algos.get(base)
+        c, rec = conv_of(convs, base), algos.get(base)
         mfma_step = c is not None and stage in ("", "gemm")          # the step of a conv that runs its GEMM(s)
         alg = c["flops"] if mfma_step else 0.0
         exe = executed_flops(rec) if mfma_step else None
@@ -512,7 +523,7 @@ def main():
                       "global_batch": global_batch, "per_gpu_batch": n, "parallelism": "batch-shard x%d" % world,
                       "weight_bcast_ms": round(bcast_ms, 3), "rccl_ranks": rccl_ranks,
                       "rank_images_per_sec": rank_rates, "repeat_values": repeat_values,
-                      "tune_source": tune_src, "wino_chains": wino_chains,
+                      "tune_source": tune_src, "wino_chains": wino_chains, "conv_pairs": net.conv_pairs,
                       "plan_steps": [[names[0], prog.objs[names[0]].name] for _, names, _ in prog.flow],
                       "weight_exchange": ("single process" if world == 1 else "one ncclBroadcast of the uint8 blob (RCCL)"
                                           if comm.device_transport else "local upload per rank -- " + getattr(comm, "why", "")),

@@ -221,6 +221,18 @@ int pl_wino4_chain_q4_f32(pl_ctx *ctx, const float *M, int N, int C, int H, int 
                           const float *scale, const float *shift, const float *resq, int act, double alpha,
                           float *yq, float *Vnext);
 
+/* Two channel-quad convolutions that read the SAME input, in one launch (both with the fused tail
+ * y = act((conv + bias) * scale + shift), no residual; group 1, dilation 1, symmetric pads; filters from
+ * pl_conv2d_prepare_q4_f32).  Replaces two calls of util.conv_for (util.py:17-44) where a graph forks: ResNet's
+ * stride-2 3x3 conv and the 1x1 stride-2 projection beside it -- the projection's tiles fill the tail of the
+ * sibling's grid and find the pixels it gathers in the L2.  Results equal the two separate launches bit for bit
+ * when those run unsplit with the same tile configuration. */
+int pl_conv2d_q4_pair_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W,
+                          const float *wq_a, int Cout_a, int kh_a, int kw_a, int sh_a, int sw_a, int pt_a, int pl_a,
+                          const float *bias_a, const float *scale_a, const float *shift_a, int act_a, double alpha_a, float *yq_a,
+                          const float *wq_b, int Cout_b, int kh_b, int kw_b, int sh_b, int sw_b, int pt_b, int pl_b,
+                          const float *bias_b, const float *scale_b, const float *shift_b, int act_b, double alpha_b, float *yq_b);
+
 /* Fully fused Winograd F(4x4,3x3) on Q4 tensors (3x3 / stride 1 / pad 1 / group 1, Cin %% 4 == 0, Cout %% 4 == 0;
  * replaces util.conv_for, util.py:17-44, + the fused tail): one workgroup carries 32 tiles x 64 output channels
  * through all 36 frequencies -- input transform into LDS, v_mfma_f32_16x16x4_f32 with the 36 accumulator blocks in

@@ -67,6 +67,7 @@ SIGNATURES = {
     "pl_conv2d_winograd4_q4_filter_elems": [_I, _I, POINTER(c_size_t)],
     "pl_conv2d_prepare_winograd4_q4_f32": [_P, _P, _I, _I, _P],
     "pl_conv2d_winograd4_q4_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, c_double],
+    "pl_conv2d_q4_pair_f32": [_P, _P, _I, _I, _I, _I] + 2 * ([_P] + [_I] * 7 + [_P, _P, _P, _I, c_double, _P]),
     "pl_conv2d_wf4_filter_elems": [_I, _I, POINTER(c_size_t)],
     "pl_conv2d_prepare_wf4_f32": [_P, _P, _I, _I, _P],
     "pl_conv2d_wf4_q4_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, c_double],

@@ -80,10 +80,10 @@ struct TileCoord {
     int m0, col0;
 };
 
+// (bid, nblk): this workgroup's index among the nblk workgroups of ITS conv -- the whole grid, except in the two-conv
+// launch (conv_q4_pair_kernel)
 template <int BM, int BN>
-__device__ __forceinline__ TileCoord tile_coord(const ConvArgs &p) {
-    const unsigned nblk = gridDim.x;
-    unsigned bid = blockIdx.x;
+__device__ __forceinline__ TileCoord tile_coord(const ConvArgs &p, unsigned bid = blockIdx.x, unsigned nblk = gridDim.x) {
     const unsigned q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;   // bijective for any grid
     TileCoord tc;
@@ -693,6 +693,7 @@ struct CfgInfo {
     void (*reduce4)(const ConvArgs, const float *, float *);
     bool pc;     // persistent producer/consumer kernel (conv_pcg_kernel.h): 512 threads, one workgroup per CU
     bool ks;     // intra-workgroup K split (conv_ks_kernel.h): 1024 threads, 32x32 tile, no split-K plans
+    void (*pair)(const ConvArgs, const ConvArgs);    // two convs on one input in one launch (conv_q4_pair_kernel), or null
 };
 
 #define CFG_ENTRY(T, nm)                                                                                 \
@@ -707,6 +708,9 @@ struct CfgInfo {
 #define Q4_ENTRY(T, nm) \
     { nm, 2, T::BM, T::BN, T::BK, T::LDS_BYTES, conv_q4_kernel<T>, conv_q4_kernel<T>, \
       reduce_tiles_q4_kernel<T::BM, T::BN>, reduce_tiles_q4_kernel<T::BM, T::BN>, false }
+#define Q4P_ENTRY(T, nm) \
+    { nm, 2, T::BM, T::BN, T::BK, T::LDS_BYTES, conv_q4_kernel<T>, conv_q4_kernel<T>, \
+      reduce_tiles_q4_kernel<T::BM, T::BN>, reduce_tiles_q4_kernel<T::BM, T::BN>, false, false, conv_q4_pair_kernel<T> }
 #define PC_ENTRY(T, nm) \
     { nm, 2, T::BM, T::BN, T::BK, T::LDS_BYTES, conv_pc_kernel<T>, conv_pc_kernel<T>, nullptr, nullptr, true }
 typedef PcCfg<128, 128> P128x128;
@@ -724,10 +728,10 @@ const CfgInfo kCfgs[] = {
     TAP_ENTRY(T128x32x32, "t128x32x32"),   TAP_ENTRY(T32x128x32, "t32x128x32"),
     TAP_ENTRY(T256x64x16, "t256x64x16"),   TAP_ENTRY(T64x256x16, "t64x256x16"),
     Q4_ENTRY(Q128x128x16, "q128x128x16"),  Q4_ENTRY(Q128x128x32, "q128x128x32"),
-    Q4_ENTRY(Q64x128x16, "q64x128x16"),    Q4_ENTRY(Q64x128x32, "q64x128x32"),
-    Q4_ENTRY(Q128x64x16, "q128x64x16"),    Q4_ENTRY(Q128x64x32, "q128x64x32"),
-    Q4_ENTRY(Q64x64x16, "q64x64x16"),      Q4_ENTRY(Q64x64x32, "q64x64x32"),
-    Q4_ENTRY(Q128x32x32, "q128x32x32"),    Q4_ENTRY(Q32x128x32, "q32x128x32"),
+    Q4P_ENTRY(Q64x128x16, "q64x128x16"),    Q4P_ENTRY(Q64x128x32, "q64x128x32"),
+    Q4_ENTRY(Q128x64x16, "q128x64x16"),    Q4P_ENTRY(Q128x64x32, "q128x64x32"),
+    Q4P_ENTRY(Q64x64x16, "q64x64x16"),      Q4P_ENTRY(Q64x64x32, "q64x64x32"),
+    Q4P_ENTRY(Q128x32x32, "q128x32x32"),    Q4_ENTRY(Q32x128x32, "q32x128x32"),
     Q4_ENTRY(Q256x64x16, "q256x64x16"),    Q4_ENTRY(Q64x256x16, "q64x256x16"),
     PC_ENTRY(P128x128, "p128x128x16"),     PC_ENTRY(P64x256, "p64x256x16"),     PC_ENTRY(P256x64, "p256x64x16"),
 #define KS_ENTRY(TM, TN, nm) \
@@ -1279,6 +1283,126 @@ int conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const
         }
     }
     return run_plan(ctx, a, plan, avec, y);
+}
+
+// ---- two channel-quad convs on one input in one launch (conv_q4_pair_kernel) ----
+struct PairConv {
+    const float *wq, *bias, *scale, *shift;
+    float *y;
+    int Cout, kh, kw, sh, sw, pt, pl, act;
+    double alpha;
+};
+
+// ConvArgs of an unsplit channel-quad conv (what conv_launch builds for layout 2, group 1, dilation 1)
+int pair_conv_args(ConvArgs &a, const float *x, int N, int Cin, int H, int W, const PairConv &c) {
+    const int Ho = (H + 2 * c.pt - (c.kh - 1) - 1 + c.sh) / c.sh, Wo = (W + 2 * c.pl - (c.kw - 1) - 1 + c.sw) / c.sw;
+    PL_REQUIRE(Ho > 0 && Wo > 0, PL_EINVAL, "conv pair: empty output (%d x %d)", Ho, Wo);
+    const int cqg = (Cin + 3) / 4, q_tot = c.kh * c.kw * cqg, q_pad = (q_tot + 7) / 8 * 8;
+    const size_t in_elems = (size_t)N * cqg * 4 * H * W, out_elems = (size_t)N * ((c.Cout + 3) / 4) * 4 * Ho * Wo;
+    const size_t w_elems = (size_t)q_pad * c.Cout * 4;
+    PL_REQUIRE(out_elems < (1ull << 29) && in_elems < (1ull << 29) && w_elems < (1ull << 29), PL_EUNSUPPORTED,
+               "conv pair: tensor above 2 GiB");
+    memset(&a, 0, sizeof a);
+    a.x = x; a.w = c.wq; a.y = c.y;
+    a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = c.Cout; a.Ho = Ho; a.Wo = Wo;
+    a.kh = c.kh; a.kw = c.kw; a.sh = c.sh; a.sw = c.sw; a.dh = a.dw = 1; a.pt = c.pt; a.pl = c.pl;
+    a.groups = 1; a.cin_g = Cin; a.cout_g = c.Cout;
+    a.K = q_tot * 4;
+    a.cqg = cqg; a.Cq = cqg; a.Coq = (c.Cout + 3) / 4; a.Qtot = q_tot; a.Qpad = q_pad;
+    a.cols = N * Ho * Wo;
+    a.HoWo = Ho * Wo; a.HW = H * W;
+    a.y_bytes = (int)(out_elems * 4); a.x_bytes = (int)(in_elems * 4); a.w_bytes = (int)(w_elems * 4);
+    a.divKhw = FastDiv(c.kh * c.kw); a.divKw = FastDiv(c.kw);
+    a.divHoWo = FastDiv(a.HoWo); a.divWo = FastDiv(Wo);
+    a.ep = make_epilogue(c.bias, c.scale, c.shift, nullptr, c.act, c.alpha);
+    return PL_OK;
+}
+
+// tile the conv for configuration ci, unsplit, whole conv in this launch
+void pair_tile(ConvArgs &a, const CfgInfo &ci) {
+    a.mtiles = (a.cout_g + ci.bm - 1) / ci.bm;
+    a.ntiles = (a.cols + ci.bn - 1) / ci.bn;
+    a.tiles = a.mtiles * a.ntiles;
+    a.divMt = FastDiv(a.mtiles);
+    const int kg = ci.bk / 4;
+    a.k_per_split = (a.Qtot + kg - 1) / kg;
+    a.splits = 1; a.tile_offset = 0; a.tile_count = a.tiles;
+    a.uni = a.cqg % kg == 0;
+    a.divCpt = FastDiv(a.cqg);
+}
+
+int pair_run(pl_ctx *ctx, ConvArgs a, ConvArgs b, int cfg) {
+    const CfgInfo &ci = kCfgs[cfg];
+    pair_tile(a, ci);
+    pair_tile(b, ci);
+    if (ci.lds > 48 * 1024) {
+        int rc = ensure_lds_attr((const void *)ci.pair, ci.lds);
+        if (rc != PL_OK) return rc;
+    }
+    hipLaunchKernelGGL(ci.pair, dim3((unsigned)(a.tile_count + b.tile_count)), dim3(256), ci.lds, ctx->stream, a, b);
+    PL_LAUNCH_CHECK();
+    char buf[96];
+    snprintf(buf, sizeof buf, "pair[%s tiles=%d+%d]", ci.name, a.tile_count, b.tile_count);
+    ctx->last_plan = buf;
+    // executed MACs of both convs (whole tiles, whole chunks) as one product
+    auto macs = [&](const ConvArgs &c) {
+        return (long long)c.mtiles * ci.bm * c.ntiles * ci.bn * ((c.Qtot * 4 + ci.bk - 1) / ci.bk * ci.bk);
+    };
+    ctx->last_gemm[0] = 1; ctx->last_gemm[1] = 1; ctx->last_gemm[2] = 1; ctx->last_gemm[3] = macs(a) + macs(b);
+    return PL_OK;
+}
+
+int pair_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const PairConv &ca, const PairConv &cb) {
+    ConvArgs a, b;
+    int rc = pair_conv_args(a, x, N, Cin, H, W, ca);
+    if (rc != PL_OK) return rc;
+    rc = pair_conv_args(b, x, N, Cin, H, W, cb);
+    if (rc != PL_OK) return rc;
+    TuneKey key = {{20, N, Cin, H, W, ca.Cout, ca.kh, ca.kw, ca.sh, ca.pt, cb.Cout, cb.kh, cb.kw, cb.sh, cb.pt,
+                    (ca.scale != nullptr) * 2 + (ca.bias != nullptr), (cb.scale != nullptr) * 2 + (cb.bias != nullptr), ca.act * 4 + cb.act}};
+    int cfg = -1;
+    {
+        std::lock_guard<std::mutex> lk(g_tune_mu);
+        auto it = g_tune.find({ctx->device, key});
+        if (it != g_tune.end()) cfg = it->second.cfg;
+    }
+    if (cfg < 0) {
+        // first sight of the pair: time every configuration that has a pair kernel (never while capturing)
+        int first = -1;
+        float best = 1e30f;
+        const bool tune = ctx->autotune && !ctx->capturing;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (tune && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) return PL_EHIP;
+        for (int c = 0; c < kNumCfgs; ++c) {
+            if (!kCfgs[c].pair) continue;
+            if (first < 0) first = c;
+            if (!tune) continue;
+            float ms_best = 1e30f;
+            for (int rep = 0; rep < 4; ++rep) {
+                (void)hipEventRecord(e0, ctx->stream);
+                if (pair_run(ctx, a, b, c) != PL_OK) break;
+                (void)hipEventRecord(e1, ctx->stream);
+                if (hipEventSynchronize(e1) != hipSuccess) break;
+                float ms = 0.f;
+                (void)hipEventElapsedTime(&ms, e0, e1);
+                if (rep > 0 && ms < ms_best) ms_best = ms;
+            }
+            if (ms_best < best) best = ms_best, cfg = c;
+        }
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        if (cfg < 0) cfg = first;
+        PL_REQUIRE(cfg >= 0, PL_EUNSUPPORTED, "conv pair: no kernel configuration");
+        if (tune) {
+            ++ctx->tune_misses;
+            std::lock_guard<std::mutex> lk(g_tune_mu);
+            g_tune[{ctx->device, key}] = Plan{cfg, 0, 1, 0};
+            if (getenv("PLANER_CONV_TUNE_LOG"))
+                fprintf(stderr, "[planer_hip] conv pair N%d C%d %dx%d -> %d k%d s%d + %d k%d s%d: %s (%.3f ms)\n", N, Cin, H, W, ca.Cout,
+                        ca.kh, ca.sh, cb.Cout, cb.kh, cb.sh, kCfgs[cfg].name, best);
+        }
+    }
+    return pair_run(ctx, a, b, cfg);
 }
 
 // conv + maxpool(3x3 / stride 2 / pad 1) in one launch: 64 x 256 tiles, a column tile = one patch of conv pixels.
@@ -2525,6 +2649,26 @@ int pl_conv2d_winograd4_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int
     return winograd4_q4_launch(ctx, xq, N, Cin, H, W, uq, Cout, bias, yq, scale, shift, resq, act, alpha, mono_lds);
 }
 
+int pl_conv2d_q4_pair_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W,
+                          const float *wq_a, int Cout_a, int kh_a, int kw_a, int sh_a, int sw_a, int pt_a, int pl_a,
+                          const float *bias_a, const float *scale_a, const float *shift_a, int act_a, double alpha_a, float *yq_a,
+                          const float *wq_b, int Cout_b, int kh_b, int kw_b, int sh_b, int sw_b, int pt_b, int pl_b,
+                          const float *bias_b, const float *scale_b, const float *shift_b, int act_b, double alpha_b, float *yq_b) {
+    PL_REQUIRE(ctx && xq && wq_a && wq_b && yq_a && yq_b, PL_EINVAL, "pl_conv2d_q4_pair_f32: null pointer");
+    PL_REQUIRE(N >= 0 && Cin > 0 && H > 0 && W > 0 && Cout_a > 0 && Cout_b > 0 && kh_a > 0 && kw_a > 0 && kh_b > 0 && kw_b > 0 &&
+                   sh_a > 0 && sw_a > 0 && sh_b > 0 && sw_b > 0 && pt_a >= 0 && pl_a >= 0 && pt_b >= 0 && pl_b >= 0,
+               PL_EINVAL, "pl_conv2d_q4_pair_f32: bad shape");
+    PL_REQUIRE(H + 2 * std::max(pt_a, pt_b) < 16384 && W + 2 * std::max(pl_a, pl_b) < 16384, PL_EUNSUPPORTED,
+               "pl_conv2d_q4_pair_f32: spatial extent above 16383");
+    PL_REQUIRE(act_a >= 0 && act_a <= 2 && act_b >= 0 && act_b <= 2, PL_EINVAL, "pl_conv2d_q4_pair_f32: bad activation code");
+    PL_REQUIRE(yq_a != yq_b, PL_EINVAL, "pl_conv2d_q4_pair_f32: the two outputs must differ");
+    if (N == 0) return PL_OK;
+    CtxGuard guard(ctx);
+    const PairConv ca{wq_a, bias_a, scale_a, shift_a, yq_a, Cout_a, kh_a, kw_a, sh_a, sw_a, pt_a, pl_a, act_a, alpha_a};
+    const PairConv cb{wq_b, bias_b, scale_b, shift_b, yq_b, Cout_b, kh_b, kw_b, sh_b, sw_b, pt_b, pl_b, act_b, alpha_b};
+    return pair_launch(ctx, xq, N, Cin, H, W, ca, cb);
+}
+
 // ---- fully fused F(4x4,3x3): conv_wf4_kernel.h ----
 int pl_conv2d_wf4_filter_elems(int Cout, int Cin, size_t *elems) {
     PL_REQUIRE(elems && Cout > 0 && Cin > 0 && Cin % 4 == 0, PL_EINVAL, "pl_conv2d_wf4_filter_elems: bad argument");
@@ -2772,7 +2916,9 @@ int pl_tune_cache_load(pl_ctx *ctx, const char *path, int *entries) {
         if (!ok || fscanf(f, "%63s %d %d %d", name, &pl.t1, &pl.s2, &pl.occ) != 4) break;
         for (int c = 0; c < kNumCfgs; ++c)
             if (!strcmp(kCfgs[c].name, name)) pl.cfg = c;
-        if (pl.cfg < 0 || !cfg_applies(kCfgs[pl.cfg], key.v[0], key.v[2] / (key.v[14] > 0 ? key.v[14] : 1))) continue;
+        if (key.v[0] == 20) {                    // a conv pair (pl_conv2d_q4_pair_f32): any configuration with a pair kernel
+            if (pl.cfg < 0 || !kCfgs[pl.cfg].pair) continue;
+        } else if (pl.cfg < 0 || !cfg_applies(kCfgs[pl.cfg], key.v[0], key.v[2] / (key.v[14] > 0 ? key.v[14] : 1))) continue;
         g_tune[{ctx->device, key}] = pl;
         if (entries) ++*entries;
     }

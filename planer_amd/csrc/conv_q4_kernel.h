@@ -335,7 +335,8 @@ __global__ void __launch_bounds__(256) reduce_tiles_q4_kernel(const ConvArgs p, 
 // POOL: the tile's BN columns are one (2*ph+1) x (2*pw+1) patch of conv pixels (rows / columns overlap the
 // neighbouring patches by one), and the tail max-pools it 3x3 / stride 2 / pad 1 through LDS (pool_tile_q4).
 template <class C, bool POOL>
-__device__ __forceinline__ void conv_q4_body(const ConvArgs &p, const PoolArgs *pap) {
+__device__ __forceinline__ void conv_q4_body(const ConvArgs &p, const PoolArgs *pap, unsigned bid = blockIdx.x,
+                                             unsigned nblk = gridDim.x) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;                         // [2][KG][BM][4]
     float *Bs = smem + 2 * C::A_ELEMS;        // [2][KG][BN][4]
@@ -345,7 +346,7 @@ __device__ __forceinline__ void conv_q4_body(const ConvArgs &p, const PoolArgs *
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / C::WN, wn = wave % C::WN;
 
-    const TileCoord tc = tile_coord<C::BM, C::BN>(p);
+    const TileCoord tc = tile_coord<C::BM, C::BN>(p, bid, nblk);
     const unsigned g = tc.g;
     const int m0 = tc.m0, col0 = tc.col0;
     const int split = blockIdx.y;
@@ -613,6 +614,19 @@ template <class C>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C::MIN_WAVES)))
 conv_q4_kernel(const ConvArgs p) {
     conv_q4_body<C, false>(p, nullptr);
+}
+
+// Two convolutions that read the SAME input in one launch: workgroups [0, pa.tile_count) run conv a, the rest conv b (both
+// unsplit).  Made for a stride-2 3x3 conv and the 1x1 stride-2 projection beside it (a ResNet block that changes resolution):
+// the projection alone is 392-784 tiles of two K chunks -- launch-bound at 0.25 of the matrix peak -- and re-reads exactly the
+// pixels its sibling gathers; here its tiles fill the tail of the sibling's grid and find those pixels in the L2.
+template <class C>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C::MIN_WAVES)))
+conv_q4_pair_kernel(const ConvArgs pa, const ConvArgs pb) {
+    if (blockIdx.x < (unsigned)pa.tile_count)
+        conv_q4_body<C, false>(pa, nullptr, blockIdx.x, (unsigned)pa.tile_count);
+    else
+        conv_q4_body<C, false>(pb, nullptr, blockIdx.x - (unsigned)pa.tile_count, (unsigned)pb.tile_count);
 }
 
 template <class C>

@@ -28,7 +28,7 @@ from . import hip
 from .hip import DeviceArray
 from . import q4 as _q4
 from .layer import layer_map, wrap
-from .plan import assign_layouts, chain_winograd, fuse_flow
+from .plan import assign_layouts, chain_winograd, fuse_flow, pair_sibling_convs
 
 _q4.register(layer_map)
 
@@ -215,6 +215,7 @@ class Net:
         self._extra = {}             # derived constant tensors (tap-major / Winograd filters)
         self._algo = {}              # conv shape signature -> chosen w_layout
         self.wino_chains = 0         # F(4x4,3x3) output / input transform pairs the last plan runs as one kernel
+        self.conv_pairs = 0          # sibling conv pairs the last plan runs as one launch
         # force_algo: w_layout (int) every eligible 3x3/s1/p1 conv must use, or None = pick by timing
         fa = os.environ.get("PLANER_HIP_CONV_ALGO")
         self.force_algo = int(fa) if fa else None
@@ -313,8 +314,8 @@ class Net:
                 val = obj(*args)
                 if profile:
                     events.append((name, obj.name, e0, hip.Event(self.ctx).record()))
-                if record is not None and obj.name in ("conv", "conv_fused", "conv_q4", "dense", "matmul", "wino4_gemm"):
-                    lay = obj.para().get("w_layout", 0) if obj.name != "conv" else 0
+                if record is not None and obj.name in ("conv", "conv_fused", "conv_q4", "dense", "matmul", "wino4_gemm", "conv_q4_pair"):
+                    lay = obj.para().get("w_layout", 2 if obj.name == "conv_q4_pair" else 0) if obj.name != "conv" else 0
                     lname = name
                     if obj.name == "wino4_gemm":               # the GEMM stage of a staged F(4x4,3x3) conv
                         lay, lname = 7, name[:-len("@gemm")]
@@ -430,6 +431,10 @@ class Net:
         out_flow = self._fuse_upsample_concat(out_body, out_flow)
         used = {n for _, names, _ in out_flow for n in names}
         out_list = [out_body[b[0]] for b in body if b[0] in used]
+        # two direct convs on one tensor (a resolution-changing ResNet block) -> one launch; PLANER_HIP_PAIR=0 turns it off
+        if os.environ.get("PLANER_HIP_PAIR", "1") != "0":
+            out_list, out_flow, self.conv_pairs = pair_sibling_convs(
+                out_list, out_flow, lambda key: shapes.get(key.split("@")[0]))
         # F(4x4,3x3) convs as explicit stages, consecutive ones sharing a transform kernel (plan.chain_winograd);
         # PLANER_HIP_WINO_CHAIN: "1" chain (default), "stages" explicit stages without chaining, "0" one call per conv
         mode = os.environ.get("PLANER_HIP_WINO_CHAIN", "1")

@@ -332,3 +332,66 @@ def chain_winograd(body, flow, supported=lambda key: True, chain=True):
             seen.add(name)
             out_body.append([name, kind, para])
     return out_body, [[srcs, [name], dst] for srcs, name, kind, para, dst in steps], nchained
+
+
+# ---- sibling convolutions --------------------------------------------------------------------------------
+# Where a graph forks into two direct channel-quad convs on the same tensor -- a ResNet block that changes resolution:
+# the stride-2 3x3 conv and the 1x1 stride-2 projection -- both run in ONE launch (q4.ConvQ4Pair,
+# csrc/conv_q4_kernel.h conv_q4_pair_kernel).  The second conv moves up to the first one's place; it only needs the
+# shared input and constants, so that is legal unless something rewrites the input in place in between.
+_IN_PLACE = ("relu", "relu_q4", "clip", "erf", "instancenormalization")
+
+
+def pair_sibling_convs(body, flow, kshape=lambda key: None):
+    """-> (body', flow', number of pairs).  One layer per step, as made by Net._prepare_filters.  `kshape(key)` gives
+    the OIHW shape of a filter key; only the projection pattern is paired -- equal strides > 1, one of the two a 1x1 --
+    because both convs then have the same output map and neither wants a split-K plan of its own."""
+    kinds = {b[0]: b for b in body}
+    steps = [[list(src) if isinstance(src, (list, tuple)) else [src], names[0] if isinstance(names, (list, tuple)) else names, dst]
+             for src, names, dst in flow]
+
+    def direct(i):
+        srcs, name, dst = steps[i]
+        _, kind, para = kinds[name]
+        full = srcs + ["None"] * (6 - len(srcs))
+        return (kind == "conv_q4" and para.get("w_layout") == 2 and isinstance(dst, str) and full[5] == "None"
+                and int(para.get("group", 1)) == 1 and [int(v) for v in para.get("dilations", (1, 1))] == [1, 1]
+                and not para.get("pool") and not para.get("rowpack") and not (int(para.get("act", 0)) & ~3))
+
+    used, npairs, out = set(), 0, []
+    for i in range(len(steps)):
+        if i in used:
+            continue
+        srcs, name, dst = steps[i]
+        j = None
+        if direct(i):
+            for k in range(i + 1, len(steps)):
+                ks, kname, kdst = steps[k]
+                if srcs[0] in ks and kinds[kname][1] in _IN_PLACE:
+                    break                                   # the shared input is rewritten: later readers see other values
+                if srcs[0] in _as_list(kdst):
+                    break
+                if k not in used and direct(k) and ks[0] == srcs[0]:
+                    p1, p2 = kinds[name][2], kinds[kname][2]
+                    k1, k2 = kshape(srcs[1]), kshape(ks[1])
+                    st1, st2 = [int(v) for v in p1.get("strides", (1, 1))], [int(v) for v in p2.get("strides", (1, 1))]
+                    if (k1 is not None and k2 is not None and st1 == st2 and min(st1) > 1
+                            and min(k1[2] * k1[3], k2[2] * k2[3]) == 1):
+                        j = k
+                        break
+        if j is None:
+            out.append((srcs, name, kinds[name][1], kinds[name][2], dst))
+            continue
+        s2, n2, d2 = steps[j]
+        f1, f2 = srcs + ["None"] * (6 - len(srcs)), s2 + ["None"] * (6 - len(s2))
+        pname = name + "&" + n2
+        out.append(([f1[0]] + f1[1:5] + f2[1:5], pname, "conv_q4_pair",
+                    {"para1": dict(kinds[name][2]), "para2": dict(kinds[n2][2])}, [dst, d2]))
+        used.add(j)
+        npairs += 1
+    out_body, seen = [], set()
+    for srcs, name, kind, para, dst in out:
+        if name not in seen:
+            seen.add(name)
+            out_body.append([name, kind, para])
+    return out_body, [[srcs, [name], dst] for srcs, name, kind, para, dst in out], npairs

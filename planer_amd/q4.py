@@ -253,6 +253,32 @@ def ConvQ4(xq, Kq, B=None, scale=None, shift=None, resq=None, group=1, strides=(
     return y
 
 
+def ConvQ4Pair(xq, K1, B1, scale1, shift1, K2, B2, scale2, shift2, para1=None, para2=None, **_):
+    """Two fused convs (ConvQ4, w_layout 2, group 1, no dilation, no residual) that read the SAME Q4 input, in one
+    launch -> (y1, y2).  Emitted by plan.pair_sibling_convs where a graph forks into two convs (ResNet's stride-2
+    3x3 conv and the 1x1 stride-2 projection of the same block)."""
+    _f32(xq, K1, B1, scale1, shift1, K2, B2, scale2, shift2)
+    if not is_q4(xq):
+        raise TypeError("ConvQ4Pair needs a Q4 activation")
+    n, cin, h, w = logical_shape(xq)
+    outs, args = [], []
+    for K, B, sc, sh, para in ((K1, B1, scale1, shift1, para1 or {}), (K2, B2, scale2, shift2, para2 or {})):
+        cout, cin_g, kh, kw = K.shape
+        strides = [int(v) for v in para.get("strides", (1, 1))]
+        pads = [int(v) for v in para.get("pads", (0, 0, 0, 0))]
+        if (cin_g != cin or int(para.get("group", 1)) != 1 or [int(v) for v in para.get("dilations", (1, 1))] != [1, 1]
+                or pads[0] != pads[2] or pads[1] != pads[3] or int(para.get("act", 0)) & ~3):
+            raise ValueError("ConvQ4Pair: group 1, dilation 1, symmetric pads, no residual; weight %s on input %s"
+                             % (K.shape, (n, cin, h, w)))
+        ho, wo = conv_out_hw(h, w, kh, kw, strides, [1, 1], pads)
+        y = _new_q4(n, cout, ho, wo, xq.ctx)
+        outs.append(y)
+        args += [K.ptr, cout, kh, kw, strides[0], strides[1], pads[0], pads[1], _ptr(B), _ptr(sc), _ptr(sh),
+                 int(para.get("act", 0)), float(para.get("alpha", 0.0)), y.ptr]
+    _lib.call("pl_conv2d_q4_pair_f32", xq.ctx.handle, xq.ptr, n, cin, h, w, *args)
+    return tuple(outs)
+
+
 # ---- Winograd F(4x4,3x3) stage by stage (plan-internal; plan.chain_winograd emits these) -----------
 def _wino_tensor(n, c, h, w, ctx):
     """V or M of an (n, c, h, w) activation: [36][c/4][T][4], T = n * ceil(h/4) * ceil(w/4)."""
@@ -469,5 +495,6 @@ Q4_LAYERS = {"maxpool": MaxpoolQ4, "averagepool": AveragePoolQ4, "gap": GlobalAv
 def register(layer_map):
     """Plan-internal kinds (never present in a user's IR)."""
     layer_map.update({"to_q4": to_q4, "from_q4": from_q4, "conv_q4": ConvQ4, "upconcat_q4": UpConcatQ4,
-                      "wino4_in": Wino4In, "wino4_gemm": Wino4Gemm, "wino4_out": Wino4Out, "wino4_chain": Wino4Chain})
+                      "wino4_in": Wino4In, "wino4_gemm": Wino4Gemm, "wino4_out": Wino4Out, "wino4_chain": Wino4Chain,
+                      "conv_q4_pair": ConvQ4Pair})
     layer_map.update({k + "_q4": f for k, f in Q4_LAYERS.items()})

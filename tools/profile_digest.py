@@ -100,6 +100,8 @@ def expected_kernels(a):
     plan, algo = a["plan"], a["algo"]
     if plan.startswith("dense32x32"):
         return ["dense_small_kernel"]
+    if plan.startswith("pair["):
+        return ["conv_q4_pair_kernel"]
     plan = re.sub(r"^wino\d\[(.*)\]$", r"\1", plan) if algo == "direct" else plan
     gemm = ["conv_ks_kernel" if "[k" in plan or plan.startswith("k") else "conv_q4_kernel" if "[q" in plan or plan.startswith("q") else "conv_pc_kernel" if "p" in plan.split()[0] else "conv_igemm_kernel"]
     if re.search(r"split=([2-9]|\d\d)", plan):
@@ -122,7 +124,7 @@ def expected_kernels(a):
 def step_kernels(step, kind, algos):
     """Kernel-name fragments a plan step launches, in order (config.plan_steps of the bench line); None = unknown kind."""
     a = algos.get(step.split("@")[0])
-    if kind in ("conv_q4", "conv_fused", "conv", "dense", "matmul"):
+    if kind in ("conv_q4", "conv_fused", "conv", "dense", "matmul", "conv_q4_pair"):
         return expected_kernels(a) if a else None
     if kind in ("wino4_in", "wino4_out", "wino4_chain"):
         return ["wino4_"]                    # wino4_chain_kernel<..> (LDS) or wino4_input_ / wino4_output_ (register kernels)
