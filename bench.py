@@ -41,6 +41,7 @@ import numpy as np  # noqa: E402
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0
 PER_GPU_BATCH = 32                 # BASELINE.json configs[2] / configs[3]: 32 images per GPU
+PROF_REPEAT = 10                   # launches of a step between its two stream markers in the per-layer passes
 PROFILE_TAG = "r03"                # profiles/<tag>_* files this build's numbers are cross-checked against
 
 
@@ -369,12 +370,15 @@ def main():
     # Each profiled pass is enqueued BEHIND ~2 ms of memsets: the Python interpreter needs about as long to launch a step
     # as the GPU needs to run it, and a GPU that waits for the host would bill the wait to the layer.  With the queue
     # pre-filled the events bracket back-to-back kernels (what the captured graph replays).
+    # Every step is launched PROF_REPEAT times between its two markers: a marker alone costs ~5 us of stream time (the
+    # `flatten` / `return` steps, which launch nothing, show it), more than the small kernels it is meant to time.
     blocker = planer_amd.hip.empty((256 << 20,), np.float32, ctx)          # 1 GiB
+    prof_steps = max(3, prof_steps // 4)
     for it in range(prof_steps + 2):
         xin = xs[it & 1].copy()
         for _ in range(8):
             planer_amd._lib.call("pl_memset", ctx.handle, blocker.ptr, 0, blocker.nbytes)
-        net._interpret(prog, [xin], profile=True)
+        net._interpret(prog, [xin], profile=True, repeat=PROF_REPEAT)
         if it >= 2:
             for name, kind, ms in net.last_events:
                 per_layer.setdefault((name, kind), []).append(ms)
@@ -469,7 +473,7 @@ def main():
         "bound": "mfma",
         "kernel": dom_name,
         "definition": "dominant = the conv kernel family with the largest summed device time in one forward (HIP events, "
-                      "single stream, %d passes); achieved/frac count the MFMA FLOPs the kernel EXECUTES (tile, K-chunk and "
+                      "single stream, %d passes x 10 launches per step); achieved/frac count the MFMA FLOPs the kernel EXECUTES (tile, K-chunk and "
                       "Winograd-tile padding included), effective_* count the direct algorithm's FLOPs" % prof_steps,
         "launches_per_forward": dom["launches"], "kernel_steps_per_forward": dom["steps"],
         "unit_of_a_launch": "one convolution of the family = all of its kernels (Winograd: transforms + 36 grouped GEMMs)",

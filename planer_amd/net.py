@@ -289,9 +289,11 @@ class Net:
         return obj.shape if hasattr(obj, "shape") else obj
 
     # ---- eager interpreter ---------------------------------------------------------
-    def _interpret(self, prog, xs, debug=False, shapes=None, profile=False, record=None):
+    def _interpret(self, prog, xs, debug=False, shapes=None, profile=False, record=None, repeat=1):
         """net.py:37-72: one kernel launch (or view) per layer, in flow order.  `record` (a list)
-        receives one dict per convolution / dense step: which kernel family and launch plan ran."""
+        receives one dict per convolution / dense step: which kernel family and launch plan ran.  `profile` brackets the
+        steps with stream markers; with `repeat` = R > 1 every step is launched R times between its markers (the time per
+        launch is what gets recorded: a marker costs about as much as a small kernel, R launches dilute it)."""
         env = {"None": None}
         env.update(zip(self.inits, self.weights))
         env.update(self._extra)
@@ -309,11 +311,13 @@ class Net:
                     print(name, obj.name, ":", obj.para())
                     print("\t--> ", keys, ":", self.info(args))
                 t0 = time.time()
-                if profile:
-                    e0 = hip.Event(self.ctx).record()
+                if profile and not events:
+                    events.append((None, None, hip.Event(self.ctx).record()))
                 val = obj(*args)
-                if profile:
-                    events.append((name, obj.name, e0, hip.Event(self.ctx).record()))
+                for _ in range(repeat - 1 if profile else 0):
+                    val = obj(*args)
+                if profile:                                  # ONE marker per step boundary: step time = marker to marker
+                    events.append((name, obj.name, hip.Event(self.ctx).record()))
                 if record is not None and obj.name in ("conv", "conv_fused", "conv_q4", "dense", "matmul", "wino4_gemm", "conv_q4_pair"):
                     lay = obj.para().get("w_layout", 2 if obj.name == "conv_q4_pair" else 0) if obj.name != "conv" else 0
                     lname = name
@@ -341,8 +345,8 @@ class Net:
             out_key = dst
         if profile:
             self.last_events = []
-            for name, kind, e0, e1 in events:
-                ms = e0.elapsed_ms(e1)
+            for (_, _, e0), (name, kind, e1) in zip(events, events[1:]):
+                ms = e0.elapsed_ms(e1) / max(1, repeat)
                 self.last_events.append((name, kind, ms))
                 self.device_timer[kind] = self.device_timer.get(kind, 0.0) + ms
         return env[out_key]
