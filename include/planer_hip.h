@@ -355,6 +355,22 @@ int pl_unary_f32(pl_ctx *ctx, const float *x, float *y, size_t n, int op, double
  * 1 one value per channel (C), 2 a single value. */
 int pl_binary_f32(pl_ctx *ctx, const float *a, const float *b, float *y, int outer, int C,
                   int inner, int op, int a_mode, int b_mode);
+/* Add/Sub/Mul/Div/Pow under general numpy broadcasting (layer.py:93-111): `shape` is the
+ * broadcast result (1..6 axes), a_stride / b_stride the operands' element strides per
+ * result axis, 0 where the operand is broadcast.  op as in pl_binary_f32. */
+int pl_binary_bcast_f32(pl_ctx *ctx, const float *a, const float *b, float *y, int ndim,
+                        const int *shape, const long long *a_stride, const long long *b_stride,
+                        int op);
+/* layer.UpSample / Resize, mode "linear", integer factors (util.py:121-153
+ * make_upmat + upsample_blinear): `weights` is a HOST table of terms x fh x fw floats
+ * (terms = 4 when both factors exceed 1: lt, rt, lb, rb; else 2), fh * fw <= 64. */
+int pl_upsample_linear_f32(pl_ctx *ctx, const float *x, float *y, int NC, int H, int W, int fh,
+                           int fw, const float *weights);
+/* layer.UpSample / Resize, mode "linear", fractional factors (util.py:194-219
+ * upsample_size) on (NC, H, W) planes: ra/ca = lower sample row / column per output
+ * row / column, rs/cs = the fractions (device arrays), columns first then rows. */
+int pl_resize_linear_f32(pl_ctx *ctx, const float *x, float *y, int NC, int H, int W, int OH,
+                         int OW, const int *ra, const float *rs, const int *ca, const float *cs);
 /* Softmax / LogSoftmax over the last axis (layer.py:141-153) */
 int pl_softmax_f32(pl_ctx *ctx, const float *x, float *y, int rows, int cols, int log_softmax);
 /* ReduceSum/Mean/Max/Min over the trailing `cols` elements (layer.py:113-123): op 0..3 */

@@ -187,15 +187,84 @@ def gap(x):
     return x.mean(axis=(-2, -1), keepdims=True)
 
 
+def _bilinear_table(fh, fw):
+    """util.make_upmat (util.py:121-132): float16 sample fractions linspace(0.5/k, 1-0.5/k, k) per axis and
+    the corner weights as float16 products, rows = (left-top, right-top, left-bottom, right-bottom); with a
+    factor of 1 on one axis the two weights of the other axis."""
+    fy = np.linspace(0.5 / fh, 1 - 0.5 / fh, fh, dtype=np.float16)
+    fx = np.linspace(0.5 / fw, 1 - 0.5 / fw, fw, dtype=np.float16)
+    if fh == 1:
+        return np.vstack([1 - fx, fx])
+    if fw == 1:
+        return np.vstack([1 - fy, fy])
+    ry, rx = fy[:, None], fx[None, :]
+    return np.vstack([((1 - rx) * (1 - ry)).reshape(1, -1), (rx * (1 - ry)).reshape(1, -1),
+                      ((1 - rx) * ry).reshape(1, -1), (rx * ry).reshape(1, -1)])
+
+
+def upsample_bilinear(x, fh, fw):
+    """util.upsample_blinear (util.py:134-153): replicate the border by one pixel along every scaled axis, take
+    every 2 x 2 (or 1 x 2 / 2 x 1) neighbourhood times the weight table (a float32 x float16 matmul), interleave
+    the fh x fw blocks and crop fh//2, fw//2."""
+    n, c, h, w = x.shape
+    if fh == 1 and fw == 1:
+        return x
+    p = x
+    if fh > 1:
+        p = np.concatenate([p[:, :, :1], p, p[:, :, -1:]], axis=2)
+    if fw > 1:
+        p = np.concatenate([p[:, :, :, :1], p, p[:, :, :, -1:]], axis=3)
+    if fh == 1:
+        corners = [p[:, :, :, :-1], p[:, :, :, 1:]]
+    elif fw == 1:
+        corners = [p[:, :, :-1, :], p[:, :, 1:, :]]
+    else:
+        corners = [p[:, :, :-1, :-1], p[:, :, :-1, 1:], p[:, :, 1:, :-1], p[:, :, 1:, 1:]]
+    field = np.stack(corners, axis=-1)
+    hh, ww = h + (fh > 1), w + (fw > 1)
+    blocks = np.matmul(field.reshape(-1, len(corners)), _bilinear_table(fh, fw))
+    out = blocks.reshape(-1, ww, fh, fw).transpose(0, 2, 1, 3).reshape(n, c, hh * fh, ww * fw)
+    return out[:, :, fh // 2:h * fh + fh // 2, fw // 2:w * fw + fw // 2]
+
+
+def upsample_to_size(x, size):
+    """util.upsample_size (util.py:194-210): separable bilinear at sample positions linspace(-0.5+0.5/k,
+    n-0.5-0.5/k, size) in the image's dtype, clipped to the map; columns first, then rows."""
+    lead, (h, w) = x.shape[:-2], x.shape[-2:]
+    def axis(n, m):
+        k = m / n
+        pos = np.linspace(-0.5 + 0.5 / k, n - 0.5 - 0.5 / k, m, dtype=x.dtype)
+        pos = np.clip(pos, 0, n - 1, out=pos)
+        lo = np.floor(np.clip(pos, 0, n - 1.001)).astype(int)
+        pos -= lo
+        return lo, pos
+    ra, rs = axis(h, size[0])
+    ca, cs = axis(w, size[1])
+    planes = x.reshape(-1, h, w)
+    cols = planes[:, :, ca] * (1 - cs) + planes[:, :, ca + 1] * cs
+    rs = rs.reshape(-1, 1)
+    out = cols[:, ra, :] * (1 - rs) + cols[:, ra + 1, :] * rs
+    return out.reshape(lead + tuple(size))
+
+
+def _upsample_any(x, k, mode):
+    """util.upsample (util.py:212-219), the dispatch on `mode` and on whole-number factors."""
+    if mode == "linear":
+        if k[0] == int(k[0]) and k[1] == int(k[1]):
+            return upsample_bilinear(x, int(k[0]), int(k[1]))
+        return upsample_to_size(x, (int(round(k[0] * x.shape[2])), int(round(k[1] * x.shape[3]))))
+    raise NotImplementedError("oracle covers nearest and linear")
+
+
 def upsample(x, k, mode="nearest"):
     """layer.UpSample (layer.py:80-82) -> util.upsample_nearest
     (util.py:184-192).  `k` is a tensor whose last two entries are the integer
-    H/W factors.  With UpSample's defaults util.offset() yields shift 0
+    H/W factors (truncated, layer.py:82).  With UpSample's defaults util.offset() yields shift 0
     (util.py:212 passes the misspelt 'half-pixcel', so no transform applies),
-    i.e. plain block replication."""
-    if mode != "nearest":
-        raise NotImplementedError("oracle covers nearest only (hot path)")
+    i.e. plain block replication.  mode "linear": util.upsample_blinear."""
     fh, fw = [int(v) for v in np.asarray(k)[-2:].astype(int).tolist()]
+    if mode != "nearest":
+        return _upsample_any(x, [fh, fw], mode)
     n, c, h, w = x.shape
     out = np.empty((n, c, h * fh, w * fw), dtype=x.dtype)
     for r in range(fh):
@@ -294,13 +363,16 @@ def unsqueeze(x, axes=None):
 
 def resize(x, roi, k, size=None, mode="nearest", coordinate_transformation_mode="half_pixel",
            nearest_mode="round_prefer_floor"):
-    """layer.Resize (layer.py:84-88), nearest; for the two mode pairs util.offset()
-    (util.py:155-170) maps to a zero shift this is plain replication like UpSample."""
+    """layer.Resize (layer.py:84-88).  Nearest: for the two mode pairs util.offset()
+    (util.py:155-170) maps to a zero shift this is plain replication like UpSample.  Linear: the two mode
+    arguments are not looked at (util.py:216-218)."""
+    if k.size == 0:
+        k = size[-2:] / np.array(x.shape[-2:])
+    if mode == "linear":
+        return _upsample_any(x, np.asarray(k)[-2:].tolist(), mode)
     if mode != "nearest" or (coordinate_transformation_mode, nearest_mode) not in (
             ("half_pixel", "round_prefer_floor"), ("asymmetric", "floor")):
         raise NotImplementedError("oracle covers the zero-shift nearest modes only")
-    if k.size == 0:
-        k = size[-2:] / np.array(x.shape[-2:])
     return upsample(x, np.asarray(k)[-2:], "nearest")
 
 

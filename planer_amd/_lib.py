@@ -116,6 +116,9 @@ SIGNATURES = {
     "pl_gap_f32": [_P, _P, _P, _I, _I],
     "pl_unary_f32": [_P, _P, _P, _Z, _I, c_double, c_double],
     "pl_binary_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I],
+    "pl_binary_bcast_f32": [_P, _P, _P, _P, _I, POINTER(c_int), POINTER(ctypes.c_longlong), POINTER(ctypes.c_longlong), _I],
+    "pl_upsample_linear_f32": [_P, _P, _P, _I, _I, _I, _I, _I, POINTER(ctypes.c_float)],
+    "pl_resize_linear_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "pl_softmax_f32": [_P, _P, _P, _I, _I, _I],
     "pl_reduce_f32": [_P, _P, _P, _I, _I, _I],
     "pl_transpose_f32": [_P, _P, _P, _I, POINTER(c_int), POINTER(c_int)],

@@ -467,6 +467,101 @@ __global__ void __launch_bounds__(TPB) binary_kernel(const float *a, const float
     }
 }
 
+// y = a (op) b under numpy broadcasting (layer.py:93-111): the result's index, axis by axis, addresses each operand
+// through its own strides -- 0 on an axis the operand is broadcast over.
+struct BcastArgs {
+    int ndim;
+    unsigned shape[6];
+    long long sa[6], sb[6];
+};
+
+__global__ void __launch_bounds__(TPB) binary_bcast_kernel(const float *a, const float *b, float *y, size_t n, int op,
+                                                           BcastArgs p) {
+    size_t stride = (size_t)gridDim.x * TPB;
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n; i += stride) {
+        unsigned rem = (unsigned)i;
+        long long ia = 0, ib = 0;
+        for (int d = p.ndim - 1; d >= 0; --d) {
+            const unsigned q = rem / p.shape[d], t = rem - q * p.shape[d];
+            rem = q;
+            ia += (long long)t * p.sa[d];
+            ib += (long long)t * p.sb[d];
+        }
+        y[i] = bin_op(op, a[ia], b[ib]);
+    }
+}
+
+// layer.UpSample / Resize, mode "linear", integer factors (util.py:121-153 upsample_blinear): the map is
+// edge-replicated by one pixel, every 2 x 2 neighbourhood (i, j) of it yields an fh x fw block
+//   lt*w[0][a][b] + rt*w[1][a][b] + lb*w[2][a][b] + rb*w[3][a][b]
+// and the result is that field cropped by fh/2, fw/2.  The weights are the reference's float16 table, handed in
+// by the host as floats.  With a factor of 1 on one axis only the other axis is interpolated (two terms).
+struct UpLinArgs {
+    int H, W, fh, fw, terms;   // terms: 4 both axes, 2 one axis
+    float w[4 * 64];
+};
+
+__global__ void __launch_bounds__(TPB) upsample_linear_kernel(const float *x, float *y, unsigned total, UpLinArgs p,
+                                                              FastDiv divOW, FastDiv divOH) {
+    const unsigned stride = gridDim.x * TPB;
+    const int kk = p.fh * p.fw;
+    for (unsigned i = blockIdx.x * TPB + threadIdx.x; i < total; i += stride) {
+        unsigned row, ox, plane, oy;
+        divOW.divmod(i, row, ox);
+        divOH.divmod(row, plane, oy);
+        const float *xp = x + (size_t)plane * p.H * p.W;
+        int r0 = (int)oy, r1 = (int)oy, a = 0, c0 = (int)ox, c1 = (int)ox, b = 0;
+        if (p.fh > 1) {
+            const int Y = (int)oy + p.fh / 2, q = Y / p.fh;
+            a = Y - q * p.fh;
+            r0 = max(q - 1, 0);
+            r1 = min(q, p.H - 1);
+        }
+        if (p.fw > 1) {
+            const int X = (int)ox + p.fw / 2, q = X / p.fw;
+            b = X - q * p.fw;
+            c0 = max(q - 1, 0);
+            c1 = min(q, p.W - 1);
+        }
+        const float *w = p.w + a * p.fw + b;
+        float v;
+        if (p.terms == 4) {
+            v = __fmul_rn(xp[(size_t)r0 * p.W + c0], w[0]);
+            v = __fmaf_rn(xp[(size_t)r0 * p.W + c1], w[kk], v);
+            v = __fmaf_rn(xp[(size_t)r1 * p.W + c0], w[2 * kk], v);
+            v = __fmaf_rn(xp[(size_t)r1 * p.W + c1], w[3 * kk], v);
+        } else if (p.fw > 1) {
+            v = __fmul_rn(xp[(size_t)r0 * p.W + c0], w[0]);
+            v = __fmaf_rn(xp[(size_t)r0 * p.W + c1], w[kk], v);
+        } else {
+            v = __fmul_rn(xp[(size_t)r0 * p.W + c0], w[0]);
+            v = __fmaf_rn(xp[(size_t)r1 * p.W + c0], w[kk], v);
+        }
+        y[i] = v;
+    }
+}
+
+// layer.UpSample / Resize, mode "linear", fractional factors (util.py:194-219 upsample_size) on (planes, H, W):
+// columns first, a*(1-cs) + b*cs, then rows on those -- the reference's order of roundings.  Sample positions
+// come from the host (float32 linspace, clip, floor).
+__global__ void __launch_bounds__(TPB) resize_planes_kernel(const float *x, float *y, unsigned total, int H, int W,
+                                                            const int *ra, const float *rs, const int *ca,
+                                                            const float *cs, FastDiv divOW, FastDiv divOH) {
+    const unsigned stride = gridDim.x * TPB;
+    for (unsigned i = blockIdx.x * TPB + threadIdx.x; i < total; i += stride) {
+        unsigned row, ox, plane, oy;
+        divOW.divmod(i, row, ox);
+        divOH.divmod(row, plane, oy);
+        const int r0 = ra[oy], c0 = ca[ox];
+        const float fr = rs[oy], fc = cs[ox];
+        const float gc = __fsub_rn(1.f, fc), gr = __fsub_rn(1.f, fr);
+        const float *p0 = x + ((size_t)plane * H + r0) * W + c0, *p1 = p0 + W;
+        const float top = __fadd_rn(__fmul_rn(p0[0], gc), __fmul_rn(p0[1], fc));
+        const float bot = __fadd_rn(__fmul_rn(p1[0], gc), __fmul_rn(p1[1], fc));
+        y[i] = __fadd_rn(__fmul_rn(top, gr), __fmul_rn(bot, fr));
+    }
+}
+
 // softmax / logsoftmax over the last axis, one wave64 per row (layer.py:141-153):
 // y = x - max; s = sum(exp(y)); out = exp(y - log s)  (or y - log s)
 __global__ void __launch_bounds__(TPB) softmax_kernel(const float *x, float *y, int rows, int cols, int logmode) {
@@ -698,6 +793,64 @@ int pl_binary_f32(pl_ctx *ctx, const float *a, const float *b, float *y, int out
     CtxGuard g(ctx);
     binary_kernel<<<stream_grid(ctx, n), TPB, 0, ctx->stream>>>(a, b, y, n, C, op, a_mode, b_mode, FastDiv(inner),
                                                               FastDiv(C));
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
+
+int pl_binary_bcast_f32(pl_ctx *ctx, const float *a, const float *b, float *y, int ndim, const int *shape,
+                        const long long *a_stride, const long long *b_stride, int op) {
+    PL_REQUIRE(ctx && shape && a_stride && b_stride, PL_EINVAL, "pl_binary_bcast_f32: null argument");
+    PL_REQUIRE(ndim >= 1 && ndim <= 6, PL_EUNSUPPORTED, "pl_binary_bcast_f32: 1..6 axes supported, got %d", ndim);
+    PL_REQUIRE(op >= 0 && op <= 4, PL_EINVAL, "pl_binary_bcast_f32: bad op %d", op);
+    BcastArgs p;
+    p.ndim = ndim;
+    size_t n = 1;
+    for (int d = 0; d < ndim; ++d) {
+        PL_REQUIRE(shape[d] >= 0 && a_stride[d] >= 0 && b_stride[d] >= 0, PL_EINVAL, "pl_binary_bcast_f32: bad axis %d", d);
+        p.shape[d] = (unsigned)shape[d];
+        p.sa[d] = a_stride[d];
+        p.sb[d] = b_stride[d];
+        n *= (size_t)shape[d];
+    }
+    if (!n) return PL_OK;
+    PL_REQUIRE(a && b && y, PL_EINVAL, "pl_binary_bcast_f32: null tensor");
+    PL_REQUIRE(n < (1ull << 32), PL_EUNSUPPORTED, "binary op: tensor too large");
+    CtxGuard g(ctx);
+    binary_bcast_kernel<<<stream_grid(ctx, n), TPB, 0, ctx->stream>>>(a, b, y, n, op, p);
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
+
+int pl_upsample_linear_f32(pl_ctx *ctx, const float *x, float *y, int NC, int H, int W, int fh, int fw,
+                           const float *weights) {
+    PL_REQUIRE(ctx && x && y && weights, PL_EINVAL, "pl_upsample_linear_f32: null argument");
+    PL_REQUIRE(NC >= 0 && H > 0 && W > 0 && fh > 0 && fw > 0, PL_EINVAL, "pl_upsample_linear_f32: bad shape");
+    PL_REQUIRE(fh * fw > 1, PL_EINVAL, "pl_upsample_linear_f32: factors 1 x 1 are the identity");
+    PL_REQUIRE(fh * fw <= 64, PL_EUNSUPPORTED, "pl_upsample_linear_f32: fh * fw <= 64 supported, got %d", fh * fw);
+    const size_t total = (size_t)NC * H * fh * W * fw;
+    if (!total) return PL_OK;
+    PL_REQUIRE(total < (1ull << 32), PL_EUNSUPPORTED, "upsample: tensor too large");
+    UpLinArgs p;
+    p.H = H; p.W = W; p.fh = fh; p.fw = fw;
+    p.terms = (fh > 1 && fw > 1) ? 4 : 2;
+    for (int i = 0; i < 4 * 64; ++i) p.w[i] = i < p.terms * fh * fw ? weights[i] : 0.f;
+    CtxGuard g(ctx);
+    upsample_linear_kernel<<<stream_grid(ctx, total), TPB, 0, ctx->stream>>>(x, y, (unsigned)total, p, FastDiv(W * fw),
+                                                                         FastDiv(H * fh));
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
+
+int pl_resize_linear_f32(pl_ctx *ctx, const float *x, float *y, int NC, int H, int W, int OH, int OW, const int *ra,
+                         const float *rs, const int *ca, const float *cs) {
+    PL_REQUIRE(ctx && x && y && ra && rs && ca && cs, PL_EINVAL, "pl_resize_linear_f32: null argument");
+    PL_REQUIRE(NC >= 0 && H > 1 && W > 1 && OH > 0 && OW > 0, PL_EINVAL, "pl_resize_linear_f32: bad shape (needs H, W >= 2)");
+    const size_t total = (size_t)NC * OH * OW;
+    if (!total) return PL_OK;
+    PL_REQUIRE(total < (1ull << 32) && (size_t)NC * H * W < (1ull << 32), PL_EUNSUPPORTED, "resize: tensor too large");
+    CtxGuard g(ctx);
+    resize_planes_kernel<<<stream_grid(ctx, total), TPB, 0, ctx->stream>>>(x, y, (unsigned)total, H, W, ra, rs, ca, cs,
+                                                                       FastDiv(OW), FastDiv(OH));
     PL_LAUNCH_CHECK();
     return PL_OK;
 }

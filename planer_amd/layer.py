@@ -214,8 +214,8 @@ def Sigmoid(x):
 
 
 def Add(x1, x2):
-    """layer.Add (layer.py:93-95): same shape, or a (1|N,C,1,1) operand
-    broadcast over the other (the two forms planer graphs contain)."""
+    """layer.Add (layer.py:93-95): same shape or a (1|N,C,1,1) operand broadcast over the other (the two
+    forms planer graphs contain) on their own kernels, any other numpy-broadcastable pair through `_binary`."""
     _f32(x1, x2)
     if x1.shape == x2.shape:
         y = empty(x1.shape, ctx=x1.ctx)
@@ -266,16 +266,71 @@ def GlobalAveragePool(x):
     return y
 
 
+def _linear_weights(fh, fw):
+    """The float16 interpolation table of util.make_upmat (util.py:121-132) as float32, laid out
+    (terms, fh, fw): sample fractions are a float16 linspace over (0.5/k, 1 - 0.5/k), the four corner weights
+    their float16 products; with a factor of 1 on one axis only the other axis' two weights remain."""
+    fy = numpy.linspace(0.5 / fh, 1 - 0.5 / fh, fh, dtype=numpy.float16)
+    fx = numpy.linspace(0.5 / fw, 1 - 0.5 / fw, fw, dtype=numpy.float16)
+    if fh == 1:
+        tab = numpy.stack([1 - fx, fx])
+    elif fw == 1:
+        tab = numpy.stack([1 - fy, fy])
+    else:
+        gy, gx = (1 - fy)[:, None], (1 - fx)[None, :]
+        tab = numpy.stack([gx * gy, fx[None, :] * gy, gx * fy[:, None], fx[None, :] * fy[:, None]])
+    return numpy.ascontiguousarray(tab.reshape(tab.shape[0], -1), dtype=numpy.float32)
+
+
+def _linear_positions(n, size, dtype=numpy.float32):
+    """Sample positions of util.upsample_size along one axis (util.py:200-210): linspace in the image's dtype,
+    clip, floor of the clipped-below-the-last-pixel position -> (lower index int32, fraction float32)."""
+    k = size / n
+    pos = numpy.linspace(-0.5 + 0.5 / k, n - 0.5 - 0.5 / k, size, dtype=dtype)
+    pos = numpy.clip(pos, 0, n - 1, out=pos)
+    lo = numpy.floor(numpy.clip(pos, 0, n - 1.001)).astype(int)
+    pos -= lo
+    return lo.astype(numpy.int32), pos
+
+
+def _upsample_linear(x, fh, fw):
+    """util.upsample, mode "linear" (util.py:212-219): integer factors -> upsample_blinear, anything else ->
+    upsample_size at round(k * size)."""
+    n, c, h, w = x.shape
+    if fh == int(fh) and fw == int(fw):
+        fh, fw = int(fh), int(fw)
+        if fh == 1 and fw == 1:
+            return x
+        y = empty((n, c, h * fh, w * fw), ctx=x.ctx)
+        if fh * fw > 64:
+            raise NotImplementedError("linear upsample: fh * fw <= 64 on the HIP path, got %d x %d" % (fh, fw))
+        tab = _linear_weights(fh, fw)
+        _lib.call("pl_upsample_linear_f32", x.ctx.handle, x.ptr, y.ptr, n * c, h, w, fh, fw,
+                  tab.ctypes.data_as(_lib.POINTER(_lib.c_float)))
+        return y
+    oh, ow = int(round(fh * h)), int(round(fw * w))
+    if h < 2 or w < 2:
+        raise ValueError("linear resize needs at least 2 x 2 pixels (the reference indexes row / column + 1)")
+    ra, rs = _linear_positions(h, oh)
+    ca, cs = _linear_positions(w, ow)
+    dev = [asarray(a, ctx=x.ctx) for a in (ra, rs, ca, cs)]
+    y = empty((n, c, oh, ow), ctx=x.ctx)
+    _lib.call("pl_resize_linear_f32", x.ctx.handle, x.ptr, y.ptr, n * c, h, w, oh, ow, *[d.ptr for d in dev])
+    return y
+
+
 def UpSample(x, k, mode="nearest"):
-    """layer.UpSample (layer.py:80-82): nearest-neighbour integer up-scaling,
+    """layer.UpSample (layer.py:80-82): nearest-neighbour integer up-scaling or bilinear ("linear"),
     factors = last two entries of the tensor `k`."""
     _f32(x)
-    if mode != "nearest":
+    if mode not in ("nearest", "linear"):
         raise NotImplementedError("upsample mode %r is not on the HIP path" % mode)
     kv = _host_values(k)
     if kv.size == 0:
         raise ValueError("upsample needs scales (the reference's size-only branch is broken, layer.py:81)")
-    fh, fw = [int(v) for v in kv[-2:].astype(int).tolist()]
+    fh, fw = [int(v) for v in kv[-2:].astype(int).tolist()]       # truncated, layer.py:82
+    if mode == "linear":
+        return _upsample_linear(x, fh, fw)
     n, c, h, w = x.shape
     y = empty((n, c, h * fh, w * fw), ctx=x.ctx)
     _lib.call("pl_upsample_nearest_f32", x.ctx.handle, x.ptr, y.ptr, n * c, h, w, fh, fw)
@@ -320,8 +375,9 @@ def Return(*x):
 
 # ---- second-wave operators -----------------------------------------
 def _broadcast_modes(x1, x2):
-    """-> (out_shape, outer, C, inner, mode1, mode2) for the broadcast forms planer graphs use:
-    equal shapes, a one-element operand, or a (1|-,C,1,...) per-channel operand."""
+    """-> (out_shape, outer, C, inner, mode1, mode2) for the broadcast forms planer graphs use most:
+    equal shapes, a one-element operand, or a (1|-,C,1,...) per-channel operand; None for any other
+    pair (general numpy broadcasting, `_binary_general`)."""
     def mode(a, ref):
         if a.shape == ref.shape:
             return 0
@@ -331,18 +387,55 @@ def _broadcast_modes(x1, x2):
         shp = (1,) * (nd - a.ndim) + a.shape
         if nd >= 2 and len(shp) == nd and shp[1] == ref.shape[1] and a.size == ref.shape[1]:
             return 1
-        raise NotImplementedError("broadcast %s with %s is not on the HIP path" % (a.shape, ref.shape))
+        return None
     ref = x1 if x1.size >= x2.size else x2
+    if tuple(numpy.broadcast_shapes(tuple(x1.shape), tuple(x2.shape))) != tuple(ref.shape):
+        return None
     m1, m2 = mode(x1, ref), mode(x2, ref)
+    if m1 is None or m2 is None:
+        return None
     c = ref.shape[1] if ref.ndim >= 2 else 1
     outer = ref.shape[0] if ref.ndim >= 2 else 1
     inner = ref.size // (outer * c) if ref.size else 1
     return ref.shape, outer, c, max(inner, 1), m1, m2
 
 
+def _binary_general(x1, x2, op):
+    """x1 (op) x2 under numpy's broadcasting rules (layer.py:93-111 rely on them): result axes that both
+    operands walk the same way are merged, what is left must fit pl_binary_bcast_f32's six axes."""
+    out = tuple(numpy.broadcast_shapes(tuple(x1.shape), tuple(x2.shape)))     # raises ValueError like numpy
+    nd = len(out)
+    y = empty(out, ctx=x1.ctx)
+    if not y.size:
+        return y
+    def strides(a):
+        shp = (1,) * (nd - a.ndim) + tuple(a.shape)
+        st = _contig_strides(shp)
+        return [0 if shp[d] == 1 else st[d] for d in range(nd)]
+    sa, sb = strides(x1), strides(x2)
+    dims = [[out[d], sa[d], sb[d]] for d in range(nd) if out[d] != 1] or [[1, 0, 0]]
+    merged = [dims[0]]
+    for n, a, b in dims[1:]:
+        m = merged[-1]
+        if m[1] == a * n and m[2] == b * n:       # the outer axis steps over exactly the inner one's extent
+            merged[-1] = [m[0] * n, a, b]
+        else:
+            merged.append([n, a, b])
+    if len(merged) > 6:
+        raise NotImplementedError("broadcast %s with %s needs more than 6 axes on the HIP path" % (x1.shape, x2.shape))
+    k = len(merged)
+    _lib.call("pl_binary_bcast_f32", x1.ctx.handle, x1.ptr, x2.ptr, y.ptr, k,
+              (_lib.c_int * k)(*[m[0] for m in merged]), (_lib.c_longlong * k)(*[m[1] for m in merged]),
+              (_lib.c_longlong * k)(*[m[2] for m in merged]), op)
+    return y
+
+
 def _binary(x1, x2, op):
     _f32(x1, x2)
-    shape, outer, c, inner, m1, m2 = _broadcast_modes(x1, x2)
+    forms = _broadcast_modes(x1, x2)
+    if forms is None:
+        return _binary_general(x1, x2, op)
+    shape, outer, c, inner, m1, m2 = forms
     y = empty(shape, ctx=x1.ctx)
     if y.size:
         _lib.call("pl_binary_f32", x1.ctx.handle, x1.ptr, x2.ptr, y.ptr, outer, c, inner, op, m1, m2)
@@ -516,19 +609,22 @@ def Unsqueeze(x, axes=None):
 
 def Resize(x, roi, k, size=None, mode="nearest", coordinate_transformation_mode="half_pixel",
            nearest_mode="round_prefer_floor"):
-    """layer.Resize (layer.py:84-88), nearest with integer scales.  The two mode pairs that
-    util.offset() maps to plain replication are supported; the shifting
-    (asymmetric, ceil) variant and linear modes are not on the HIP path."""
-    if mode != "nearest":
+    """layer.Resize (layer.py:84-88).  Nearest with integer scales: the two mode pairs that util.offset()
+    maps to plain replication; the shifting (asymmetric, ceil) variant is not on the HIP
+    path.  Linear: the reference ignores the two mode arguments (util.py:212-219), so does this."""
+    if mode not in ("nearest", "linear"):
         raise NotImplementedError("resize mode %r is not on the HIP path" % mode)
-    if (coordinate_transformation_mode, nearest_mode) not in (("half_pixel", "round_prefer_floor"),
-                                                              ("asymmetric", "floor")):
-        raise NotImplementedError("resize %s/%s is not on the HIP path" % (coordinate_transformation_mode, nearest_mode))
     kv = _host_values(k)
     if kv.size == 0:
         sz = _host_values(size)
         kv = sz[-2:] / numpy.array(x.shape[-2:])
     fh, fw = [float(v) for v in kv[-2:].tolist()]
+    if mode == "linear":
+        _f32(x)
+        return _upsample_linear(x, fh, fw)
+    if (coordinate_transformation_mode, nearest_mode) not in (("half_pixel", "round_prefer_floor"),
+                                                              ("asymmetric", "floor")):
+        raise NotImplementedError("resize %s/%s is not on the HIP path" % (coordinate_transformation_mode, nearest_mode))
     if fh != int(fh) or fw != int(fw) or fh < 1 or fw < 1:
         raise NotImplementedError("resize: only integer up-scaling is on the HIP path")
     return UpSample(x, numpy.array([1, 1, fh, fw], numpy.float32))

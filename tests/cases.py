@@ -98,6 +98,27 @@ def layer_cases():
     c.append(("resize_asym_floor", "resize", [_r(461, 1, 2, 4, 4), np.zeros(0, np.float32),
                                               np.array([1, 1, 3, 2], np.float32)],
               {"mode": "nearest", "coordinate_transformation_mode": "asymmetric", "nearest_mode": "floor"}))
+    # ---- general numpy broadcasting (layer.py:93-111) and linear up-sampling (util.py:121-153, 194-219) ----
+    c.append(("add_bcast_rows", "add", [_r(470, 2, 3, 4, 5), _r(471, 4, 1)], {}))
+    c.append(("sub_bcast_outer", "sub", [_r(472, 3, 1), _r(473, 1, 4)], {}))
+    c.append(("mul_bcast_cross", "mul", [_r(474, 2, 1, 4, 1), _r(475, 1, 3, 1, 5)], {}))
+    c.append(("div_bcast_lower_rank_lhs", "div", [_r(476, 5), np.abs(_r(477, 2, 3, 4, 5)) + 0.5], {}))
+    c.append(("add_bcast_batch", "add", [_r(478, 1, 6, 5, 7), _r(479, 3, 1, 5, 1)], {}))
+    c.append(("mul_bcast_spatial", "mul", [_r(480, 2, 6, 5, 7), _r(481, 2, 1, 5, 7)], {}))
+    c.append(("pow_bcast_rows", "pow", [np.abs(_r(482, 2, 3, 4)) + 0.1, _r(483, 3, 1)], {}))
+    c.append(("upsample_linear_x2", "upsample", [_r(484, 2, 3, 5, 6), np.array([1, 1, 2, 2], np.float32)], {"mode": "linear"}))
+    c.append(("upsample_linear_3x2", "upsample", [_r(485, 1, 2, 4, 7), np.array([1, 1, 3, 2], np.float32)], {"mode": "linear"}))
+    c.append(("upsample_linear_1x2", "upsample", [_r(486, 1, 2, 4, 5), np.array([1, 1, 1, 2], np.float32)], {"mode": "linear"}))
+    c.append(("upsample_linear_4x1", "upsample", [_r(487, 2, 2, 3, 5), np.array([1, 1, 4, 1], np.float32)], {"mode": "linear"}))
+    c.append(("upsample_linear_trunc", "upsample", [_r(488, 1, 2, 4, 5), np.array([1, 1, 2.7, 2.2], np.float32)], {"mode": "linear"}))
+    c.append(("resize_linear_x2", "resize", [_r(489, 2, 3, 5, 6), np.zeros(0, np.float32),
+                                             np.array([1, 1, 2, 2], np.float32)], {"mode": "linear"}))
+    c.append(("resize_linear_frac", "resize", [_r(490, 2, 3, 6, 8), np.zeros(0, np.float32),
+                                               np.array([1, 1, 1.5, 2.25], np.float32)], {"mode": "linear"}))
+    c.append(("resize_linear_down", "resize", [_r(491, 1, 2, 9, 11), np.zeros(0, np.float32),
+                                               np.array([1, 1, 0.5, 0.7], np.float32)], {"mode": "linear"}))
+    c.append(("resize_linear_size", "resize", [_r(492, 1, 3, 5, 7), np.zeros(0, np.float32), np.zeros(0, np.float32),
+                                               np.array([1, 3, 13, 10], np.int64)], {"mode": "linear"}))
     # ---- structural ops on the strided-map kernel + ConvTranspose2d ----
     i64 = lambda *v: np.array(v, np.int64)
     c.append(("slice_basic", "slice", [_r(500, 2, 6, 9, 11), i64(1, 2), i64(5, 9), i64(1, 3), i64(1, 1)], {}))

@@ -53,7 +53,8 @@ EXACT = ["relu", "leakyrelu_0.1", "leakyrelu_default", "add", "batchnorm", "maxp
          "where", "where_scalar_rhs", "constantofshape_f32", "constantofshape_i64", "erf", "concat_shape_tensors",
          "mul_shape_tensors", "scatternd_rows", "scatternd_elements", "nonzero_f32", "nonzero_bool", "nonzero_none",
          "nonzero_i64_1d", "topk_last", "topk_axis1", "topk_smallest_quirk", "topk_yolo_candidates", "topk_long_row",
-         "topk_long_row_smallest"]
+         "topk_long_row_smallest", "add_bcast_rows", "sub_bcast_outer", "mul_bcast_cross", "div_bcast_lower_rank_lhs",
+         "add_bcast_batch", "mul_bcast_spatial", "resize_linear_frac", "resize_linear_down", "resize_linear_size"]
 
 
 @pytest.mark.parametrize("name", EXACT)
@@ -356,3 +357,55 @@ def test_sorting_and_data_dependent_ops_edge_cases(pa):
     for g_, w_ in zip(got, want):
         assert g_.shape == w_.shape
         assert_close(g_.get(), w_, RTOL, "lstm one step")
+
+
+def test_general_broadcasting_random_pairs(pa):
+    """Add / Sub / Mul / Div under numpy's broadcasting rules (layer.py:93-107) on 40 random shape pairs: ranks 0-6
+    on either side, axes of extent 1 sprinkled in, against numpy itself -- bit for bit."""
+    rng = np.random.default_rng(20260929)
+    ops = [("add", np.add), ("sub", np.subtract), ("mul", np.multiply), ("div", np.divide)]
+    for trial in range(40):
+        nd = int(rng.integers(1, 7))
+        full = [int(rng.integers(1, 6)) for _ in range(nd)]
+        def operand():
+            keep = int(rng.integers(0, nd + 1))
+            shp = [d if rng.random() < 0.6 else 1 for d in full[nd - keep:]]
+            return rng.standard_normal(shp).astype(np.float32)
+        a, b = operand(), operand()
+        kind, fn = ops[trial % 4]
+        if kind == "div":
+            b = np.abs(b) + 0.5
+        want = fn(a, b)
+        got = pa.layer_map[kind](pa.asarray(a), pa.asarray(b))
+        assert tuple(got.shape) == want.shape, (kind, a.shape, b.shape)
+        assert np.array_equal(got.get(), want), (kind, a.shape, b.shape)
+
+
+def test_broadcast_mismatch_raises_like_numpy(pa):
+    with pytest.raises(ValueError):
+        pa.layer_map["add"](pa.asarray(np.zeros((2, 3), np.float32)), pa.asarray(np.zeros((4,), np.float32)))
+
+
+def test_linear_upsample_and_broadcast_add_inside_a_net(pa):
+    """conv -> relu -> linear upsample x2 -> add of a (1, 1, H, 1) constant -> conv, as a Net through the plan compiler
+    (the two new steps stay on the NCHW kernels between channel-quad convs) against the oracle's interpreter."""
+    rng = np.random.default_rng(7)
+    inits = [("K1", (rng.standard_normal((8, 4, 3, 3)) * 0.2).astype(np.float32)), ("B1", rng.standard_normal(8).astype(np.float32)),
+             ("k", np.array([1, 1, 2, 2], np.float32)), ("row", rng.standard_normal((1, 1, 12, 1)).astype(np.float32)),
+             ("K2", (rng.standard_normal((8, 8, 3, 3)) * 0.2).astype(np.float32)), ("B2", rng.standard_normal(8).astype(np.float32))]
+    cp = {"group": 1, "strides": [1, 1], "dilations": [1, 1], "pads": [1, 1, 1, 1]}
+    graph = {"input": ["x"], "inits": [[n, list(a.shape), str(a.dtype)] for n, a in inits],
+             "layers": [["c1", "conv", cp], ["r1", "relu", {}], ["up", "upsample", {"mode": "linear"}], ["ad", "add", {}],
+                        ["c2", "conv", cp], ["return", "return", {}]],
+             "flow": [[["x", "K1", "B1"], ["c1"], "a"], ["a", ["r1"], "b"], [["b", "k"], ["up"], "u"],
+                      [["u", "row"], ["ad"], "s"], [["s", "K2", "B2"], ["c2"], "y"], [["y"], ["return"], "plrst"]]}
+    blob = np.concatenate([a.reshape(-1).view(np.uint8) for _, a in inits])
+    x = rng.standard_normal((2, 4, 6, 7)).astype(np.float32)
+    ref = onp.OracleNet()
+    ref.load_json(graph["input"], graph["inits"], graph["layers"], graph["flow"])
+    ref.load_weights(blob)
+    want = ref(x.copy())
+    net = pa.from_graph(graph, blob)
+    for rnd in range(2):
+        got = net(x)
+        assert_close(got, want, RTOL, "linear upsample net")
