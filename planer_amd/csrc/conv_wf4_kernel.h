@@ -96,6 +96,58 @@ __device__ __forceinline__ void wf4_transform_row(const float *P, float *V, int 
     dst[2] = make_float2(o[4], o[5]);
 }
 
+// The same row for TWO channels per lane (16-byte-cell patch layout): every value is a channel pair out of one 8-byte LDS read
+// and every operation a packed one -- half the vector instructions of the one-channel form and no operand shuffling.  Lanes =
+// 32 tiles x 2 channel pairs (pair fastest: consecutive lanes read consecutive 8 bytes).  Same formulas, same roundings.
+typedef float wf4_v2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ wf4_v2 wf4_fma2(float a, wf4_v2 b, wf4_v2 c) { return __builtin_elementwise_fma((wf4_v2){a, a}, b, c); }
+__device__ __forceinline__ void wf4_bt2(const wf4_v2 (&d)[6], wf4_v2 (&o)[6]) {
+    const wf4_v2 s = d[4] - d[2], t = d[3] - d[1];
+    o[0] = wf4_fma2(4.f, d[0], wf4_fma2(-5.f, d[2], d[4]));
+    o[1] = wf4_fma2(-4.f, d[1] + d[2], d[3] + d[4]);
+    o[2] = wf4_fma2(4.f, d[1] - d[2], d[4] - d[3]);
+    o[3] = wf4_fma2(2.f, t, s);
+    o[4] = wf4_fma2(-2.f, t, s);
+    o[5] = wf4_fma2(4.f, d[1], wf4_fma2(-5.f, d[3], d[5]));
+}
+template <int A>
+__device__ __forceinline__ wf4_v2 wf4_bt_row2(const wf4_v2 (&d)[6]) {
+    if constexpr (A == 0) return wf4_fma2(4.f, d[0], wf4_fma2(-5.f, d[2], d[4]));
+    else if constexpr (A == 1) return wf4_fma2(-4.f, d[1] + d[2], d[3] + d[4]);
+    else if constexpr (A == 2) return wf4_fma2(4.f, d[1] - d[2], d[4] - d[3]);
+    else if constexpr (A == 3) return wf4_fma2(2.f, d[3] - d[1], d[4] - d[2]);
+    else if constexpr (A == 4) return wf4_fma2(-2.f, d[3] - d[1], d[4] - d[2]);
+    else return wf4_fma2(4.f, d[1], wf4_fma2(-5.f, d[3], d[5]));
+}
+// pbase: float index of the pair's first value in the tile's first patch cell; vbase: float index of V[half][even channel][i][0]
+// (the odd channel's row is 16 x 36 floats further on); rs = floats per patch row, ps = floats per x phase
+template <int A, int rs, int ps>
+__device__ __forceinline__ void wf4_transform_row2(const float *P, float *V, int pbase, int vbase) {
+    wf4_v2 d[6][6];
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+        const float *col = P + pbase + (b & 3) * ps + (b >> 2) * 4;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            constexpr bool used[6][6] = {{1, 0, 1, 0, 1, 0}, {0, 1, 1, 1, 1, 0}, {0, 1, 1, 1, 1, 0},
+                                         {0, 1, 1, 1, 1, 0}, {0, 1, 1, 1, 1, 0}, {0, 1, 0, 1, 0, 1}};
+            d[b][k] = used[A][k] ? *reinterpret_cast<const wf4_v2 *>(col + k * rs) : (wf4_v2){0.f, 0.f};
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    wf4_v2 m[6];
+#pragma unroll
+    for (int b = 0; b < 6; ++b) m[b] = wf4_bt_row2<A>(d[b]);
+    wf4_v2 o[6];
+    wf4_bt2(m, o);
+    float *v0 = V + vbase + A * 6, *v1 = v0 + 16 * 36;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        v0[j] = o[j].x;
+        v1[j] = o[j].y;
+    }
+}
+
 // row A of the 4x4 output tile of one channel quad: A^T over the frequency rows for each of the 6 frequency columns, then A^T
 // over the columns, fused tail, four 16-byte stores (the residual quads were requested before the first row started)
 template <int A>
@@ -239,10 +291,24 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
     int pb0, vb0, pb1, vb1;
     item_bases(0, pb0, vb0);
     item_bases(1, pb1, vb1);
+    // 16-byte-cell layout: a lane takes a channel PAIR of one of the block's 32 tiles (wf4_transform_row2), so a whole row of
+    // B^T d B is ONE wave-item: six per step -- waves 4-7 rows 0-3, waves 0-1 rows 4-5
+    int pb2 = 0, vb2 = 0;
+    if constexpr (!PLANAR) {
+        const int tj = lane >> 1, cp = lane & 1;
+        const int t_nb = tj >> lT, t_r = (tj >> LBC) & BRm, t_c = tj & BCm;
+        pb2 = 2 * cp + (((t_nb * p.R + 4 * t_r) * 4) * S + t_c) * 4;
+        vb2 = ((((tj >> 4) * 4 + 2 * cp) * 16) + (tj & 15)) * 36;
+    }
     auto transform_first = [&](int pbuf, int vbuf) {           // waves 4-7: a whole row (both halves)
         const float *Pb = pbuf ? Ps1 : Ps0;
         float *Vb = vbuf ? Vs1 : Vs0;
-        if (wave == 4) {
+        if constexpr (!PLANAR) {
+            if (wave == 4) wf4_transform_row2<0, rs, psz>(Pb, Vb, pb2, vb2);
+            else if (wave == 5) wf4_transform_row2<1, rs, psz>(Pb, Vb, pb2, vb2);
+            else if (wave == 6) wf4_transform_row2<2, rs, psz>(Pb, Vb, pb2, vb2);
+            else if (wave == 7) wf4_transform_row2<3, rs, psz>(Pb, Vb, pb2, vb2);
+        } else if (wave == 4) {
             wf4_transform_row<0, rs, psz, cst>(Pb, Vb, pb0, vb0);
             wf4_transform_row<0, rs, psz, cst>(Pb, Vb, pb1, vb1);
         } else if (wave == 5) {
@@ -260,8 +326,13 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
     auto transform_last = [&](int pbuf, int vbuf) {            // waves 0-3: row 4 or 5 of one half
         const float *Pb = pbuf ? Ps1 : Ps0;
         float *Vb = vbuf ? Vs1 : Vs0;
-        if (wave < 2) wf4_transform_row<4, rs, psz, cst>(Pb, Vb, pbw, vbw);
-        else if (wave < 4) wf4_transform_row<5, rs, psz, cst>(Pb, Vb, pbw, vbw);
+        if constexpr (!PLANAR) {
+            if (wave == 0) wf4_transform_row2<4, rs, psz>(Pb, Vb, pb2, vb2);
+            else if (wave == 1) wf4_transform_row2<5, rs, psz>(Pb, Vb, pb2, vb2);
+        } else {
+            if (wave < 2) wf4_transform_row<4, rs, psz, cst>(Pb, Vb, pbw, vbw);
+            else if (wave < 4) wf4_transform_row<5, rs, psz, cst>(Pb, Vb, pbw, vbw);
+        }
     };
 
     f32x4 acc[36];
