@@ -42,6 +42,9 @@ struct Wf4Args {
     Epilogue ep;
 };
 
+#ifndef WF4_RES_PER_ROW
+#define WF4_RES_PER_ROW 1
+#endif
 constexpr int WF4_A_FLOATS = 36 * 256, WF4_V_FLOATS = 2 * 36 * 64, WF4_P_PASSES = 2;      // patch passes of 512 cells
 constexpr int WF4_P_CELLS = 1024, WF4_P_FLOATS = WF4_P_CELLS * 4;
 constexpr int WF4_LDS_BYTES = (2 * WF4_A_FLOATS + 2 * WF4_V_FLOATS + 2 * WF4_P_FLOATS) * 4;
@@ -169,6 +172,81 @@ __device__ __forceinline__ void wf4_output_row(const Wf4Args &p, const f32x4 (&a
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         const float4 v = apply_epilogue4(p.ep, bias, scale, shift, rsd[b], 4, o[b]);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
+                                               yrsrc, off[b], 0, PLANER_STORE_AUX);
+    }
+}
+
+// The same row on channel PAIRS (the accumulator's registers 0-1 and 2-3 are natural pairs): packed arithmetic throughout.
+// TAIL 0: the general fused tail (apply_epilogue4, every option a per-element select); TAIL 1 / 2: the tail convolutions of a
+// residual net carry -- per-channel scale and shift, [residual,] ReLU, no bias -- written out straight (same operations, same
+// order, same roundings as apply_epilogue4 takes for that combination).
+template <int A>
+__device__ __forceinline__ wf4_v2 wf4_at_row2(const wf4_v2 (&m)[6]) {
+    if constexpr (A == 0) return (m[0] + (m[1] + m[2])) + (m[3] + m[4]);
+    else {
+        const wf4_v2 q = m[1] - m[2], t = m[3] - m[4], pp = m[1] + m[2], r = m[3] + m[4];
+        if constexpr (A == 1) return q + 2.f * t;
+        else if constexpr (A == 2) return pp + 4.f * r;
+        else return (q + 8.f * t) + m[5];
+    }
+}
+__device__ __forceinline__ void wf4_at2(const wf4_v2 (&m)[6], wf4_v2 (&o)[4]) {
+    const wf4_v2 pp = m[1] + m[2], q = m[1] - m[2], r = m[3] + m[4], t = m[3] - m[4];
+    o[0] = (m[0] + pp) + r;
+    o[1] = q + 2.f * t;
+    o[2] = pp + 4.f * r;
+    o[3] = (q + 8.f * t) + m[5];
+}
+template <bool RES>
+__device__ __forceinline__ wf4_v2 wf4_tail2(wf4_v2 v, wf4_v2 sc, wf4_v2 sh, wf4_v2 rs) {
+    v = v * sc;
+    v = v + sh;
+    if constexpr (RES) v = v + rs;
+    const wf4_v2 z = v * 0.f;                          // relu_ref: x > 0 ? x : x * 0
+    return (wf4_v2){v.x > 0.f ? v.x : z.x, v.y > 0.f ? v.y : z.y};
+}
+template <int A, int TAIL>
+__device__ __forceinline__ void wf4_output_row2(const Wf4Args &p, const f32x4 (&acc)[36], float4 bias, float4 scale, float4 shift,
+                                                const __amdgpu_buffer_rsrc_t yrsrc, const int (&off)[4], const float4 (&rsd)[4]) {
+    wf4_v2 olo[4], ohi[4];
+    {
+        wf4_v2 s[6];
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            wf4_v2 m[6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) m[a] = __builtin_shufflevector(acc[a * 6 + b], acc[a * 6 + b], 0, 1);
+            s[b] = wf4_at_row2<A>(m);
+        }
+        wf4_at2(s, olo);
+        if constexpr (TAIL != 0) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                olo[b] = wf4_tail2<TAIL == 2>(olo[b], (wf4_v2){scale.x, scale.y}, (wf4_v2){shift.x, shift.y}, (wf4_v2){rsd[b].x, rsd[b].y});
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        wf4_v2 s[6];
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            wf4_v2 m[6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) m[a] = __builtin_shufflevector(acc[a * 6 + b], acc[a * 6 + b], 2, 3);
+            s[b] = wf4_at_row2<A>(m);
+        }
+        wf4_at2(s, ohi);
+        if constexpr (TAIL != 0) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                ohi[b] = wf4_tail2<TAIL == 2>(ohi[b], (wf4_v2){scale.z, scale.w}, (wf4_v2){shift.z, shift.w}, (wf4_v2){rsd[b].z, rsd[b].w});
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        float4 v = make_float4(olo[b].x, olo[b].y, ohi[b].x, ohi[b].y);
+        if constexpr (TAIL == 0) v = apply_epilogue4(p.ep, bias, scale, shift, rsd[b], 4, v);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
                                                yrsrc, off[b], 0, PLANER_STORE_AUX);
     }
@@ -417,8 +495,8 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
     const unsigned row0 = ((unsigned)(n * p.Coq + cqc) * (unsigned)p.H + (unsigned)(ty * 4)) * (unsigned)p.W + (unsigned)(tx * 4);
     // the residual quads are requested two output rows at a time: two memory round trips per tile instead of four
     // (all sixteen at once would not fit beside the 144 accumulator registers)
-    auto rows_pair = [&](auto first) {
-        constexpr int A0 = decltype(first)::value;
+    auto rows_pair = [&](auto first, auto tail) {
+        constexpr int A0 = decltype(first)::value, TAIL = decltype(tail)::value;
         int off[2][4];
         float4 rsd[2][4];
 #pragma unroll
@@ -426,13 +504,42 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 off[a][b] = (cok && ty * 4 + A0 + a < p.H && tx * 4 + b < p.W) ? (int)((row0 + (unsigned)((A0 + a) * p.W + b)) << 4) : OOB;
-                rsd[a][b] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off[a][b], 0, 0));
+                if constexpr (TAIL == 0 || (TAIL == 2 && !WF4_RES_PER_ROW))
+                    rsd[a][b] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off[a][b], 0, 0));
+                else
+                    rsd[a][b] = z4;
             }
-        wf4_output_row<A0>(p, acc, bias, scale, shift, yrsrc, off[0], rsd[0]);
-        wf4_output_row<A0 + 1>(p, acc, bias, scale, shift, yrsrc, off[1], rsd[1]);
+        if constexpr (TAIL == 2 && WF4_RES_PER_ROW) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) rsd[0][b] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off[0][b], 0, 0));
+            wf4_output_row2<A0, TAIL>(p, acc, bias, scale, shift, yrsrc, off[0], rsd[0]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) rsd[0][b] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off[1][b], 0, 0));
+            wf4_output_row2<A0 + 1, TAIL>(p, acc, bias, scale, shift, yrsrc, off[1], rsd[0]);
+            return;
+        }
+        if constexpr (TAIL == 0) {
+            wf4_output_row<A0>(p, acc, bias, scale, shift, yrsrc, off[0], rsd[0]);
+            wf4_output_row<A0 + 1>(p, acc, bias, scale, shift, yrsrc, off[1], rsd[1]);
+        } else {
+            wf4_output_row2<A0, TAIL>(p, acc, bias, scale, shift, yrsrc, off[0], rsd[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            wf4_output_row2<A0 + 1, TAIL>(p, acc, bias, scale, shift, yrsrc, off[1], rsd[1]);
+        }
     };
-    rows_pair(std::integral_constant<int, 0>{});
-    rows_pair(std::integral_constant<int, 2>{});
+    // the tail is the same for the whole launch: one scalar branch picks the straight-line form where it applies
+    const bool plain = !p.ep.bias && p.ep.scale && p.ep.shift && p.ep.act == 1;
+    if (plain && !p.ep.res) {
+        rows_pair(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+        rows_pair(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{});
+    } else if (plain && !p.ep.res_post) {
+        rows_pair(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+        rows_pair(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
+    } else {
+        rows_pair(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        rows_pair(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
+    }
 }
 
 template <bool DMA_A, bool PLANAR, bool STAGGER, int LBC>
