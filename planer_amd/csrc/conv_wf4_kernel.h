@@ -42,9 +42,6 @@ struct Wf4Args {
     Epilogue ep;
 };
 
-#ifndef WF4_RES_PER_ROW
-#define WF4_RES_PER_ROW 1
-#endif
 constexpr int WF4_A_FLOATS = 36 * 256, WF4_V_FLOATS = 2 * 36 * 64, WF4_P_PASSES = 2;      // patch passes of 512 cells
 constexpr int WF4_P_CELLS = 1024, WF4_P_FLOATS = WF4_P_CELLS * 4;
 constexpr int WF4_LDS_BYTES = (2 * WF4_A_FLOATS + 2 * WF4_V_FLOATS + 2 * WF4_P_FLOATS) * 4;
@@ -177,10 +174,8 @@ __device__ __forceinline__ void wf4_output_row(const Wf4Args &p, const f32x4 (&a
     }
 }
 
-// The same row on channel PAIRS (the accumulator's registers 0-1 and 2-3 are natural pairs): packed arithmetic throughout.
-// TAIL 0: the general fused tail (apply_epilogue4, every option a per-element select); TAIL 1 / 2: the tail convolutions of a
-// residual net carry -- per-channel scale and shift, [residual,] ReLU, no bias -- written out straight (same operations, same
-// order, same roundings as apply_epilogue4 takes for that combination).
+// A^T m A on channel PAIRS (the accumulator's registers 0-1 and 2-3 are natural pairs): packed arithmetic throughout, the
+// operations and their order are those of w4_at4_row / w4_at4.
 template <int A>
 __device__ __forceinline__ wf4_v2 wf4_at_row2(const wf4_v2 (&m)[6]) {
     if constexpr (A == 0) return (m[0] + (m[1] + m[2])) + (m[3] + m[4]);
@@ -198,17 +193,23 @@ __device__ __forceinline__ void wf4_at2(const wf4_v2 (&m)[6], wf4_v2 (&o)[4]) {
     o[2] = pp + 4.f * r;
     o[3] = (q + 8.f * t) + m[5];
 }
-template <bool RES>
-__device__ __forceinline__ wf4_v2 wf4_tail2(wf4_v2 v, wf4_v2 sc, wf4_v2 sh, wf4_v2 rs) {
-    v = v * sc;
-    v = v + sh;
-    if constexpr (RES) v = v + rs;
-    const wf4_v2 z = v * 0.f;                          // relu_ref: x > 0 ? x : x * 0
-    return (wf4_v2){v.x > 0.f ? v.x : z.x, v.y > 0.f ? v.y : z.y};
-}
-template <int A, int TAIL>
-__device__ __forceinline__ void wf4_output_row2(const Wf4Args &p, const f32x4 (&acc)[36], float4 bias, float4 scale, float4 shift,
-                                                const __amdgpu_buffer_rsrc_t yrsrc, const int (&off)[4], const float4 (&rsd)[4]) {
+// Coalesced form of the row for the tail the convolutions of a residual net carry (per-channel scale and shift, [residual,]
+// ReLU, no bias).  In the MFMA's C layout a lane owns one tile x one channel quad, so a 16-byte
+// store instruction scatters 64 pieces at 64-byte strides over four channel planes -- the end-of-kernel store burst of all
+// workgroups ran at ~2 TB/s.  Here the row goes through a wave-private LDS buffer [b][quad][tile] (68-cell rows: the padding
+// makes the read-back conflict-free) and comes back as lane = (tile, pixel b of the tile's row): one instruction then writes
+// (and, for the residual, reads) 16 tiles x 4 pixels = one contiguous 1 KB run of a channel plane.  Scale and shift are applied
+// before the exchange (a lane knows its quad's parameters there), residual and ReLU after it: the same operations in the same
+// order on every value.
+template <int A, bool RES>
+__device__ __forceinline__ void wf4_output_row_coalesced(const f32x4 (&acc)[36], float4 scale, float4 shift, float4 *xb, int wr_cell,
+                                                         int rd_cell, const __amdgpu_buffer_rsrc_t yrsrc,
+                                                         const __amdgpu_buffer_rsrc_t rrsrc, const int (&off)[4]) {
+    float4 rs[4];
+    if constexpr (RES) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rs[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off[q], 0, 0));
+    }
     wf4_v2 olo[4], ohi[4];
     {
         wf4_v2 s[6];
@@ -220,13 +221,9 @@ __device__ __forceinline__ void wf4_output_row2(const Wf4Args &p, const f32x4 (&
             s[b] = wf4_at_row2<A>(m);
         }
         wf4_at2(s, olo);
-        if constexpr (TAIL != 0) {
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
-                olo[b] = wf4_tail2<TAIL == 2>(olo[b], (wf4_v2){scale.x, scale.y}, (wf4_v2){shift.x, shift.y}, (wf4_v2){rsd[b].x, rsd[b].y});
-        }
+        for (int b = 0; b < 4; ++b) olo[b] = olo[b] * (wf4_v2){scale.x, scale.y} + (wf4_v2){shift.x, shift.y};
     }
-    __builtin_amdgcn_sched_barrier(0);
     {
         wf4_v2 s[6];
 #pragma unroll
@@ -237,18 +234,30 @@ __device__ __forceinline__ void wf4_output_row2(const Wf4Args &p, const f32x4 (&
             s[b] = wf4_at_row2<A>(m);
         }
         wf4_at2(s, ohi);
-        if constexpr (TAIL != 0) {
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
-                ohi[b] = wf4_tail2<TAIL == 2>(ohi[b], (wf4_v2){scale.z, scale.w}, (wf4_v2){shift.z, shift.w}, (wf4_v2){rsd[b].z, rsd[b].w});
-        }
+        for (int b = 0; b < 4; ++b) ohi[b] = ohi[b] * (wf4_v2){scale.z, scale.w} + (wf4_v2){shift.z, shift.w};
     }
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        float4 v = make_float4(olo[b].x, olo[b].y, ohi[b].x, ohi[b].y);
-        if constexpr (TAIL == 0) v = apply_epilogue4(p.ep, bias, scale, shift, rsd[b], 4, v);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
-                                               yrsrc, off[b], 0, PLANER_STORE_AUX);
+    for (int b = 0; b < 4; ++b) xb[b * 68 + wr_cell] = make_float4(olo[b].x, olo[b].y, ohi[b].x, ohi[b].y);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = xb[rd_cell + q * 16];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                   // the next row overwrites the buffer
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        wf4_v2 lo = (wf4_v2){v[q].x, v[q].y}, hi = (wf4_v2){v[q].z, v[q].w};
+        if constexpr (RES) {
+            lo = lo + (wf4_v2){rs[q].x, rs[q].y};
+            hi = hi + (wf4_v2){rs[q].z, rs[q].w};
+        }
+        const wf4_v2 zl = lo * 0.f, zh = hi * 0.f;     // relu_ref: x > 0 ? x : x * 0
+        const float4 o = make_float4(lo.x > 0.f ? lo.x : zl.x, lo.y > 0.f ? lo.y : zl.y, hi.x > 0.f ? hi.x : zh.x, hi.y > 0.f ? hi.y : zh.y);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o),
+                                               yrsrc, off[q], 0, PLANER_STORE_AUX);
     }
 }
 
@@ -495,8 +504,8 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
     const unsigned row0 = ((unsigned)(n * p.Coq + cqc) * (unsigned)p.H + (unsigned)(ty * 4)) * (unsigned)p.W + (unsigned)(tx * 4);
     // the residual quads are requested two output rows at a time: two memory round trips per tile instead of four
     // (all sixteen at once would not fit beside the 144 accumulator registers)
-    auto rows_pair = [&](auto first, auto tail) {
-        constexpr int A0 = decltype(first)::value, TAIL = decltype(tail)::value;
+    auto rows_pair = [&](auto first) {
+        constexpr int A0 = decltype(first)::value;
         int off[2][4];
         float4 rsd[2][4];
 #pragma unroll
@@ -504,41 +513,45 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 off[a][b] = (cok && ty * 4 + A0 + a < p.H && tx * 4 + b < p.W) ? (int)((row0 + (unsigned)((A0 + a) * p.W + b)) << 4) : OOB;
-                if constexpr (TAIL == 0 || (TAIL == 2 && !WF4_RES_PER_ROW))
-                    rsd[a][b] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off[a][b], 0, 0));
-                else
-                    rsd[a][b] = z4;
+                rsd[a][b] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off[a][b], 0, 0));
             }
-        if constexpr (TAIL == 2 && WF4_RES_PER_ROW) {
-#pragma unroll
-            for (int b = 0; b < 4; ++b) rsd[0][b] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off[0][b], 0, 0));
-            wf4_output_row2<A0, TAIL>(p, acc, bias, scale, shift, yrsrc, off[0], rsd[0]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int b = 0; b < 4; ++b) rsd[0][b] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off[1][b], 0, 0));
-            wf4_output_row2<A0 + 1, TAIL>(p, acc, bias, scale, shift, yrsrc, off[1], rsd[0]);
-            return;
-        }
-        if constexpr (TAIL == 0) {
-            wf4_output_row<A0>(p, acc, bias, scale, shift, yrsrc, off[0], rsd[0]);
-            wf4_output_row<A0 + 1>(p, acc, bias, scale, shift, yrsrc, off[1], rsd[1]);
-        } else {
-            wf4_output_row2<A0, TAIL>(p, acc, bias, scale, shift, yrsrc, off[0], rsd[0]);
-            __builtin_amdgcn_sched_barrier(0);
-            wf4_output_row2<A0 + 1, TAIL>(p, acc, bias, scale, shift, yrsrc, off[1], rsd[1]);
-        }
+        wf4_output_row<A0>(p, acc, bias, scale, shift, yrsrc, off[0], rsd[0]);
+        wf4_output_row<A0 + 1>(p, acc, bias, scale, shift, yrsrc, off[1], rsd[1]);
     };
-    // the tail is the same for the whole launch: one scalar branch picks the straight-line form where it applies
+    // the tail is the same for the whole launch: one scalar branch picks the straight-line, coalesced form where it applies
     const bool plain = !p.ep.bias && p.ep.scale && p.ep.shift && p.ep.act == 1;
-    if (plain && !p.ep.res) {
-        rows_pair(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
-        rows_pair(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{});
-    } else if (plain && !p.ep.res_post) {
-        rows_pair(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
-        rows_pair(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
+    if (plain && (!p.ep.res || !p.ep.res_post)) {
+        float4 *xb = reinterpret_cast<float4 *>(As0) + wave * (4 * 68);      // the K loop is over: A0 is free (8 x 4.25 KB)
+        const int t2 = lane >> 2, b2 = lane & 3;
+        const int oj2 = wn * 16 + t2;
+        const int n2 = n0 + (oj2 >> lT), ty2 = ty0 + ((oj2 >> LBC) & BRm), tx2 = tx0 + (oj2 & BCm);
+        const int x2 = tx2 * 4 + b2, cq0 = (int)coutblk * 16 + wm * 4;
+        const bool ok2 = n2 < p.N && ty2 < p.th && tx2 < p.tw && x2 < p.W;
+        auto row = [&](auto first, auto res) {
+            constexpr int A = decltype(first)::value;
+            constexpr bool RES = decltype(res)::value;
+            const int yy = ty2 * 4 + A;
+            int off[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                off[q] = (ok2 && yy < p.H && cq0 + q < p.Coq)
+                             ? (int)((((unsigned)(n2 * p.Coq + cq0 + q) * (unsigned)p.H + (unsigned)yy) * (unsigned)p.W + (unsigned)x2) << 4) : OOB;
+            wf4_output_row_coalesced<A, RES>(acc, scale, shift, xb, lk * 16 + li, b2 * 68 + t2, yrsrc, rrsrc, off);
+        };
+        if (p.ep.res) {
+            row(std::integral_constant<int, 0>{}, std::true_type{});
+            row(std::integral_constant<int, 1>{}, std::true_type{});
+            row(std::integral_constant<int, 2>{}, std::true_type{});
+            row(std::integral_constant<int, 3>{}, std::true_type{});
+        } else {
+            row(std::integral_constant<int, 0>{}, std::false_type{});
+            row(std::integral_constant<int, 1>{}, std::false_type{});
+            row(std::integral_constant<int, 2>{}, std::false_type{});
+            row(std::integral_constant<int, 3>{}, std::false_type{});
+        }
     } else {
-        rows_pair(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-        rows_pair(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
+        rows_pair(std::integral_constant<int, 0>{});
+        rows_pair(std::integral_constant<int, 2>{});
     }
 }
 
