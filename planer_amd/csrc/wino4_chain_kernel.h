@@ -40,52 +40,93 @@ struct Wino4ChainArgs {
     Epilogue ep;
 };
 
+// The transforms on channel PAIRS: a float4 cell is two register pairs, and on pairs every operation is one packed
+// instruction (v_pk_add / v_pk_mul) with no operand shuffling.  Expression for expression the formulas of w4_bt_row / w4_bt /
+// w4_at4_row / w4_at4 (same operations, same order, no contraction): results are bit-identical to the register kernels'.
+typedef float wc_v2 __attribute__((ext_vector_type(2)));
 template <int A>
-__device__ __forceinline__ float4 w4_bt_row4(const float4 (&d)[6]) {
-    const float dx[6] = {d[0].x, d[1].x, d[2].x, d[3].x, d[4].x, d[5].x};
-    const float dy[6] = {d[0].y, d[1].y, d[2].y, d[3].y, d[4].y, d[5].y};
-    const float dz[6] = {d[0].z, d[1].z, d[2].z, d[3].z, d[4].z, d[5].z};
-    const float dw[6] = {d[0].w, d[1].w, d[2].w, d[3].w, d[4].w, d[5].w};
-    return make_float4(w4_bt_row<A>(dx), w4_bt_row<A>(dy), w4_bt_row<A>(dz), w4_bt_row<A>(dw));
+__device__ __forceinline__ wc_v2 wc_bt_row2(const wc_v2 (&d)[6]) {
+    if constexpr (A == 0) return 4.f * d[0] - 5.f * d[2] + d[4];
+    else if constexpr (A == 1) return -4.f * (d[1] + d[2]) + d[3] + d[4];
+    else if constexpr (A == 2) return 4.f * (d[1] - d[2]) - d[3] + d[4];
+    else if constexpr (A == 3) return 2.f * (d[3] - d[1]) - d[2] + d[4];
+    else if constexpr (A == 4) return 2.f * (d[1] - d[3]) - d[2] + d[4];
+    else return 4.f * d[1] - 5.f * d[3] + d[5];
 }
-
-__device__ __forceinline__ void w4_bt4(const float4 (&m)[6], float4 (&o)[6]) {
-    const float mx[6] = {m[0].x, m[1].x, m[2].x, m[3].x, m[4].x, m[5].x};
-    const float my[6] = {m[0].y, m[1].y, m[2].y, m[3].y, m[4].y, m[5].y};
-    const float mz[6] = {m[0].z, m[1].z, m[2].z, m[3].z, m[4].z, m[5].z};
-    const float mw[6] = {m[0].w, m[1].w, m[2].w, m[3].w, m[4].w, m[5].w};
-    float ox[6], oy[6], oz[6], ow[6];
-    w4_bt(mx, ox);
-    w4_bt(my, oy);
-    w4_bt(mz, oz);
-    w4_bt(mw, ow);
-#pragma unroll
-    for (int j = 0; j < 6; ++j) o[j] = make_float4(ox[j], oy[j], oz[j], ow[j]);
+__device__ __forceinline__ void wc_bt2(const wc_v2 (&d)[6], wc_v2 (&o)[6]) {
+    o[0] = 4.f * d[0] - 5.f * d[2] + d[4];
+    o[1] = -4.f * (d[1] + d[2]) + d[3] + d[4];
+    o[2] = 4.f * (d[1] - d[2]) - d[3] + d[4];
+    o[3] = 2.f * (d[3] - d[1]) - d[2] + d[4];
+    o[4] = 2.f * (d[1] - d[3]) - d[2] + d[4];
+    o[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+}
+template <int A>
+__device__ __forceinline__ wc_v2 wc_at_row2(const wc_v2 (&m)[6]) {
+    if constexpr (A == 0) return (m[0] + (m[1] + m[2])) + (m[3] + m[4]);
+    else {
+        const wc_v2 q = m[1] - m[2], t = m[3] - m[4], pp = m[1] + m[2], r = m[3] + m[4];
+        if constexpr (A == 1) return q + 2.f * t;
+        else if constexpr (A == 2) return pp + 4.f * r;
+        else return q + 8.f * t + m[5];
+    }
+}
+__device__ __forceinline__ void wc_at2(const wc_v2 (&m)[6], wc_v2 (&o)[4]) {
+    const wc_v2 pp = m[1] + m[2], q = m[1] - m[2], r = m[3] + m[4], t = m[3] - m[4];
+    o[0] = (m[0] + pp) + r;
+    o[1] = q + 2.f * t;
+    o[2] = pp + 4.f * r;
+    o[3] = q + 8.f * t + m[5];
+}
+__device__ __forceinline__ wc_v2 wc_lo(float4 v) { return (wc_v2){v.x, v.y}; }
+__device__ __forceinline__ wc_v2 wc_hi(float4 v) { return (wc_v2){v.z, v.w}; }
+// the tail a residual net's convolutions carry (scale, shift, [residual,] ReLU; no bias) written straight: what apply_epilogue4
+// does for that combination, without its per-element option selects
+__device__ __forceinline__ wc_v2 wc_plain_tail(wc_v2 v, wc_v2 sc, wc_v2 sh, wc_v2 rs, bool has_res) {
+    v = v * sc;
+    v = v + sh;
+    if (has_res) v = v + rs;
+    const wc_v2 z = v * 0.f;
+    return (wc_v2){v.x > 0.f ? v.x : z.x, v.y > 0.f ? v.y : z.y};
 }
 
 // P1: row A of the 4x4 output tile (quad cql, tile (ty, tx)) out of the LDS slab, fused tail, into the plane
-template <int A>
+template <int A, bool PLAIN>
 __device__ __forceinline__ void wc_out_row(const Wino4ChainArgs &p, const float4 *slab, float4 *plane, const float4 *prm,
                                            unsigned r, unsigned cql, unsigned ty, unsigned tx) {
-    float4 s[6];
+    wc_v2 slo[6], shi[6];
 #pragma unroll
     for (int b = 0; b < 6; ++b) {
-        float4 m[6];
+        wc_v2 mlo[6], mhi[6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) m[k] = slab[(unsigned)(k * 6 + b) * (unsigned)p.gt + r];
-        s[b] = w4_at4_row<A>(m);
+        for (int k = 0; k < 6; ++k) {
+            const float4 m = slab[(unsigned)(k * 6 + b) * (unsigned)p.gt + r];
+            mlo[k] = wc_lo(m);
+            mhi[k] = wc_hi(m);
+        }
+        slo[b] = wc_at_row2<A>(mlo);
+        shi[b] = wc_at_row2<A>(mhi);
     }
-    float4 o[4];
-    w4_at4(s, o);
+    wc_v2 olo[4], ohi[4];
+    wc_at2(slo, olo);
+    wc_at2(shi, ohi);
     const float4 bias = prm[cql], scale = prm[p.G + cql], shift = prm[2 * p.G + cql];
     const int h = (int)ty * 4 + A;
     float4 *row = plane + ((size_t)cql * p.R + h + 1) * 4 * p.S;
+    const bool has_res = p.ep.res != nullptr;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         const int w = (int)tx * 4 + b, xp = w + 1;
         float4 *cell = row + (xp & 3) * p.S + (xp >> 2);
         const float4 rs = *cell;                  // the residual (P0 put it there) or zero
-        const float4 v = apply_epilogue4(p.ep, bias, scale, shift, rs, 4, o[b]);
+        float4 v;
+        if constexpr (PLAIN) {
+            const wc_v2 lo = wc_plain_tail(olo[b], wc_lo(scale), wc_lo(shift), wc_lo(rs), has_res);
+            const wc_v2 hi = wc_plain_tail(ohi[b], wc_hi(scale), wc_hi(shift), wc_hi(rs), has_res);
+            v = make_float4(lo.x, lo.y, hi.x, hi.y);
+        } else {
+            v = apply_epilogue4(p.ep, bias, scale, shift, rs, 4, make_float4(olo[b].x, olo[b].y, ohi[b].x, ohi[b].y));
+        }
         const bool ok = h < p.H && w < p.W;       // past the map's edge: the next conv's zero padding
         *cell = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -95,21 +136,27 @@ __device__ __forceinline__ void wc_out_row(const Wino4ChainArgs &p, const float4
 template <int A>
 __device__ __forceinline__ void wc_in_row(const Wino4ChainArgs &p, const float4 *plane, unsigned cql, unsigned ty,
                                           unsigned tx, size_t vbase, size_t vplane) {
-    float4 m[6];
+    wc_v2 mlo[6], mhi[6];
     const float4 *rows = plane + ((size_t)cql * p.R + ty * 4) * 4 * p.S;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
         const int xp = (int)tx * 4 + j;
         const float4 *col = rows + (xp & 3) * p.S + (xp >> 2);
-        float4 d[6];
+        wc_v2 dlo[6], dhi[6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) d[k] = col[(size_t)k * 4 * p.S];
-        m[j] = w4_bt_row4<A>(d);
+        for (int k = 0; k < 6; ++k) {
+            const float4 d = col[(size_t)k * 4 * p.S];
+            dlo[k] = wc_lo(d);
+            dhi[k] = wc_hi(d);
+        }
+        mlo[j] = wc_bt_row2<A>(dlo);
+        mhi[j] = wc_bt_row2<A>(dhi);
     }
-    float4 o[6];
-    w4_bt4(m, o);
+    wc_v2 olo[6], ohi[6];
+    wc_bt2(mlo, olo);
+    wc_bt2(mhi, ohi);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) p.V[(size_t)(A * 6 + j) * vplane + vbase] = o[j];
+    for (int j = 0; j < 6; ++j) p.V[(size_t)(A * 6 + j) * vplane + vbase] = make_float4(olo[j].x, olo[j].y, ohi[j].x, ohi[j].y);
 }
 
 template <bool FROM_M>
@@ -169,6 +216,7 @@ __global__ void __launch_bounds__(512) wino4_chain_kernel(const Wino4ChainArgs p
 
     // ---- P1: products -> y (in the plane) ----
     if (FROM_M) {
+        const bool plain = !p.ep.bias && p.ep.scale && p.ep.shift && p.ep.act == 1 && !(p.ep.res && p.ep.res_post);
         for (unsigned j = tid; j < 4u * (unsigned)p.per; j += bd) {
             unsigned a, r;
             p.divPer.divmod(j, a, r);
@@ -176,11 +224,20 @@ __global__ void __launch_bounds__(512) wino4_chain_kernel(const Wino4ChainArgs p
                 unsigned cql, tl, ty, tx;
                 p.divTiles.divmod(r, cql, tl);
                 p.divTw.divmod(tl, ty, tx);
-                switch (a) {
-                case 0: wc_out_row<0>(p, slab, plane, prm, r, cql, ty, tx); break;
-                case 1: wc_out_row<1>(p, slab, plane, prm, r, cql, ty, tx); break;
-                case 2: wc_out_row<2>(p, slab, plane, prm, r, cql, ty, tx); break;
-                default: wc_out_row<3>(p, slab, plane, prm, r, cql, ty, tx); break;
+                if (plain) {
+                    switch (a) {
+                    case 0: wc_out_row<0, true>(p, slab, plane, prm, r, cql, ty, tx); break;
+                    case 1: wc_out_row<1, true>(p, slab, plane, prm, r, cql, ty, tx); break;
+                    case 2: wc_out_row<2, true>(p, slab, plane, prm, r, cql, ty, tx); break;
+                    default: wc_out_row<3, true>(p, slab, plane, prm, r, cql, ty, tx); break;
+                    }
+                } else {
+                    switch (a) {
+                    case 0: wc_out_row<0, false>(p, slab, plane, prm, r, cql, ty, tx); break;
+                    case 1: wc_out_row<1, false>(p, slab, plane, prm, r, cql, ty, tx); break;
+                    case 2: wc_out_row<2, false>(p, slab, plane, prm, r, cql, ty, tx); break;
+                    default: wc_out_row<3, false>(p, slab, plane, prm, r, cql, ty, tx); break;
+                    }
                 }
             }
         }
