@@ -174,6 +174,17 @@ int pl_conv2d_rowpack_q4_f32(pl_ctx *ctx, const float *x, int N, int Cin, int H,
                              const float *wq, int Cout, int kh, int kw, const float *bias,
                              float *yq, int sh, int sw, int pt, int pl, const float *scale,
                              const float *shift, const float *resq, int act, double alpha);
+/* The two halves of pl_conv2d_rowpack_q4_f32, for callers that own the input buffer of a captured plan: the re-layout
+ * (x NCHW -> xp, pl_rowpack_input_elems floats, 16-byte aligned) can then BE the copy that brings a new batch into the
+ * plan -- planer_amd.net feeds a plan this way instead of copying the batch and re-laying it inside the graph -- and the
+ * convolution reads the packed image.  Same kernels, same results as the one-call form (util.py:17-44). */
+int pl_rowpack_input_elems(int N, int Cin, int H, int W, int kw, int sw, int pt, int pl, size_t *elems);
+int pl_rowpack_input_f32(pl_ctx *ctx, const float *x, float *xp, int N, int Cin, int H, int W, int kw,
+                         int sw, int pt, int pl);
+int pl_conv2d_rowpacked_q4_f32(pl_ctx *ctx, const float *xp, int N, int Cin, int H, int W,
+                               const float *wq, int Cout, int kh, int kw, const float *bias,
+                               float *yq, int sh, int sw, int pt, int pl, const float *scale,
+                               const float *shift, const float *resq, int act, double alpha);
 /* conv + layer.Maxpool(w = 3x3, strides 2, pads 1) (layer.py:71-72 -> util.py:79-95) in ONE kernel: the conv tile is
  * max-pooled through LDS (zero padding, -1e4 start, the reference's tap order) and yq is the POOLED Q4 tensor
  * (N, Cout, (Ho+1)/2, (Wo+1)/2): the full-resolution conv output never reaches HBM.  No residual.  Emitted by the

@@ -2492,31 +2492,87 @@ int pl_conv2d_prepare_rowpack_f32(pl_ctx *ctx, const float *w, int Cout, int Cin
     return PL_OK;
 }
 
-static int rowpack_conv(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const float *wq, int Cout, int kh,
-                        int kw, const float *bias, float *yq, int sh, int sw, int pt, int pl, const float *scale,
-                        const float *shift, const float *resq, int act, double alpha, int pool) {
+// geometry of the row-packed (zero-padded NHWC) image of an input: rows, pixels per row, floats incl. the slack the last
+// window's quads may overrun
+static void rowpack_geometry(int N, int Cin, int H, int W, int kw, int sw, int pt, int pl, int &Hp, int &Wp, size_t &pelems) {
+    const int Wo = (W + 2 * pl - kw + sw) / sw;
+    Hp = H + 2 * pt;
+    Wp = rowpack_row_pixels(W, pl, Wo, sw, kw, Cin);
+    pelems = ((size_t)N * Hp * Wp * Cin + 8 + 3) / 4 * 4;
+}
+
+static int rowpack_pack(pl_ctx *ctx, const float *x, float *xp, int N, int Cin, int H, int W, int kw, int sw, int pt, int pl) {
+    int Hp, Wp;
+    size_t pelems;
+    rowpack_geometry(N, Cin, H, W, kw, sw, pt, pl, Hp, Wp, pelems);
+    PL_REQUIRE(pelems < (1ull << 29), PL_EUNSUPPORTED, "row-packed input above 2 GiB");
+    const unsigned total = (unsigned)((size_t)N * Hp * Wp * Cin), total4 = (unsigned)((pelems + 3) / 4);   // incl. the slack
+    nchw_to_rowpack_kernel<<<std::min<unsigned>((total4 + 255) / 256, 256 * 16), 256, 0, ctx->stream>>>(
+        x, xp, total4, total, Cin, H, W, Hp, Wp, pt, pl, FastDiv(Cin), FastDiv(Wp), FastDiv(Hp));
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
+
+static int rowpack_check(pl_ctx *ctx, const void *x, int N, int Cin, int H, int W, const float *wq, int Cout, int kh, int kw,
+                         float *yq, int sh, int sw, int pt, int pl, const float *resq) {
     PL_REQUIRE(ctx && x && wq && yq, PL_EINVAL, "pl_conv2d_rowpack_q4_f32: null pointer");
     PL_REQUIRE(N >= 0 && Cin > 0 && Cin < 4 && H > 0 && W > 0 && Cout > 0 && kh > 0 && kw > 0 && sh > 0 && sw > 0 &&
                    pt >= 0 && pl >= 0, PL_EINVAL, "pl_conv2d_rowpack_q4_f32: bad shape (Cin must be 1..3)");
     PL_REQUIRE(((reinterpret_cast<uintptr_t>(yq) | reinterpret_cast<uintptr_t>(wq) | reinterpret_cast<uintptr_t>(resq)) & 15u) == 0,
                PL_EINVAL, "Q4 tensors must be 16-byte aligned");
-    if (N == 0) return PL_OK;
     const int Ho = (H + 2 * pt - kh + sh) / sh, Wo = (W + 2 * pl - kw + sw) / sw;
-    PL_REQUIRE(Ho > 0 && Wo > 0, PL_EINVAL, "pl_conv2d_rowpack_q4_f32: empty output");
-    const int Hp = H + 2 * pt, Wp = rowpack_row_pixels(W, pl, Wo, sw, kw, Cin);
-    const size_t pelems = ((size_t)N * Hp * Wp * Cin + 8 + 3) / 4 * 4;
-    PL_REQUIRE(pelems < (1ull << 29), PL_EUNSUPPORTED, "row-packed input above 2 GiB");
+    PL_REQUIRE(N == 0 || (Ho > 0 && Wo > 0), PL_EINVAL, "pl_conv2d_rowpack_q4_f32: empty output");
+    return PL_OK;
+}
+
+static int rowpack_conv(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const float *wq, int Cout, int kh,
+                        int kw, const float *bias, float *yq, int sh, int sw, int pt, int pl, const float *scale,
+                        const float *shift, const float *resq, int act, double alpha, int pool) {
+    int rc = rowpack_check(ctx, x, N, Cin, H, W, wq, Cout, kh, kw, yq, sh, sw, pt, pl, resq);
+    if (rc != PL_OK) return rc;
+    if (N == 0) return PL_OK;
+    int Hp, Wp;
+    size_t pelems;
+    rowpack_geometry(N, Cin, H, W, kw, sw, pt, pl, Hp, Wp, pelems);
     CtxGuard guard(ctx);
     float *xp = nullptr;
-    int rc = pl_alloc(ctx, pelems * sizeof(float), (void **)&xp);
+    rc = pl_alloc(ctx, pelems * sizeof(float), (void **)&xp);
     if (rc != PL_OK) return rc;
-    const unsigned total = (unsigned)((size_t)N * Hp * Wp * Cin), total4 = (unsigned)((pelems + 3) / 4);   // incl. the slack
-    nchw_to_rowpack_kernel<<<std::min<unsigned>((total4 + 255) / 256, 256 * 16), 256, 0, ctx->stream>>>(
-        x, xp, total4, total, Cin, H, W, Hp, Wp, pt, pl, FastDiv(Cin), FastDiv(Wp), FastDiv(Hp));
-    rc = conv_launch(ctx, xp, N, Cin, H, W, wq, Cout, kh, kw, bias, yq, sh, sw, 1, 1, pt, pl, pt, pl, 1, scale, shift, resq,
-                     act, alpha, 6, pool);
+    rc = rowpack_pack(ctx, x, xp, N, Cin, H, W, kw, sw, pt, pl);
+    if (rc == PL_OK)
+        rc = conv_launch(ctx, xp, N, Cin, H, W, wq, Cout, kh, kw, bias, yq, sh, sw, 1, 1, pt, pl, pt, pl, 1, scale, shift, resq,
+                         act, alpha, 6, pool);
     pl_free(ctx, xp);            // stream-ordered
     return rc;
+}
+
+int pl_rowpack_input_elems(int N, int Cin, int H, int W, int kw, int sw, int pt, int pl, size_t *elems) {
+    PL_REQUIRE(elems && N >= 0 && Cin > 0 && Cin < 4 && H > 0 && W > 0 && kw > 0 && sw > 0 && pt >= 0 && pl >= 0, PL_EINVAL,
+               "pl_rowpack_input_elems: bad argument");
+    int Hp, Wp;
+    rowpack_geometry(N, Cin, H, W, kw, sw, pt, pl, Hp, Wp, *elems);
+    return PL_OK;
+}
+
+int pl_rowpack_input_f32(pl_ctx *ctx, const float *x, float *xp, int N, int Cin, int H, int W, int kw, int sw, int pt, int pl) {
+    PL_REQUIRE(ctx && x && xp, PL_EINVAL, "pl_rowpack_input_f32: null pointer");
+    PL_REQUIRE(N >= 0 && Cin > 0 && Cin < 4 && H > 0 && W > 0 && kw > 0 && sw > 0 && pt >= 0 && pl >= 0, PL_EINVAL,
+               "pl_rowpack_input_f32: bad shape (Cin must be 1..3)");
+    PL_REQUIRE((reinterpret_cast<uintptr_t>(xp) & 15u) == 0, PL_EINVAL, "pl_rowpack_input_f32: unaligned output");
+    if (N == 0) return PL_OK;
+    CtxGuard guard(ctx);
+    return rowpack_pack(ctx, x, xp, N, Cin, H, W, kw, sw, pt, pl);
+}
+
+int pl_conv2d_rowpacked_q4_f32(pl_ctx *ctx, const float *xp, int N, int Cin, int H, int W, const float *wq, int Cout, int kh,
+                               int kw, const float *bias, float *yq, int sh, int sw, int pt, int pl, const float *scale,
+                               const float *shift, const float *resq, int act, double alpha) {
+    int rc = rowpack_check(ctx, xp, N, Cin, H, W, wq, Cout, kh, kw, yq, sh, sw, pt, pl, resq);
+    if (rc != PL_OK) return rc;
+    if (N == 0) return PL_OK;
+    CtxGuard guard(ctx);
+    return conv_launch(ctx, xp, N, Cin, H, W, wq, Cout, kh, kw, bias, yq, sh, sw, 1, 1, pt, pl, pt, pl, 1, scale, shift, resq, act,
+                       alpha, 6, 0);
 }
 
 int pl_conv2d_rowpack_q4_f32(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const float *wq, int Cout, int kh,

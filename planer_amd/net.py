@@ -62,6 +62,16 @@ def prog_body(prog):
     return [(name, obj.name) for name, obj in prog.objs.items()]
 
 
+def _feed_static(ctx, dst, a, always=False):
+    """A new batch `a` (a device tensor) into a captured plan's static input `dst`, on `ctx`'s stream.  Where the plan's
+    only reader of that input is the row-packed stem conv (Net._capture, `dst.packed`), the batch is re-laid straight
+    into the packed image the graph reads -- that pass replaces the copy -- and the NCHW tensor is left alone."""
+    if dst.packed is not None:
+        _q4.pack_rows(dst, src_ptr=a.ptr, ctx=ctx)
+    elif always or a is not dst:
+        _lib.call("pl_d2d", ctx.handle, dst.ptr, a.ptr, dst.nbytes)
+
+
 class _Plan:
     """One captured forward pass for one input signature."""
 
@@ -77,8 +87,7 @@ class _Plan:
     def feed(self, xs):
         """Copy new inputs into the plan's static input buffers (on the plan's stream)."""
         for s, a in zip(self.inputs, xs):
-            if a is not s:
-                s.copy_from(a)
+            _feed_static(self.ctx, s, a)
 
     def launch(self, join=True):
         _lib.call("pl_graph_launch", self.graph)
@@ -123,7 +132,7 @@ class _MultiPlan:
         n = self.inputs[0].shape[0] // len(self.subs)
         for i, sp in enumerate(self.subs):
             for dst, a in zip(sp.inputs, xs):
-                _lib.call("pl_d2d", sp.ctx.handle, dst.ptr, a.rows(i * n, (i + 1) * n).ptr, dst.nbytes)
+                _feed_static(sp.ctx, dst, a.rows(i * n, (i + 1) * n), always=True)
 
     def launch(self, join=True):
         """join=True: fork from / join into the net's own stream (what Net.__call__ needs: inputs
@@ -172,7 +181,7 @@ class _PipelinePlan:
     def feed(self, xs):
         rp = self.replicas[self.turn]
         for dst, a in zip(rp.inputs, xs):
-            _lib.call("pl_d2d", rp.ctx.handle, dst.ptr, a.ptr, dst.nbytes)      # on the replica's stream
+            _feed_static(rp.ctx, dst, a, always=True)                           # on the replica's stream
 
     def launch(self, join=True):
         rp = self.replicas[self.turn]
@@ -825,6 +834,7 @@ class Net:
         for src, names, dst in prog.flow:
             if kinds.get(_as_list(names)[0]) in ("relu", "relu_q4", "flatten", "identity", "return"):
                 inplace.update(_as_list(src))
+        self._pack_static_inputs(prog, statics, inplace)
         _lib.call("pl_capture_begin", ctx.handle)
         try:
             fill()
@@ -850,6 +860,33 @@ class Net:
         plan.algos = algos
         return plan
 
+    def _pack_static_inputs(self, prog, statics, inplace):
+        """A graph input whose ONLY reader is the row-packed stem conv (w_layout 6, no fused pool) gets its row-packed image
+        as a persistent buffer beside it (`static.packed`): the captured conv reads that image, the re-layout kernel stays
+        out of the graph and runs when the plan is fed (`_feed_static`) -- as the copy that brings the batch in.
+        PLANER_HIP_FEED_PACK=0 keeps the re-layout inside the graph."""
+        if os.environ.get("PLANER_HIP_FEED_PACK", "1") == "0":
+            return
+        for k, s_ in zip(self.input, statics):
+            readers = [(src, names) for src, names, dst in prog.flow if k in _as_list(src)]
+            if len(readers) != 1 or k in inplace or s_.packed is not None or len(s_.shape) != 4 or s_.base is not None:
+                continue
+            src, names = readers[0]
+            obj = prog.objs[_as_list(names)[0]]
+            para = obj.para()
+            if (obj.name != "conv_q4" or para.get("w_layout") != 6 or para.get("pool") or _as_list(src)[0] != k
+                    or _as_list(src).count(k) != 1):
+                continue
+            kw = self._shape_of_init(_as_list(src)[1])[3]
+            strides, pads = para.get("strides", (1, 1)), para.get("pads", (0, 0, 0, 0))
+            _q4.pack_rows(s_, geom=(int(kw), int(strides[1]), int(pads[0]), int(pads[1])))
+
+    def _shape_of_init(self, key):
+        v = dict(zip(self.inits, self.weights)).get(key)
+        if v is None:
+            v = self._extra[key]
+        return v.shape
+
     def _replay(self, xs, private=True):
         plan = self.compile(*xs)
         if isinstance(plan, _PipelinePlan):
@@ -859,8 +896,11 @@ class Net:
             plan.feed(xs)
         else:
             for s, a in zip(plan.inputs, xs):      # on the main stream; launch() forks behind it
-                if a is not s:
-                    s.copy_from(a)
+                if isinstance(plan, _MultiPlan) or not isinstance(a, DeviceArray):
+                    if a is not s:
+                        s.copy_from(a)
+                else:
+                    _feed_static(self.ctx, s, a)
         plan.launch()
         out = plan.outputs
         if not private:                            # the caller copies to the host right away

@@ -179,6 +179,22 @@ def w1d_q4_eligible(k_shape, group=1, strides=(1, 1), dilations=(1, 1), pads=(0,
             and list(dilations) == [1, 1] and list(pads) == [1, 1, 1, 1])
 
 
+def pack_rows(x, geom=None, src_ptr=None, ctx=None):
+    """The row-packed (zero-padded NHWC) image the stem kernel reads (pl_rowpack_input_f32), kept BESIDE a plan's static
+    NCHW input `x` as `x.packed = (geom, image)`, geom = (kw, stride_w, pad_top, pad_left).  First call (geom given):
+    allocates the image and fills it from `x`.  Later calls re-fill it from `src_ptr` -- the batch a caller feeds the
+    plan -- on `ctx`'s stream: the re-layout then IS the copy into the plan, the NCHW tensor is not written."""
+    n, c, h, w = x.shape
+    if x.packed is None:
+        elems = ctypes.c_size_t()
+        _lib.call("pl_rowpack_input_elems", n, c, h, w, geom[0], geom[1], geom[2], geom[3], ctypes.byref(elems))
+        x.packed = (tuple(geom), empty((int(elems.value),), ctx=x.ctx))
+    g, img = x.packed
+    cx = ctx or x.ctx
+    _lib.call("pl_rowpack_input_f32", cx.handle, x.ptr if src_ptr is None else src_ptr, img.ptr, n, c, h, w, g[0], g[1], g[2], g[3])
+    return img
+
+
 def ConvQ4(xq, Kq, B=None, scale=None, shift=None, resq=None, group=1, strides=(1, 1),
            dilations=(1, 1), pads=(0, 0, 0, 0), act=ACT_NONE, alpha=0.0, w_layout=2, pool=False, **_):
     """layer.ConvFused on Q4 tensors: act((conv(x,K)+B)*scale + shift + res), all activations Q4.
@@ -208,6 +224,11 @@ def ConvQ4(xq, Kq, B=None, scale=None, shift=None, resq=None, group=1, strides=(
         y = _new_q4(n, cout, ho, wo, xq.ctx)
         if resq is not None and resq.shape != y.shape:
             raise ValueError("fused residual shape %s != conv output %s" % (resq.shape, y.shape))
+        if xq.packed is not None and xq.packed[0] == (kw, strides[1], pads[0], pads[1]):
+            # a plan's static input whose row-packed image is kept up to date by whoever feeds the plan (pack_rows)
+            _lib.call("pl_conv2d_rowpacked_q4_f32", xq.ctx.handle, xq.packed[1].ptr, n, cin, h, w, Kq.ptr, cout, kh, kw, _ptr(B),
+                      y.ptr, strides[0], strides[1], pads[0], pads[1], _ptr(scale), _ptr(shift), _ptr(resq), int(act), float(alpha))
+            return y
         _lib.call("pl_conv2d_rowpack_q4_f32", xq.ctx.handle, xq.ptr, n, cin, h, w, Kq.ptr, cout, kh, kw, _ptr(B), y.ptr,
                   strides[0], strides[1], pads[0], pads[1], _ptr(scale), _ptr(shift), _ptr(resq), int(act), float(alpha))
         return y

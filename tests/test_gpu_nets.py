@@ -127,6 +127,38 @@ def test_call_on_a_pipelined_plan_sees_each_new_input(pa, streams, monkeypatch):
         assert_close(net(x), ref(x.copy()), RTOL, "host call %d" % seed)
 
 
+@pytest.mark.parametrize("streams", ["1x1", "pipe2"])
+def test_feeding_a_plan_relays_the_batch_into_the_stem_image(pa, streams, monkeypatch):
+    """Where the row-packed stem conv is the only reader of a graph input, the plan keeps the packed image beside the
+    static input and `feed` re-lays each new batch straight into it (no copy + in-graph re-layout).  Same results, bit for
+    bit, as the plan that re-lays inside the graph (PLANER_HIP_FEED_PACK=0), for batches fed one after another."""
+    g, b = resnet18.build()
+    xs = [pa.asarray(resnet18.make_input(2, seed=70 + s, size=64)) for s in range(4)]
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("PLANER_HIP_FEED_PACK", flag)
+        net = pa.from_graph(g, b)
+        net.streams = streams
+        plan = net.compile(xs[0], mode="throughput")
+        statics = (plan.replicas[0] if hasattr(plan, "replicas") else plan).inputs
+        assert (statics[0].packed is not None) == (flag == "1")
+        got = []
+        for x in xs + xs[:2]:
+            plan.feed([x])
+            plan.launch(join=False)
+            held = plan.outputs
+            plan.join()
+            net.ctx.synchronize()
+            got.append((held[0] if isinstance(held, tuple) else held).get())
+        outs[flag] = got
+        y = net(xs[3])                                   # the latency path feeds the same way
+        np.testing.assert_array_equal((y[0] if isinstance(y, tuple) else y).get(), got[3])
+    for a, c in zip(outs["1"], outs["0"]):
+        np.testing.assert_array_equal(a, c)
+    np.testing.assert_array_equal(outs["1"][0], outs["1"][4])
+    assert not np.array_equal(outs["1"][0], outs["1"][1])
+
+
 @pytest.mark.parametrize("streams", ["pipe2", "pipe3", "auto"])
 def test_pipelined_batches_keep_their_own_results(pa, streams):
     """Throughput plans pipeline consecutive batches over several streams (one full-batch graph per
