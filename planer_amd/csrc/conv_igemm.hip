@@ -1201,9 +1201,13 @@ int conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const
                 return PL_OK;
             }
         }
+        // 16-byte stores through a wave-private LDS exchange (conv_smallcin_nchw_kernel<true>): PLANER_HIP_SMALLCIN_WIDE=0 / 1
+        const char *wide_env = getenv("PLANER_HIP_SMALLCIN_WIDE");        // read per call: tests switch it
+        const bool wide = (Ho * Wo) % 4 == 0 && (wide_env ? atoi(wide_env) != 0 : true);
         auto lds_for = [&](int t) {
             const int rows_max = (SC_PIX * t + Wo - 1) / Wo + 3;
-            return ((size_t)SC_MAXK * SC_CO + SC_CO + 4 + (size_t)Cin * rows_max * (W + 2)) * sizeof(float);
+            const size_t base = ((size_t)SC_MAXK * SC_CO + SC_CO + 4 + (size_t)Cin * rows_max * (W + 2) + 3) / 4 * 4;
+            return (base + (wide ? 4 * 256 : 0)) * sizeof(float);
         };
         while (tpw > 1 && lds_for(tpw) > 64 * 1024) --tpw;
         const size_t lds = lds_for(tpw);
@@ -1215,12 +1219,14 @@ int conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const
             sa.y_bytes = (int)(out_elems * 4);
             sa.HoWo = Ho * Wo; sa.Wp = W + 2; sa.K = Cin * 9; sa.steps = (sa.K + 1) / 2; sa.tpw = tpw;
             sa.divWo = FastDiv(Wo); sa.divK = FastDiv(sa.K);
-            int rc = ensure_lds_attr((const void *)conv_smallcin_nchw_kernel, 64 * 1024);
+            sa.xb_off = (int)(lds / sizeof(float)) - 4 * 256;
+            void (*kern)(const SmallCinArgs) = wide ? conv_smallcin_nchw_kernel<true> : conv_smallcin_nchw_kernel<false>;
+            int rc = ensure_lds_attr((const void *)kern, 64 * 1024);
             if (rc != PL_OK) return rc;
-            hipLaunchKernelGGL(conv_smallcin_nchw_kernel, dim3((unsigned)((tiles_img + tpw - 1) / tpw), (unsigned)co_blocks, (unsigned)N),
+            hipLaunchKernelGGL(kern, dim3((unsigned)((tiles_img + tpw - 1) / tpw), (unsigned)co_blocks, (unsigned)N),
                                dim3(256), lds, ctx->stream, sa);
             PL_LAUNCH_CHECK();
-            ctx->last_plan = "smallcin3x3 " + std::to_string(tpw) + "x256px x 64co";
+            ctx->last_plan = std::string(wide ? "smallcin3x3w " : "smallcin3x3 ") + std::to_string(tpw) + "x256px x 64co";
             ctx->last_gemm[0] = 1; ctx->last_gemm[1] = (long long)co_blocks * SC_CO;
             ctx->last_gemm[2] = (long long)N * tiles_img * SC_PIX; ctx->last_gemm[3] = (long long)sa.steps * 2;
             return PL_OK;

@@ -19,6 +19,7 @@ struct SmallCinArgs {
     int x_bytes, y_bytes;
     int HoWo, Wp, K, steps;          // Wp = W + 2: every staged row carries one zero column at each end
     int tpw;                         // 256-pixel tiles per workgroup (filter and input rows are staged once for all of them)
+    int xb_off;                      // WIDE: float offset of the waves' exchange buffers (4 x 256 floats, 16-byte aligned) in LDS
     FastDiv divWo, divK;
 };
 
@@ -78,6 +79,11 @@ __device__ __forceinline__ void sc_stage(const SmallCinArgs &p, float *As, float
     }
 }
 
+// WIDE: the output leaves through 16-byte stores.  In the MFMA's C layout a lane holds ONE pixel of 16 channels, so the plain
+// form stores 4 bytes per lane (a wave instruction = two 128-byte lines); here four accumulator registers at a time (8 channels
+// x 32 pixels) cross a wave-private 1 KB LDS buffer -- no workgroup barrier -- and come back as lane = (channel, pixel quad): a
+// wave instruction then writes eight full 128-byte lines, a quarter of the store instructions.  Needs Ho*Wo % 4 == 0.
+template <bool WIDE>
 __global__ void __launch_bounds__(256) conv_smallcin_nchw_kernel(const SmallCinArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;                         // [steps*2][64]   filter, k-major, zero padded
@@ -112,6 +118,7 @@ __global__ void __launch_bounds__(256) conv_smallcin_nchw_kernel(const SmallCinA
     struct TileAt {
         int pbase[2];
         int yoff[2];                 // byte offset of (channel co0, this lane's pixel) in y, out of range when masked
+        int yq[2];                   // WIDE: byte offset of (channel co0 + lane / 8, pixel quad lane % 8 of pixel block b)
         bool live;
     };
     constexpr int YOOB = (int)0x80000000;
@@ -130,6 +137,9 @@ __global__ void __launch_bounds__(256) conv_smallcin_nchw_kernel(const SmallCinA
             p.divWo.divmod((unsigned)(ok ? pix : p0), ho, wo);
             ta.pbase[b] = ((int)ho - r0) * p.Wp + (int)wo;   // staged (row ho-r0, column wo) = image (ho-pad, wo-pad)
             ta.yoff[b] = ok ? (int)((((unsigned)(n * p.Cout + co0)) * (unsigned)p.HoWo + (unsigned)pix) << 2) : YOOB;
+            const int pq = pt0 + wave * 64 + b * 32 + 4 * (lane & 7);
+            ta.yq[b] = (WIDE && ta.live && pq < p.HoWo)
+                           ? (int)((((unsigned)(n * p.Cout + co0 + (lane >> 3))) * (unsigned)p.HoWo + (unsigned)pq) << 2) : YOOB;
         }
         return ta;
     };
@@ -168,15 +178,47 @@ __global__ void __launch_bounds__(256) conv_smallcin_nchw_kernel(const SmallCinA
             }
         }
     };
+    // WIDE: group g = (channel block a, register quad j, pixel block b): registers 4j..4j+3 of acc[a][b] = channels
+    // 32a + 8j + (0..3) + 4 lhi x pixels 32b + l31
+    float *xb = smem + p.xb_off + wave * 256;
+    float bias_w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bias_w[i] = WIDE ? Bs[(i >> 2) * 32 + 8 * (i & 3) + (lane >> 3)] : 0.f;
+    auto exchange_wide = [&](const f32x16 (&acc)[2][2], int g) {
+        const int a = g >> 3, j = (g >> 1) & 3, b = g & 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xb[(q + 4 * lhi) * 32 + l31] = acc[a][b][4 * j + q];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        return *reinterpret_cast<const float4 *>(xb + lane * 4);
+    };
+    auto store_wide = [&](float4 v, const TileAt &ta, int g) {
+        const int a = g >> 3, j = (g >> 1) & 3, b = g & 1;
+        const int co = a * 32 + 8 * j + (lane >> 3);
+        if (p.bias) {
+            const float bv = bias_w[a * 4 + j];
+            v = make_float4(__fadd_rn(v.x, bv), __fadd_rn(v.y, bv), __fadd_rn(v.z, bv), __fadd_rn(v.w, bv));
+        }
+        const bool cok = co0 + co < p.Cout;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), yrsrc,
+                                               (cok && ta.yq[b] != YOOB) ? ta.yq[b] + (((a * 32 + 8 * j) * p.HoWo) << 2) : YOOB, 0, 0);
+    };
     f32x16 acc0[2][2], acc1[2][2];
     TileAt cur = locate(0), prev = cur;
     prev.live = false;
     auto run_tile = [&](f32x16 (&acc)[2][2], const f32x16 (&old)[2][2]) {       // tile `cur` into acc, tile `prev` out of old
         zero(acc);
+        float4 pend = make_float4(0.f, 0.f, 0.f, 0.f);        // WIDE: group s2 is exchanged now and stored one step later
 #pragma unroll
         for (int s2 = 0; s2 < SC_MAXK / 2; ++s2) {
             if (s2 < p.steps && cur.live) mma_step(acc, cur, s2);
-            if (s2 < 16 && prev.live) store_group(old, prev, s2);
+            if constexpr (WIDE) {
+                if (s2 >= 1 && s2 <= 16 && prev.live) store_wide(pend, prev, s2 - 1);
+                if (s2 < 16 && prev.live) pend = exchange_wide(old, s2);
+            } else {
+                if (s2 < 16 && prev.live) store_group(old, prev, s2);
+            }
         }
     };
     for (int t = 0; t <= p.tpw; t += 2) {

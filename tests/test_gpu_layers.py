@@ -305,9 +305,14 @@ def test_small_cin_producer_consumer_kernel_matches_oracle(pa, monkeypatch):
         y = pa.Conv2d(*args, pads=[pad] * 4).get()
         assert pa.hip.context().last_conv_plan().startswith("smallcin3x3pc"), pa.hip.context().last_conv_plan()
         monkeypatch.setenv("PLANER_HIP_SMALLCIN_PC", "0")
+        monkeypatch.setenv("PLANER_HIP_SMALLCIN_WIDE", "0")
         y1 = pa.Conv2d(*args, pads=[pad] * 4).get()
         assert pa.hip.context().last_conv_plan().startswith("smallcin3x3 ")
         np.testing.assert_array_equal(y, y1)             # same k order, same bias add
+        monkeypatch.delenv("PLANER_HIP_SMALLCIN_WIDE")   # default: 16-byte stores through the wave-private LDS exchange
+        y2 = pa.Conv2d(*args, pads=[pad] * 4).get()
+        assert pa.hip.context().last_conv_plan().startswith("smallcin3x3w ")
+        np.testing.assert_array_equal(y2, y1)
         if n * h * w <= 20000:
             assert_close(y, np.ascontiguousarray(onp.conv2d(x, k, b, pads=[pad] * 4)), RTOL, str((n, c, h, w, co)))
 
