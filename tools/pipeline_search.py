@@ -1,22 +1,36 @@
 """GPU: does the per-conv algorithm that wins in ISOLATION also win inside the pipelined throughput plan?
-Coordinate descent over Net._algo (conv shape signature -> w_layout): for every signature try every
-candidate algorithm, rebuild the three-stream plan and measure images/s; keep what is faster."""
-import os, sys, time
+Coordinate descent over the conv shape signatures of ResNet-18 at batch 32: for every signature try every candidate
+algorithm, rebuild the three-stream plan and measure images/s; keep what is faster by more than the noise (0.4 %), and
+confirm a winner with a second A/B pair.  A kernel that owns a fraction of the CUs for longer (the fused F(4x4,3x3) kernel
+on 128 workgroups) loses in isolation and can win here: the other streams' kernels take the rest of the chip.
+
+    python tools/pipeline_search.py [--write path/to/<stem>.algo.json]
+
+--write stores the picks that differ from the isolated ones in the file's "algo" table.
+
+Round-3 finding: the fused kernel on layer2 (128 workgroups) measures +1.2 % in one run and -15 % in the next of the same
+plan -- with a kernel that holds half the chip for 65 us the three streams fall into one of two phase patterns -- so the
+shipped database keeps the isolated picks, which repeat within 0.5 %."""
+import argparse, json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import planer_amd
 from planer_amd.irgen import resnet18
 
+ap = argparse.ArgumentParser()
+ap.add_argument("--write")
+ap.add_argument("--cands", default="2,8,7,9")
+args = ap.parse_args()
 ctx = planer_amd.hip.context()
 g, blob = resnet18.build()
 xs = [planer_amd.asarray(np.random.default_rng(1 + i).standard_normal((32, 3, 224, 224)).astype(np.float32), ctx=ctx) for i in range(2)]
 
 
-def measure(algo, steps=150):
+def measure(tp, steps=150):
     net = planer_amd.from_graph(g, blob)
     net.streams = os.environ.get("STREAMS", "pipe3")
-    net._algo_loaded = True
-    net._algo = dict(algo)
+    net._load_algo_cache()
+    net._algo.update(tp)
     plan = net.compile(xs[0], mode="throughput")
     best = 0.0
     for rep in range(3):
@@ -28,22 +42,44 @@ def measure(algo, steps=150):
             plan.feed([xs[i & 1]]); plan.launch(join=False)
         plan.join(); ctx.synchronize()
         best = max(best, 32 * steps / (time.perf_counter() - t0))
-    return best, dict(net._algo)
+    return best, {k: v for k, v in net._algo.items() if k[1][0] == 32 and len(k[2]) == 4 and k[2][2:] == (3, 3)}
 
 
-base, algo = measure({})
-print("isolated picks: %.0f img/s" % base, {k[1][1:3] + (k[3][3],): v for k, v in algo.items()}, flush=True)
-cur, cur_rate = dict(algo), base
-for sig in sorted(algo, key=repr):
-    for lay in (2, 5, 8, 4, 7):
-        if lay == cur[sig]:
+def short(sig):
+    return "C%d %dx%d res=%s" % (sig[1][1], sig[1][2], sig[1][3], sig[3][3])
+
+
+base, iso = measure({})
+print("isolated picks: %.0f img/s" % base, {short(k): v for k, v in iso.items()}, flush=True)
+cur, cur_rate = {}, base
+groups = {}
+for sig in iso:                               # the convs of one stage (same input and filter shape, any tail) move together
+    groups.setdefault((sig[1], sig[2]), []).append(sig)
+for shape in sorted(groups, key=repr):
+    sigs = groups[shape]
+    for lay in [int(v) for v in args.cands.split(",")]:
+        if all(lay == cur.get(sg, iso[sg]) for sg in sigs):
             continue
-        trial = dict(cur); trial[sig] = lay
+        trial = dict(cur)
+        trial.update({sg: lay for sg in sigs})
         try:
             rate, _ = measure(trial)
         except Exception as e:
-            print("  sig", sig[1], "lay", lay, "failed:", str(e)[:60]); continue
-        print("  C%d %dx%d res=%s: w_layout %d -> %d: %.0f img/s (%+.1f%%)" % (sig[1][1], sig[1][2], sig[1][3], sig[3][3], cur[sig], lay, rate, 100 * (rate / cur_rate - 1)), flush=True)
+            print("  %s w_layout %d failed: %s" % (short(sigs[0]), lay, str(e)[:60])); continue
+        print("  C%d %dx%d (%d tails): w_layout %s -> %d: %.0f img/s (%+.1f%%)" % (shape[0][1], shape[0][2], shape[0][3], len(sigs),
+              sorted({cur.get(sg, iso[sg]) for sg in sigs}), lay, rate, 100 * (rate / cur_rate - 1)), flush=True)
         if rate > cur_rate * 1.004:
-            cur, cur_rate = trial, rate
-print("after search: %.0f img/s (%+.1f%% over the isolated picks)" % (cur_rate, 100 * (cur_rate / base - 1)), {k[1][1:3] + (k[3][3],): v for k, v in cur.items()})
+            again, _ = measure(trial)
+            ref, _ = measure(cur)
+            print("     confirm: %.0f against %.0f img/s" % (again, ref), flush=True)
+            if again > ref * 1.004:
+                cur, cur_rate = trial, max(rate, again)
+cur = {k: v for k, v in cur.items() if v != iso[k]}
+print("after search: %.0f img/s (%+.1f%% over the isolated picks)" % (cur_rate, 100 * (cur_rate / base - 1)), {short(k): v for k, v in cur.items()})
+if args.write:
+    with open(args.write) as f:
+        db = json.load(f)
+    db.setdefault("algo", {}).update({repr(k): v for k, v in sorted(cur.items(), key=repr)})
+    with open(args.write, "w") as f:
+        json.dump(db, f, indent=1)
+    print("wrote", len(cur), "throughput picks to", args.write)
