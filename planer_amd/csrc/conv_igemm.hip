@@ -2102,6 +2102,7 @@ __global__ void __launch_bounds__(256) wino4_output_rows_q4_kernel(const float4 
 }
 
 #include "wino4_chain_kernel.h"
+#include "wino4_gemm_as_kernel.h"
 
 // ---- F(4x4,3x3) stage by stage.  winograd4_q4_launch below runs the three stages of ONE conv; the plan
 //      compiler (planer_amd/plan.py chain_winograd) calls the stages itself so that consecutive
@@ -2203,6 +2204,24 @@ int wino4_input_launch(pl_ctx *ctx, const float *xq, float *V, const WinoArgs &p
 }
 
 int wino4_gemm_launch(pl_ctx *ctx, const float *V, const float *Uq, float *M, const WinoArgs &p) {
+    // 128 input channels: the filter-stationary kernel (wino4_gemm_as_kernel.h).  PLANER_HIP_WINO_GEMM_AS=0 / 1 forces.
+    const char *as_env = getenv("PLANER_HIP_WINO_GEMM_AS");
+    const size_t v_bytes = (size_t)36 * p.C * p.T * 4, m_bytes = (size_t)36 * p.Cout * p.T * 4;
+    const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
+    if (p.C == 128 && p.Cout % 128 == 0 && v_bytes < (1ull << 31) && m_bytes < (1ull << 31) && ctx->conv_cfg < 0 &&
+        (as_env ? atoi(as_env) != 0 : (long long)36 * (p.Cout / 128) * ((p.T + 31) / 32) >= 2LL * cus)) {
+        Wino4GemmAsArgs a;
+        a.U = Uq; a.V = V; a.M = M; a.Cout = p.Cout; a.T = p.T;
+        const int nsub = (p.T + 31) / 32, fm = 36 * (p.Cout / 128);
+        a.nt = std::max(1, (int)(((long long)fm * nsub + cus - 1) / cus));       // one round of workgroups
+        a.wpf = (nsub + a.nt - 1) / a.nt;
+        a.u_bytes = (unsigned)((size_t)36 * 32 * p.Cout * 16); a.v_bytes = (unsigned)v_bytes; a.m_bytes = (unsigned)m_bytes;
+        hipLaunchKernelGGL(wino4_gemm_as_kernel, dim3((unsigned)(fm * a.wpf)), dim3(256), 0, ctx->stream, a);
+        PL_LAUNCH_CHECK();
+        ctx->last_plan = "wino4[as128x32 nt=" + std::to_string(a.nt) + " blocks=" + std::to_string(fm * a.wpf) + "]";
+        ctx->last_gemm[0] = 36; ctx->last_gemm[1] = p.Cout; ctx->last_gemm[2] = (long long)nsub * 32; ctx->last_gemm[3] = 128;
+        return PL_OK;
+    }
     int rc = conv_launch(ctx, V, 1, 36 * p.C, p.N * p.th, p.tw, Uq, 36 * p.Cout, 1, 1, nullptr, M, 1, 1, 1, 1, 0, 0, 0, 0, 36,
                          nullptr, nullptr, nullptr, PL_ACT_NONE, 0.0, 2);
     ctx->last_plan = "wino4[" + ctx->last_plan + "]";

@@ -293,6 +293,30 @@ def test_winograd_f43_matches_oracle(pa):
     assert worst < 3e-5                       # keep a 3x margin to the 1e-4 bar
 
 
+def test_winograd_f43_filter_stationary_gemm_matches_oracle(pa, monkeypatch):
+    """wino4_gemm_as_kernel (128 input channels: one frequency's filter block stays in LDS, V streams through): forced on
+    for a ragged column count (T = 11 x 49 = 539, not a multiple of the 32-column sub-tile), two 128-row blocks, a map
+    with tile padding, and the real layer2 shape at batch 8; against the oracle and against the tiled kernel (different
+    summation order: equal within 1e-5 of max|ref|)."""
+    from planer_amd import q4
+    rng = np.random.default_rng(41)
+    for (n, h, w, cout) in [(11, 26, 26, 128), (3, 13, 17, 256), (8, 28, 28, 128)]:
+        x = rng.standard_normal((n, 128, h, w)).astype(np.float32)
+        k = (rng.standard_normal((cout, 128, 3, 3)) * (2.0 / (9 * 128)) ** 0.5).astype(np.float32)
+        sc = rng.uniform(0.5, 1.5, (1, cout, 1, 1)).astype(np.float32)
+        sh = rng.standard_normal((1, cout, 1, 1)).astype(np.float32)
+        res = rng.standard_normal((n, cout, h, w)).astype(np.float32)
+        xq, U, rq = q4.to_q4(pa.asarray(x)), q4.prepare_winograd4_q4_weights(pa.asarray(k)), q4.to_q4(pa.asarray(res))
+        outs = {}
+        for flag in ("1", "0"):
+            monkeypatch.setenv("PLANER_HIP_WINO_GEMM_AS", flag)
+            outs[flag] = q4.from_q4(q4.ConvQ4(xq, U, None, pa.asarray(sc), pa.asarray(sh), rq, pads=[1, 1, 1, 1], act=1, w_layout=7)).get()
+            assert ("as128x32" in pa.hip.context().last_conv_plan()) == (flag == "1"), pa.hip.context().last_conv_plan()
+        ref = onp.relu(onp.batchnorm(np.ascontiguousarray(onp.conv2d(x, k, pads=[1, 1, 1, 1])), sc, sh) + res)
+        assert_close(outs["1"], ref, RTOL, "filter-stationary GEMM %s" % ((n, h, w, cout),))
+        assert np.abs(outs["1"] - outs["0"]).max() <= 1e-5 * np.abs(ref).max()
+
+
 def test_winograd_1d_f43_fused_matches_oracle(pa):
     """Fused 1-D Winograd F(4,3) along W (conv_w1d4_kernel): widths that are / are not multiples of 4,
     Cout not a multiple of 64 or 4, K tails, fused tail; error bar as for the 2-D F(4,3)."""

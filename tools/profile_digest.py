@@ -103,6 +103,8 @@ def expected_kernels(a):
     if plan.startswith("pair["):
         return ["conv_q4_pair_kernel"]
     plan = re.sub(r"^wino\d\[(.*)\]$", r"\1", plan) if algo == "direct" else plan
+    if plan.startswith("as128"):
+        return ["wino4_gemm_as_kernel"]      # filter-stationary GEMM stage of a 128-channel F(4x4,3x3) conv
     gemm = ["conv_ks_kernel" if "[k" in plan or plan.startswith("k") else "conv_q4_kernel" if "[q" in plan or plan.startswith("q") else "conv_pc_kernel" if "p" in plan.split()[0] else "conv_igemm_kernel"]
     if re.search(r"split=([2-9]|\d\d)", plan):
         gemm.append("reduce_tiles")
