@@ -153,8 +153,8 @@ def test_feeding_a_plan_relays_the_batch_into_the_stem_image(pa, streams, monkey
         outs[flag] = got
         y = net(xs[3])                                   # the latency path feeds the same way
         np.testing.assert_array_equal((y[0] if isinstance(y, tuple) else y).get(), got[3])
-    for a, c in zip(outs["1"], outs["0"]):
-        np.testing.assert_array_equal(a, c)
+    for a, c in zip(outs["1"], outs["0"]):               # (two nets: each times its own launch plans for these small shapes,
+        assert_close(a, c, 1e-5, "fed vs in-graph")      #  so split-K / algorithm picks -- the summation order -- may differ)
     np.testing.assert_array_equal(outs["1"][0], outs["1"][4])
     assert not np.array_equal(outs["1"][0], outs["1"][1])
 
