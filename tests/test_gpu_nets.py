@@ -130,8 +130,9 @@ def test_call_on_a_pipelined_plan_sees_each_new_input(pa, streams, monkeypatch):
 @pytest.mark.parametrize("streams", ["1x1", "pipe2"])
 def test_feeding_a_plan_relays_the_batch_into_the_stem_image(pa, streams, monkeypatch):
     """Where the row-packed stem conv is the only reader of a graph input, the plan keeps the packed image beside the
-    static input and `feed` re-lays each new batch straight into it (no copy + in-graph re-layout).  Same results, bit for
-    bit, as the plan that re-lays inside the graph (PLANER_HIP_FEED_PACK=0), for batches fed one after another."""
+    static input and `feed` re-lays each new batch straight into it (no copy + in-graph re-layout).  Same results as the
+    plan that re-lays inside the graph (PLANER_HIP_FEED_PACK=0) for batches fed one after another; re-feeding a batch
+    reproduces its result bit for bit."""
     g, b = resnet18.build()
     xs = [pa.asarray(resnet18.make_input(2, seed=70 + s, size=64)) for s in range(4)]
     outs = {}
