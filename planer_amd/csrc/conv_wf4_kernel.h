@@ -148,32 +148,6 @@ __device__ __forceinline__ void wf4_transform_row2(const float *P, float *V, int
     }
 }
 
-// row A of the 4x4 output tile of one channel quad: A^T over the frequency rows for each of the 6 frequency columns, then A^T
-// over the columns, fused tail, four 16-byte stores (the residual quads were requested before the first row started)
-template <int A>
-__device__ __forceinline__ void wf4_output_row(const Wf4Args &p, const f32x4 (&acc)[36], float4 bias, float4 scale, float4 shift,
-                                               const __amdgpu_buffer_rsrc_t yrsrc, const int (&off)[4], const float4 (&rsd)[4]) {
-    float4 s[6];
-#pragma unroll
-    for (int b = 0; b < 6; ++b) {
-        float4 m[6];
-#pragma unroll
-        for (int a = 0; a < 6; ++a) {
-            const f32x4 v = acc[a * 6 + b];
-            m[a] = make_float4(v[0], v[1], v[2], v[3]);
-        }
-        s[b] = w4_at4_row<A>(m);
-    }
-    float4 o[4];
-    w4_at4(s, o);
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const float4 v = apply_epilogue4(p.ep, bias, scale, shift, rsd[b], 4, o[b]);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
-                                               yrsrc, off[b], 0, PLANER_STORE_AUX);
-    }
-}
-
 // A^T m A on channel PAIRS (the accumulator's registers 0-1 and 2-3 are natural pairs): packed arithmetic throughout, the
 // operations and their order are those of w4_at4_row / w4_at4.
 template <int A>
@@ -201,10 +175,13 @@ __device__ __forceinline__ void wf4_at2(const wf4_v2 (&m)[6], wf4_v2 (&o)[4]) {
 // (and, for the residual, reads) 16 tiles x 4 pixels = one contiguous 1 KB run of a channel plane.  Scale and shift are applied
 // before the exchange (a lane knows its quad's parameters there), residual and ReLU after it: the same operations in the same
 // order on every value.
-template <int A, bool RES>
-__device__ __forceinline__ void wf4_output_row_coalesced(const f32x4 (&acc)[36], float4 scale, float4 shift, float4 *xb, int wr_cell,
-                                                         int rd_cell, const __amdgpu_buffer_rsrc_t yrsrc,
-                                                         const __amdgpu_buffer_rsrc_t rrsrc, const int (&off)[4]) {
+// PLAIN: that tail written straight (packed operations, no per-element option selects); otherwise the general fused tail in
+// the same two halves -- bias / scale / shift before the exchange, residual / activation / late residual after it.
+template <int A, bool RES, bool PLAIN>
+__device__ __forceinline__ void wf4_output_row_coalesced(const Wf4Args &p, const f32x4 (&acc)[36], int cqc, float4 scale,
+                                                         float4 shift, float4 *xb, int wr_cell, int rd_cell,
+                                                         const __amdgpu_buffer_rsrc_t yrsrc, const __amdgpu_buffer_rsrc_t rrsrc,
+                                                         const int (&off)[4]) {
     float4 rs[4];
     if constexpr (RES) {
 #pragma unroll
@@ -221,8 +198,10 @@ __device__ __forceinline__ void wf4_output_row_coalesced(const f32x4 (&acc)[36],
             s[b] = wf4_at_row2<A>(m);
         }
         wf4_at2(s, olo);
+        if constexpr (PLAIN) {
 #pragma unroll
-        for (int b = 0; b < 4; ++b) olo[b] = olo[b] * (wf4_v2){scale.x, scale.y} + (wf4_v2){shift.x, shift.y};
+            for (int b = 0; b < 4; ++b) olo[b] = olo[b] * (wf4_v2){scale.x, scale.y} + (wf4_v2){shift.x, shift.y};
+        }
     }
     {
         wf4_v2 s[6];
@@ -234,11 +213,29 @@ __device__ __forceinline__ void wf4_output_row_coalesced(const f32x4 (&acc)[36],
             s[b] = wf4_at_row2<A>(m);
         }
         wf4_at2(s, ohi);
+        if constexpr (PLAIN) {
 #pragma unroll
-        for (int b = 0; b < 4; ++b) ohi[b] = ohi[b] * (wf4_v2){scale.z, scale.w} + (wf4_v2){shift.z, shift.w};
+            for (int b = 0; b < 4; ++b) ohi[b] = ohi[b] * (wf4_v2){scale.z, scale.w} + (wf4_v2){shift.z, shift.w};
+        }
     }
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // (the general form fetches its quad's parameters here, row by row: twelve more registers held across the whole epilogue
+    //  would spill beside the 144 accumulators)
+    float4 gbias = z4, gscale = z4, gshift = z4;
+    if constexpr (!PLAIN) {
+        if (p.ep.bias) gbias = reinterpret_cast<const float4 *>(p.ep.bias)[cqc];
+        if (p.ep.scale) gscale = reinterpret_cast<const float4 *>(p.ep.scale)[cqc];
+        if (p.ep.shift) gshift = reinterpret_cast<const float4 *>(p.ep.shift)[cqc];
+    }
+    Epilogue affine = p.ep, rest = p.ep;          // the general tail's two halves (apply_epilogue4 skips what is null / 0)
+    affine.res = nullptr; affine.act = 0;
+    rest.bias = rest.scale = rest.shift = nullptr;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) xb[b * 68 + wr_cell] = make_float4(olo[b].x, olo[b].y, ohi[b].x, ohi[b].y);
+    for (int b = 0; b < 4; ++b) {
+        float4 o = make_float4(olo[b].x, olo[b].y, ohi[b].x, ohi[b].y);
+        if constexpr (!PLAIN) o = apply_epilogue4(affine, gbias, gscale, gshift, z4, 4, o);
+        xb[b * 68 + wr_cell] = o;
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -249,13 +246,18 @@ __device__ __forceinline__ void wf4_output_row_coalesced(const f32x4 (&acc)[36],
     __builtin_amdgcn_wave_barrier();                   // the next row overwrites the buffer
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        wf4_v2 lo = (wf4_v2){v[q].x, v[q].y}, hi = (wf4_v2){v[q].z, v[q].w};
-        if constexpr (RES) {
-            lo = lo + (wf4_v2){rs[q].x, rs[q].y};
-            hi = hi + (wf4_v2){rs[q].z, rs[q].w};
+        float4 o;
+        if constexpr (PLAIN) {
+            wf4_v2 lo = (wf4_v2){v[q].x, v[q].y}, hi = (wf4_v2){v[q].z, v[q].w};
+            if constexpr (RES) {
+                lo = lo + (wf4_v2){rs[q].x, rs[q].y};
+                hi = hi + (wf4_v2){rs[q].z, rs[q].w};
+            }
+            const wf4_v2 zl = lo * 0.f, zh = hi * 0.f;     // relu_ref: x > 0 ? x : x * 0
+            o = make_float4(lo.x > 0.f ? lo.x : zl.x, lo.y > 0.f ? lo.y : zl.y, hi.x > 0.f ? hi.x : zh.x, hi.y > 0.f ? hi.y : zh.y);
+        } else {
+            o = apply_epilogue4(rest, z4, z4, z4, RES ? rs[q] : z4, 4, v[q]);
         }
-        const wf4_v2 zl = lo * 0.f, zh = hi * 0.f;     // relu_ref: x > 0 ? x : x * 0
-        const float4 o = make_float4(lo.x > 0.f ? lo.x : zl.x, lo.y > 0.f ? lo.y : zl.y, hi.x > 0.f ? hi.x : zh.x, hi.y > 0.f ? hi.y : zh.y);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o),
                                                yrsrc, off[q], 0, PLANER_STORE_AUX);
     }
@@ -493,71 +495,47 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
         if (c + 1 < p.nchunks) kstep(std::integral_constant<int, 1>{}, c + 1);
     }
 
-    // ---- lane-local output transform + fused tail: this lane's tile and channel quad ----
-    const int oj = wn * 16 + li;
-    const int o_nb = oj >> lT, o_r = (oj >> LBC) & BRm, o_c = oj & BCm;
-    const int n = n0 + o_nb, ty = ty0 + o_r, tx = tx0 + o_c;
+    // ---- lane-local output transform; fused tail and stores through the wave's exchange buffer ----
     const int coq = (int)coutblk * 16 + wm * 4 + lk;
-    const bool cok = n < p.N && ty < p.th && tx < p.tw && coq < p.Coq;
     const int cqc = min(coq, p.Coq - 1);
     const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rrsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.ep.res), 0, p.ep.res ? p.y_bytes : 0u, 0x00020000);
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f), one4 = make_float4(1.f, 1.f, 1.f, 1.f);
-    const float4 bias = p.ep.bias ? reinterpret_cast<const float4 *>(p.ep.bias)[cqc] : z4;
-    const float4 scale = p.ep.scale ? reinterpret_cast<const float4 *>(p.ep.scale)[cqc] : one4;
-    const float4 shift = p.ep.shift ? reinterpret_cast<const float4 *>(p.ep.shift)[cqc] : z4;
-    const unsigned row0 = ((unsigned)(n * p.Coq + cqc) * (unsigned)p.H + (unsigned)(ty * 4)) * (unsigned)p.W + (unsigned)(tx * 4);
-    // the residual quads are requested two output rows at a time: two memory round trips per tile instead of four
-    // (all sixteen at once would not fit beside the 144 accumulator registers)
-    auto rows_pair = [&](auto first) {
-        constexpr int A0 = decltype(first)::value;
-        int off[2][4];
-        float4 rsd[2][4];
+    const bool plain = !p.ep.bias && p.ep.scale && p.ep.shift && p.ep.act == 1 && !(p.ep.res && p.ep.res_post);
+    const float4 scale = plain ? reinterpret_cast<const float4 *>(p.ep.scale)[cqc] : one4;      // the straight-line tail's
+    const float4 shift = plain ? reinterpret_cast<const float4 *>(p.ep.shift)[cqc] : z4;        // parameters, held in registers
+    // the tail is the same for the whole launch: scalar branches pick the straight-line form where it applies and whether a
+    // residual is fetched
+    float4 *xb = reinterpret_cast<float4 *>(As0) + wave * (4 * 68);      // the K loop is over: A0 is free (8 x 4.25 KB)
+    const int te = lane >> 2, be = lane & 3;
+    const int oj2 = wn * 16 + te;
+    const int n2 = n0 + (oj2 >> lT), ty2 = ty0 + ((oj2 >> LBC) & BRm), tx2 = tx0 + (oj2 & BCm);
+    const int x2 = tx2 * 4 + be, cq0 = (int)coutblk * 16 + wm * 4;
+    const bool ok2 = n2 < p.N && ty2 < p.th && tx2 < p.tw && x2 < p.W;
+    auto row = [&](auto first, auto res, auto pl) {
+        constexpr int A = decltype(first)::value;
+        const int yy = ty2 * 4 + A;
+        int off[4];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                off[a][b] = (cok && ty * 4 + A0 + a < p.H && tx * 4 + b < p.W) ? (int)((row0 + (unsigned)((A0 + a) * p.W + b)) << 4) : OOB;
-                rsd[a][b] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off[a][b], 0, 0));
-            }
-        wf4_output_row<A0>(p, acc, bias, scale, shift, yrsrc, off[0], rsd[0]);
-        wf4_output_row<A0 + 1>(p, acc, bias, scale, shift, yrsrc, off[1], rsd[1]);
+        for (int q = 0; q < 4; ++q)
+            off[q] = (ok2 && yy < p.H && cq0 + q < p.Coq)
+                         ? (int)((((unsigned)(n2 * p.Coq + cq0 + q) * (unsigned)p.H + (unsigned)yy) * (unsigned)p.W + (unsigned)x2) << 4) : OOB;
+        wf4_output_row_coalesced<A, decltype(res)::value, decltype(pl)::value>(p, acc, cqc, scale, shift, xb, lk * 16 + li,
+                                                                              be * 68 + te, yrsrc, rrsrc, off);
     };
-    // the tail is the same for the whole launch: one scalar branch picks the straight-line, coalesced form where it applies
-    const bool plain = !p.ep.bias && p.ep.scale && p.ep.shift && p.ep.act == 1;
-    if (plain && (!p.ep.res || !p.ep.res_post)) {
-        float4 *xb = reinterpret_cast<float4 *>(As0) + wave * (4 * 68);      // the K loop is over: A0 is free (8 x 4.25 KB)
-        const int t2 = lane >> 2, b2 = lane & 3;
-        const int oj2 = wn * 16 + t2;
-        const int n2 = n0 + (oj2 >> lT), ty2 = ty0 + ((oj2 >> LBC) & BRm), tx2 = tx0 + (oj2 & BCm);
-        const int x2 = tx2 * 4 + b2, cq0 = (int)coutblk * 16 + wm * 4;
-        const bool ok2 = n2 < p.N && ty2 < p.th && tx2 < p.tw && x2 < p.W;
-        auto row = [&](auto first, auto res) {
-            constexpr int A = decltype(first)::value;
-            constexpr bool RES = decltype(res)::value;
-            const int yy = ty2 * 4 + A;
-            int off[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                off[q] = (ok2 && yy < p.H && cq0 + q < p.Coq)
-                             ? (int)((((unsigned)(n2 * p.Coq + cq0 + q) * (unsigned)p.H + (unsigned)yy) * (unsigned)p.W + (unsigned)x2) << 4) : OOB;
-            wf4_output_row_coalesced<A, RES>(acc, scale, shift, xb, lk * 16 + li, b2 * 68 + t2, yrsrc, rrsrc, off);
-        };
-        if (p.ep.res) {
-            row(std::integral_constant<int, 0>{}, std::true_type{});
-            row(std::integral_constant<int, 1>{}, std::true_type{});
-            row(std::integral_constant<int, 2>{}, std::true_type{});
-            row(std::integral_constant<int, 3>{}, std::true_type{});
-        } else {
-            row(std::integral_constant<int, 0>{}, std::false_type{});
-            row(std::integral_constant<int, 1>{}, std::false_type{});
-            row(std::integral_constant<int, 2>{}, std::false_type{});
-            row(std::integral_constant<int, 3>{}, std::false_type{});
-        }
+    auto rows = [&](auto res, auto pl) {
+        row(std::integral_constant<int, 0>{}, res, pl);
+        row(std::integral_constant<int, 1>{}, res, pl);
+        row(std::integral_constant<int, 2>{}, res, pl);
+        row(std::integral_constant<int, 3>{}, res, pl);
+    };
+    if (plain) {
+        if (p.ep.res) rows(std::true_type{}, std::true_type{});
+        else rows(std::false_type{}, std::true_type{});
     } else {
-        rows_pair(std::integral_constant<int, 0>{});
-        rows_pair(std::integral_constant<int, 2>{});
+        if (p.ep.res) rows(std::true_type{}, std::false_type{});
+        else rows(std::false_type{}, std::false_type{});
     }
 }
 
