@@ -82,6 +82,9 @@ int pl_event_destroy(pl_event *ev);
 
 /* fork/join between two contexts (streams) of one device */
 int pl_stream_wait(pl_ctx *waiter, pl_ctx *signal);
+/* the waiter's stream waits for one recorded point of another stream (Net.submit: a pending result is handed to the
+ * caller's stream without waiting for what was queued behind it) */
+int pl_stream_wait_event(pl_ctx *waiter, pl_event *ev);
 
 /* whole-forward capture: the HIP-native replacement for interpreting the flow
  * in Python on every call (net.py:37-72).  Between begin/end every launch and

@@ -46,6 +46,7 @@ SIGNATURES = {
     "pl_event_elapsed_ms": [_P, _P, POINTER(c_float)],
     "pl_event_destroy": [_P],
     "pl_stream_wait": [_P, _P],
+    "pl_stream_wait_event": [_P, _P],
     "pl_capture_begin": [_P],
     "pl_capture_end": [_P, POINTER(_P)],
     "pl_graph_launch": [_P],

@@ -1364,10 +1364,13 @@ int pair_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const
     if (rc != PL_OK) return rc;
     rc = pair_conv_args(b, x, N, Cin, H, W, cb);
     if (rc != PL_OK) return rc;
-    TuneKey key = {{20, N, Cin, H, W, ca.Cout, ca.kh, ca.kw, ca.sh, ca.pt, cb.Cout, cb.kh, cb.kw, cb.sh, cb.pt,
+    // horizontal stride / pad ride in the high bits of the vertical ones (zero when equal: keys of square geometries are unchanged)
+    TuneKey key = {{20, N, Cin, H, W, ca.Cout, ca.kh, ca.kw, ca.sh + 1024 * (ca.sw - ca.sh), ca.pt + 1024 * (ca.pl - ca.pt), cb.Cout, cb.kh,
+                    cb.kw, cb.sh + 1024 * (cb.sw - cb.sh), cb.pt + 1024 * (cb.pl - cb.pt),
                     (ca.scale != nullptr) * 2 + (ca.bias != nullptr), (cb.scale != nullptr) * 2 + (cb.bias != nullptr), ca.act * 4 + cb.act}};
     int cfg = -1;
-    {
+    if (ctx->conv_cfg >= 0 && ctx->conv_cfg < kNumCfgs && kCfgs[ctx->conv_cfg].pair) cfg = ctx->conv_cfg;      // forced (tests, sweeps)
+    if (cfg < 0) {
         std::lock_guard<std::mutex> lk(g_tune_mu);
         auto it = g_tune.find({ctx->device, key});
         if (it != g_tune.end()) cfg = it->second.cfg;

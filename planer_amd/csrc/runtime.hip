@@ -280,6 +280,14 @@ int pl_stream_wait(pl_ctx *waiter, pl_ctx *signal) {
     return PL_OK;
 }
 
+int pl_stream_wait_event(pl_ctx *waiter, pl_event *ev) {
+    PL_REQUIRE(waiter && ev, PL_EINVAL, "pl_stream_wait_event: null argument");
+    PL_REQUIRE(waiter->device == ev->ctx->device, PL_EINVAL, "pl_stream_wait_event: event of another device");
+    CtxGuard g(waiter);
+    PL_HIP(hipStreamWaitEvent(waiter->stream, ev->ev, 0));
+    return PL_OK;
+}
+
 // ---- whole-forward capture ----------------------------------------------
 int pl_capture_begin(pl_ctx *ctx) {
     PL_REQUIRE(ctx, PL_EINVAL, "null ctx");

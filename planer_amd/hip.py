@@ -71,6 +71,10 @@ class Context:
         """Order this context's stream after everything already enqueued on `other`'s."""
         _lib.call("pl_stream_wait", self.handle, other.handle)
 
+    def wait_event(self, event):
+        """Order this context's stream after the point `event` recorded (on any stream of this device)."""
+        _lib.call("pl_stream_wait_event", self.handle, event.handle)
+
     def pool_stats(self):
         r, u = c_size_t(), c_size_t()
         _lib.call("pl_pool_stats", self.handle, byref(r), byref(u))
@@ -206,7 +210,14 @@ class DeviceArray:
             self._allocate()
             if self.host is not None and self.nbytes:
                 h = numpy.require(self.host, dtype=self.dtype, requirements="C")
-                _lib.call("pl_h2d", self.ctx.handle, self._p, h.ctypes.data, h.nbytes)
+                try:
+                    _lib.call("pl_h2d", self.ctx.handle, self._p, h.ctypes.data, h.nbytes)
+                except Exception:
+                    # the upload did not happen (e.g. NotCapturable during a stream capture): back to the lazy state, or
+                    # every later `.ptr` / `.get()` would hand out an allocated but never written block
+                    p, self._p, self._owned = self._p, None, False
+                    _lib.load().pl_free(self.ctx.handle, c_void_p(p))
+                    raise
         return self._p
 
     # -- numpy-like metadata ------------------------------------------------

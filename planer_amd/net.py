@@ -62,6 +62,14 @@ def prog_body(prog):
     return [(name, obj.name) for name, obj in prog.objs.items()]
 
 
+def graph_tag_of(layers, flow, init_shapes):
+    """crc32 over layer kinds and parameters, flow wiring and init shapes (Net.graph_tag)."""
+    import json
+    import zlib
+    text = json.dumps([layers, flow, [list(map(int, s)) for s in init_shapes]], sort_keys=True, default=repr)
+    return "%08x" % (zlib.crc32(text.encode()) & 0xffffffff)
+
+
 def _feed_static(ctx, dst, a, always=False):
     """A new batch `a` (a device tensor) into a captured plan's static input `dst`, on `ctx`'s stream.  Where the plan's
     only reader of that input is the row-packed stem conv (Net._capture, `dst.packed`), the batch is re-laid straight
@@ -199,6 +207,43 @@ class _PipelinePlan:
                 self.ctx.wait_for(rp.ctx)
 
 
+class Pending:
+    """Handle of a forward pass submitted with `Net.submit`: the pass runs on one of the net's replica streams while the
+    caller goes on (submits the next batch, prepares inputs).  `result()` hands the outputs to the net's own stream --
+    device arrays, private to this handle, ordered behind the pass (no host wait); `get()` returns host arrays.  Both
+    unwrap like `Net.__call__` (net.py:101)."""
+
+    def __init__(self, net, outs, event, to_host, final=False):
+        self.net, self._outs, self._event, self._to_host, self._final = net, outs, event, to_host, final
+
+    def done(self):
+        """Host-side wait for this pass alone (not for passes submitted after it)."""
+        if self._event is not None:
+            self._event.synchronize()
+        return self
+
+    def result(self):
+        if self._event is not None:
+            self.net.ctx.wait_event(self._event)
+            self.net._events.append(self._event)
+            self._event = None
+        rst = self._outs
+        if self._final:                               # Net.__call__ ran the pass (flows that cannot be captured): as it returned
+            return rst
+        if self._to_host:
+            rst = tuple(i.get() for i in rst) if isinstance(rst, tuple) else rst.get()
+        return rst[0] if len(rst) == 1 else rst
+
+    def get(self):
+        if self._final:
+            rst = self._outs
+            if isinstance(rst, tuple):
+                return tuple(i.get() if isinstance(i, DeviceArray) else i for i in rst)
+            return rst.get() if isinstance(rst, DeviceArray) else rst
+        self._to_host = True
+        return self.result()
+
+
 class Net:
     def __init__(self, ctx=None):
         self.weights, self.body, self.flow = [], [], []
@@ -214,12 +259,13 @@ class Net:
         # streams: how many sub-batch graphs a forward pass is fanned out to ("auto" measures 1/2/4)
         self.streams = os.environ.get("PLANER_HIP_STREAMS", "auto")
         self._side = []
+        self._events = []            # recycled stream markers of finished Pending handles (Net.submit)
         self.device_timer = {}       # kind -> ms of device time (profile mode)
         self.last_events = []        # [(layer name, kind, ms)] of the last profiled forward
         self._blob = None
         self._slots = []             # (offset, nbytes) per weight inside the blob
         self._program = None
-        self._eager_prog = None      # fused program for nets whose flow cannot be captured (Net.__call__)
+        self._eager_prog = {}        # input signature -> fused program, for nets whose flow cannot be captured (Net.__call__)
         self._plans = {}
         self._extra = {}             # derived constant tensors (tap-major / Winograd filters)
         self._algo = {}              # conv shape signature -> chosen w_layout
@@ -275,7 +321,7 @@ class Net:
             self._host[o:o + n] = raw[pos:pos + n]
             pos += n
         self._blob.set(self._host)
-        self._plans, self._extra, self._eager_prog = {}, {}, None
+        self._plans, self._extra, self._eager_prog = {}, {}, {}
 
     def weight_blob(self):
         """The single device allocation holding all weights (RCCL broadcast unit)."""
@@ -634,6 +680,11 @@ class Net:
             json.dump(data, f, indent=1)
         os.replace(tmp, path)
 
+    def graph_tag(self):
+        """A short structural hash of the loaded graph: stored stream-plan picks are keyed by it, so that another net with
+        the same input shape and step count cannot take them."""
+        return graph_tag_of(self.layer, self.flow, [w.shape for w in self.weights])
+
     def tune_source(self):
         """Where this net's kernel choices came from, for run reports: "shipped" (every launch plan, algorithm and
         stream plan was in the database shipped for this device), "cache", or what had to be measured."""
@@ -690,7 +741,7 @@ class Net:
         # a stream plan chosen for this (mode, inputs, graph) before -- shipped database or the user's cache -- is taken
         # without measuring, so that consecutive runs time the same thing
         self._load_algo_cache()
-        pick_key = repr((mode, [tuple(a.shape) for a in xs], len(self.flow), want))
+        pick_key = repr((mode, [tuple(a.shape) for a in xs], "%d:%s" % (len(self.flow), self.graph_tag()), want))
         stored = self._streams_pick.get(pick_key) if want == "auto" else None
         if stored and stored.startswith("pipe") and mode == "throughput":
             cands, pipes = [], [int(stored[4:])]
@@ -722,7 +773,7 @@ class Net:
                 except _NotSplittable:
                     continue
                 except _lib.NotCapturable:
-                    self._eager_prog = program_for(1)[0]      # Net.__call__ runs this one eagerly
+                    self._eager_prog[key[1:]] = program_for(1)[0]      # Net.__call__ runs this one eagerly
                     self.timer = timer
                     raise
             else:
@@ -910,6 +961,55 @@ class Net:
             return tuple(o.copy() if isinstance(o, DeviceArray) else o for o in out)
         return out.copy() if isinstance(out, DeviceArray) else out
 
+    def submit(self, *x):
+        """Asynchronous form of `net(x)` (net.py:94-101): enqueue one forward pass and return a `Pending` handle at once.
+        Consecutive submits rotate over the replicas of the throughput plan (R full-batch graphs on R streams,
+        `compile(mode="throughput")`), so one batch's tails and memory-bound layers run under the next one's convs --
+        a loop of submits reaches the rate `bench.py` reports for the plan API.  Each handle owns private copies of its
+        outputs (the replica's buffers are rewritten R submits later)."""
+        if type(x[0]) is dict:
+            x = [x[0][i] for i in self.input]
+        host = [isinstance(i, numpy.ndarray) for i in x]
+        xs = [hip.asarray(i, ctx=self.ctx) if b else i for i, b in zip(x, host)]
+        plan = None
+        if self.use_graph and not self.profile:
+            try:
+                plan = self.compile(*xs, mode="throughput")
+            except _lib.NotCapturable:
+                self.use_graph = False
+        if plan is None:                              # flows that need the host between kernels: run now, hand back a finished handle
+            return Pending(self, self(*x), None, any(host), final=True)
+        if isinstance(plan, _PipelinePlan):
+            rp = plan.replicas[plan.turn]
+            rp.ctx.wait_for(self.ctx)                 # the caller produced xs on the net's own stream
+            plan.feed(xs)
+            plan.launch(join=False)
+            cx, out = rp.ctx, rp.outputs
+        else:
+            plan.feed(xs)
+            plan.launch()
+            cx, out = self.ctx, plan.outputs
+        # private copies on the replica's stream, then the marker result() waits for
+        outs = tuple(o.copy() if isinstance(o, DeviceArray) else o for o in out) if isinstance(out, tuple) else out.copy()
+        ev = self._events.pop() if self._events else hip.Event(cx)      # a marker can be recorded on any stream of its device
+        _lib.call("pl_event_record", cx.handle, ev.handle)
+        return Pending(self, outs, ev, any(host))
+
+    def _eager_program(self, xs):
+        """The fused program for THESE input shapes (conv algorithms, Winograd chaining, row packing and the fusions are
+        all decided per shape, so a program fused for one image size must not run another): built on first sight of a
+        signature like a plan is, from an unfused pass that records every shape."""
+        sig = tuple((a.shape, str(a.dtype)) for a in xs)
+        prog = self._eager_prog.get(sig)
+        if prog is None:
+            shapes = {k: a.shape for k, a in zip(self.input, xs)}
+            shapes.update({k: w.shape for k, w in zip(self.inits, self.weights)})
+            timer = dict(self.timer)
+            self._interpret(self._program, [a.copy() for a in xs], shapes=shapes)     # ReLU works in place: copies
+            self.timer = timer
+            prog = self._eager_prog[sig] = self._fuse(shapes, self.use_fusion)[0]
+        return prog
+
     # ---- entry point ---------------------------------------------------------------------
     def __call__(self, *x, **key):
         """net.py:94-101."""
@@ -930,9 +1030,8 @@ class Net:
                 # step by step from here on
                 self.use_graph = graphable = False
         if not graphable:
-            eager = getattr(self, "_eager_prog", None)
-            if eager is not None and not key.get("debug") and not self.profile and all(isinstance(i, DeviceArray) for i in x):
-                rst = self._interpret(eager, list(x))
+            if self._eager_prog and not key.get("debug") and not self.profile and all(isinstance(i, DeviceArray) for i in x):
+                rst = self._interpret(self._eager_program(list(x)), list(x))
             else:
                 rst = self.forward(*x, **key)
         if need:

@@ -371,7 +371,8 @@ def pair_sibling_convs(body, flow, kshape=lambda key: None):
                     break                                   # the shared input is rewritten: later readers see other values
                 if srcs[0] in _as_list(kdst):
                     break
-                if k not in used and direct(k) and ks[0] == srcs[0]:
+                # the flow's LAST step defines the program's result (net.py:72): hoisting it would make another step last
+                if k not in used and k != len(steps) - 1 and i != len(steps) - 1 and direct(k) and ks[0] == srcs[0]:
                     p1, p2 = kinds[name][2], kinds[kname][2]
                     k1, k2 = kshape(srcs[1]), kshape(ks[1])
                     st1, st2 = [int(v) for v in p1.get("strides", (1, 1))], [int(v) for v in p2.get("strides", (1, 1))]

@@ -285,6 +285,84 @@ def test_postprocessing_flow_with_data_dependent_shapes(pa):
         assert_close(got[3], want[3], RTOL, "scatternd")
 
 
+def test_eager_fallback_rebuilds_its_program_for_a_new_input_shape(pa):
+    """A flow that cannot be captured (NonZero) runs its FUSED program eagerly; that program is specialised for the input
+    shapes it was fused for (conv algorithm picks, Winograd chaining, row packing), so a second image size must get a
+    program of its own -- detection nets are called with varying sizes (round-3 advisor finding)."""
+    rng = np.random.default_rng(11)
+    inits = [("K1", (rng.standard_normal((16, 8, 3, 3)) * 0.2).astype(np.float32)),
+             ("K2", (rng.standard_normal((16, 16, 3, 3)) * 0.2).astype(np.float32)),
+             ("thr", np.array([0.5], np.float32))]
+    conv = {"group": 1, "strides": [1, 1], "dilations": [1, 1], "pads": [1, 1, 1, 1]}
+    graph = {"input": ["x"], "inits": [[n, list(a.shape), str(a.dtype)] for n, a in inits],
+             "layers": [["c1", "conv", conv], ["r1", "relu", {}], ["c2", "conv", conv], ["sig", "sigmoid", {}],
+                        ["gt", "greater", {}], ["nz", "nonzero", {}], ["return", "return", {}]],
+             "flow": [[["x", "K1"], ["c1"], "a"], ["a", ["r1"], "b"], [["b", "K2"], ["c2"], "c"], ["c", ["sig"], "s"],
+                      [["s", "thr"], ["gt"], "m"], ["m", ["nz"], "nzi"], [["s", "nzi"], ["return"], "plrst"]]}
+    blob = np.concatenate([a.reshape(-1).view(np.uint8) for _, a in inits])
+    ref = onp.OracleNet()
+    ref.load_json(graph["input"], graph["inits"], graph["layers"], graph["flow"])
+    ref.load_weights(blob)
+    net = pa.from_graph(graph, blob)
+    for shape in ((1, 8, 12, 12), (2, 8, 40, 36), (1, 8, 12, 12), (1, 8, 64, 64)):
+        x = rng.standard_normal(shape).astype(np.float32)
+        want = ref(x.copy())
+        got = net(pa.hip.asarray(x, ctx=net.ctx))
+        assert net.use_graph is False
+        assert_close(got[0].get(), want[0], RTOL, "sigmoid map %s" % (shape,))
+        # positions may only differ where the sigmoid sits within rounding distance of the threshold
+        if np.abs(want[0] - 0.5).min() > 1e-5:
+            np.testing.assert_array_equal(got[1].get(), want[1])
+    assert len(net._eager_prog) == 3
+
+
+def test_submit_keeps_batches_in_flight_and_matches_call(pa):
+    """Net.submit = asynchronous net(x): handles of several batches in flight (more than the plan has replicas) each
+    hold their own batch's result, bit-identical to net(x); host arrays in -> host arrays out; the submit loop runs at
+    the plan API's rate (what bench.py times)."""
+    import time
+    g, b = resnet18.build()
+    net = pa.from_graph(g, b)
+    xs = [resnet18.make_input(8, size=64, seed=s) for s in range(7)]
+    ds = [pa.asarray(x) for x in xs]
+    want = [net(d).get() for d in ds]
+    hs = [net.submit(d) for d in ds]                      # 7 in flight over (at most) 3 replicas
+    got = [h.result() for h in reversed(hs)][::-1]        # consumed out of order
+    for i, (y, w) in enumerate(zip(got, want)):
+        assert isinstance(y, pa.hip.DeviceArray) and y.shape == w.shape
+        np.testing.assert_array_equal(y.get(), w, "batch %d" % i)
+    yh = net.submit(xs[3]).result()
+    assert isinstance(yh, np.ndarray)
+    np.testing.assert_array_equal(yh, want[3])
+    np.testing.assert_array_equal(net.submit({"x": ds[5]}).get(), want[5])
+    # rate at BASELINE's size (GPU-bound): a loop of submits against the plan API (feed + launch of the same plan)
+    ds = [pa.asarray(resnet18.make_input(32, seed=s)) for s in range(2)]
+    plan = net.compile(ds[0], mode="throughput")
+
+    def loop_plan(k):
+        for i in range(k):
+            plan.feed([ds[i & 1]])
+            plan.launch(join=False)
+        plan.join()
+        net.ctx.synchronize()
+
+    def loop_submit(k):
+        hs = [net.submit(ds[i & 1]) for i in range(k)]
+        hs[-1].done()
+        net.ctx.synchronize()
+    rates = {}
+    for name, loop in (("plan", loop_plan), ("submit", loop_submit)):
+        loop(50)
+        best = 0.0
+        for _ in range(3):
+            t0 = time.perf_counter()
+            loop(300)
+            best = max(best, 300 / (time.perf_counter() - t0))
+        rates[name] = best
+    print("passes/s: plan API %.0f, submit %.0f (%.2f)" % (rates["plan"], rates["submit"], rates["submit"] / rates["plan"]))
+    assert rates["submit"] >= 0.93 * rates["plan"]
+
+
 def test_two_host_threads_two_contexts(pa):
     """The library is thread-compatible: one context (stream + pool) per host thread, shared launch-plan cache behind a
     mutex, thread-local error text.  Two threads run different nets on their own contexts at the same time."""

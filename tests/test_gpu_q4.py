@@ -296,11 +296,11 @@ def test_winograd_f43_matches_oracle(pa):
 def test_winograd_f43_filter_stationary_gemm_matches_oracle(pa, monkeypatch):
     """wino4_gemm_as_kernel (128 input channels: one frequency's filter block stays in LDS, V streams through): forced on
     for a ragged column count (T = 11 x 49 = 539, not a multiple of the 32-column sub-tile), two 128-row blocks, a map
-    with tile padding, and the real layer2 shape at batch 8; against the oracle and against the tiled kernel (different
+    with tile padding, and the real layer2 shape at batch 8 and at batch 32 (what the bench runs); against the oracle and against the tiled kernel (different
     summation order: equal within 1e-5 of max|ref|)."""
     from planer_amd import q4
     rng = np.random.default_rng(41)
-    for (n, h, w, cout) in [(11, 26, 26, 128), (3, 13, 17, 256), (8, 28, 28, 128)]:
+    for (n, h, w, cout) in [(11, 26, 26, 128), (3, 13, 17, 256), (8, 28, 28, 128), (32, 28, 28, 128)]:
         x = rng.standard_normal((n, 128, h, w)).astype(np.float32)
         k = (rng.standard_normal((cout, 128, 3, 3)) * (2.0 / (9 * 128)) ** 0.5).astype(np.float32)
         sc = rng.uniform(0.5, 1.5, (1, cout, 1, 1)).astype(np.float32)

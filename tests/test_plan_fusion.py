@@ -349,10 +349,11 @@ def test_chain_winograd_leaves_other_convs_alone():
 def _fork_prog(stride=2, k2=(128, 64, 1, 1)):
     d2 = {"w_layout": 2, "strides": [stride, stride], "pads": [1, 1, 1, 1], "act": 1, "alpha": 0.0, "group": 1, "dilations": [1, 1]}
     dd = dict(d2, pads=[0, 0, 0, 0], act=0)
-    body = [["a", "conv_q4", d2], ["b", "conv_q4", {"w_layout": 7}], ["d", "conv_q4", dd]]
+    body = [["a", "conv_q4", d2], ["b", "conv_q4", {"w_layout": 7}], ["d", "conv_q4", dd], ["s", "add_q4", {}]]
     flow = [[["x", "Ka@q4g1", "None", "sa", "ta", "None"], ["a"], "ya"],
             [["ya", "Kb@wino4q4", "None", "sb", "tb", "None"], ["b"], "yb"],
-            [["x", "Kd@q4g1", "None", "sd", "td", "None"], ["d"], "yd"]]
+            [["x", "Kd@q4g1", "None", "sd", "td", "None"], ["d"], "yd"],
+            [["yb", "yd"], ["s"], "out"]]
     shapes = {"Ka": (128, 64, 3, 3), "Kb": (128, 128, 3, 3), "Kd": k2}
     return body, flow, (lambda key: shapes.get(key.split("@")[0]))
 
@@ -363,7 +364,7 @@ def test_pair_sibling_convs_merges_the_projection_pattern():
     b, f, n = pair_sibling_convs(body, flow, kshape)
     assert n == 1
     assert f[0] == [["x", "Ka@q4g1", "None", "sa", "ta", "Kd@q4g1", "None", "sd", "td"], ["a&d"], ["ya", "yd"]]
-    assert [names[0] for _, names, _ in f] == ["a&d", "b"]
+    assert [names[0] for _, names, _ in f] == ["a&d", "b", "s"]
     pair = [e for e in b if e[0] == "a&d"][0]
     assert pair[1] == "conv_q4_pair" and pair[2]["para1"]["act"] == 1 and pair[2]["para2"]["pads"] == [0, 0, 0, 0]
 
@@ -373,7 +374,11 @@ def test_pair_sibling_convs_leaves_other_forks_alone():
     for kw in (dict(stride=1), dict(k2=(128, 64, 3, 3))):                     # stride 1; two 3x3 convs
         body, flow, kshape = _fork_prog(**kw)
         b, f, n = pair_sibling_convs(body, flow, kshape)
-        assert n == 0 and [names[0] for _, names, _ in f] == ["a", "b", "d"]
+        assert n == 0 and [names[0] for _, names, _ in f] == ["a", "b", "d", "s"]
+    # the projection is the flow's LAST step (the program's result, net.py:72): hoisting it would make another step last
+    body, flow, kshape = _fork_prog()
+    b, f, n = pair_sibling_convs(body[:3], flow[:3], kshape)
+    assert n == 0 and [names[0] for _, names, _ in f] == ["a", "b", "d"]
     # an in-place ReLU on the shared input between the two convs: the second one must see the rewritten tensor
     body, flow, kshape = _fork_prog()
     body.insert(1, ["r", "relu_q4", {}])
