@@ -297,7 +297,7 @@ def test_winograd_f43_filter_stationary_gemm_matches_oracle(pa, monkeypatch):
     """wino4_gemm_as_kernel (128 input channels: one frequency's filter block stays in LDS, V streams through): forced on
     for a ragged column count (T = 11 x 49 = 539, not a multiple of the 32-column sub-tile), two 128-row blocks, a map
     with tile padding, and the real layer2 shape at batch 8 and at batch 32 (what the bench runs); against the oracle and against the tiled kernel (different
-    summation order: equal within 1e-5 of max|ref|)."""
+    summation order: equal within 3e-5 of max|ref|)."""
     from planer_amd import q4
     rng = np.random.default_rng(41)
     for (n, h, w, cout) in [(11, 26, 26, 128), (3, 13, 17, 256), (8, 28, 28, 128), (32, 28, 28, 128)]:
@@ -314,7 +314,9 @@ def test_winograd_f43_filter_stationary_gemm_matches_oracle(pa, monkeypatch):
             assert ("as128x32" in pa.hip.context().last_conv_plan()) == (flag == "1"), pa.hip.context().last_conv_plan()
         ref = onp.relu(onp.batchnorm(np.ascontiguousarray(onp.conv2d(x, k, pads=[1, 1, 1, 1])), sc, sh) + res)
         assert_close(outs["1"], ref, RTOL, "filter-stationary GEMM %s" % ((n, h, w, cout),))
-        assert np.abs(outs["1"] - outs["0"]).max() <= 1e-5 * np.abs(ref).max()
+        # two summation orders of F(4x4,3x3) (each within ~1.2e-5 of the oracle): 1.04e-5 apart at worst over the 3.2 M
+        # outputs of the batch-32 shape
+        assert np.abs(outs["1"] - outs["0"]).max() <= 3e-5 * np.abs(ref).max()
 
 
 def test_winograd_1d_f43_fused_matches_oracle(pa):
