@@ -644,6 +644,7 @@ __global__ void __launch_bounds__(256) permute_weights_kernel(const float *w, fl
 #include "conv_ks_kernel.h"
 #include "conv_pcg_kernel.h"
 #include "conv_smallcin_kernel.h"
+#include "conv_smallcin_valu_kernel.h"
 
 // ---- configurations ---------------------------------------------------------
 typedef Cfg<128, 128, 16, 2, 2> C128x128;
@@ -1161,6 +1162,51 @@ int conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const
     const char *sc_env = getenv("PLANER_HIP_SMALLCIN");
     const int sc_cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
     const bool sc_big = (long long)N * ((Ho * Wo + SC_PIX - 1) / SC_PIX) * ((Cout + SC_CO - 1) / SC_CO) >= 3LL * sc_cus;
+    // ... and, where output rows are whole pixel quads, the vector-ALU kernel of conv_smallcin_valu_kernel.h: no matrix
+    // instruction, 16-byte stores of contiguous 1 KB runs straight from the accumulators.  PLANER_HIP_SMALLCIN_VALU=0 / 1
+    // forces; PLANER_HIP_SCV_CPB = output channels per workgroup (8..64).
+    {
+        const char *scv_env = getenv("PLANER_HIP_SMALLCIN_VALU");
+        const long long quads = (long long)Ho * Wo / 4;
+        if (layout == 0 && kh == 3 && kw == 3 && sh == 1 && sw == 1 && dh == 1 && dw == 1 && group == 1 && Cin <= 4 && pt == pl &&
+            pt <= 1 && !scale && !shift && !res && act == PL_ACT_NONE && ctx->conv_cfg < 0 && out_elems < (1ull << 29) && Wo % 4 == 0 &&
+            (scv_env ? atoi(scv_env) != 0 : (sc_env ? atoi(sc_env) != 0 : sc_big))) {
+            const char *cpb_env = getenv("PLANER_HIP_SCV_CPB");
+            int cpb = cpb_env ? atoi(cpb_env) : 0;
+            if (cpb <= 0) {
+                // as many channels per workgroup as still leave 12 waves per CU -- one resident round at 3-4 waves per SIMD (the input
+                // window is re-read per channel block; measured on config 2: 64 / 32 / 16 / 8 channels = 29.2 / 28.7 / 29.2 / 32.3 us)
+                cpb = 64;
+                while (cpb > 8 && (long long)N * ((quads + 255) / 256) * ((Cout + cpb - 1) / cpb) * 4 < 12LL * sc_cus) cpb /= 2;
+            }
+            cpb = std::max(8, std::min(SCV_MAXC, (cpb + 7) / 8 * 8));
+            SmallCinValuArgs va;
+            va.x = x; va.w = w; va.bias = bias; va.y = y;
+            va.N = N; va.H = H; va.W = W; va.Cout = Cout; va.Ho = Ho; va.Wo = Wo;
+            va.quads = (int)quads; va.cpb = cpb;
+            va.x_bytes = (unsigned)(in_elems * 4); va.y_bytes = (unsigned)(out_elems * 4);
+            va.divQw = FastDiv(Wo / 4);
+            void (*kern)(const SmallCinValuArgs) = nullptr;
+            switch (Cin * 2 + pt) {
+            case 2: kern = conv_smallcin_valu_kernel<1, 0>; break;
+            case 3: kern = conv_smallcin_valu_kernel<1, 1>; break;
+            case 4: kern = conv_smallcin_valu_kernel<2, 0>; break;
+            case 5: kern = conv_smallcin_valu_kernel<2, 1>; break;
+            case 6: kern = conv_smallcin_valu_kernel<3, 0>; break;
+            case 7: kern = conv_smallcin_valu_kernel<3, 1>; break;
+            case 8: kern = conv_smallcin_valu_kernel<4, 0>; break;
+            default: kern = conv_smallcin_valu_kernel<4, 1>; break;
+            }
+            hipLaunchKernelGGL(kern, dim3((unsigned)((quads + 255) / 256), (unsigned)((Cout + cpb - 1) / cpb), (unsigned)N), dim3(256), 0,
+                               ctx->stream, va);
+            PL_LAUNCH_CHECK();
+            ctx->last_plan = "smallcin3x3valu 4px x " + std::to_string(cpb) + "co";
+            // (no MFMA: the extents describe the FMAs issued, padded channels included)
+            ctx->last_gemm[0] = 1; ctx->last_gemm[1] = (long long)((Cout + cpb - 1) / cpb) * cpb;
+            ctx->last_gemm[2] = (long long)N * ((quads + 255) / 256) * 1024; ctx->last_gemm[3] = Cin * 9;
+            return PL_OK;
+        }
+    }
     if (layout == 0 && kh == 3 && kw == 3 && sh == 1 && sw == 1 && dh == 1 && dw == 1 && group == 1 && Cin <= 4 &&
         pt == pl && pt <= 1 && !scale && !shift && !res && act == PL_ACT_NONE && ctx->conv_cfg < 0 && out_elems < (1ull << 29) &&
         (sc_env ? atoi(sc_env) != 0 : sc_big)) {
@@ -1168,39 +1214,6 @@ int conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const
         const int cus = sc_cus;
         const int tiles_img = (Ho * Wo + SC_PIX - 1) / SC_PIX, co_blocks = (Cout + SC_CO - 1) / SC_CO;
         int tpw = std::max(1, std::min(8, (int)((long long)tiles_img * co_blocks * N / (cus * 3 / 2))));
-        // producer/consumer variant (conv_smallcin_pc_kernel): one 512-thread workgroup per CU, MFMA waves and store waves
-        // (opt-in, PLANER_HIP_SMALLCIN_PC=1: 33.6 against 40 us for one launch, but 30.3 against 27.4 us per batch when three
-        //  streams pipeline -- a workgroup that owns its CU's LDS leaves the other streams nothing to interleave with)
-        const char *scp_env = getenv("PLANER_HIP_SMALLCIN_PC");
-        if ((Ho * Wo) % 4 == 0 && scp_env && atoi(scp_env) != 0) {
-            const long long total_tiles = (long long)tiles_img * co_blocks * N;
-            int t7 = (int)std::max<long long>(1, (total_tiles + cus - 1) / cus);          // one round of workgroups
-            auto lds_pc = [&](int t) {
-                const int rows_max = (SC_PIX * t + Wo - 1) / Wo + 3;
-                return ((size_t)SC_MAXK * SC_CO + SC_CO + 4 + 60 + 2 * SC_CO * SCP_PIX + 4 + (size_t)Cin * rows_max * (W + 2)) * sizeof(float);
-            };
-            while (t7 > 1 && lds_pc(t7) > 156 * 1024) --t7;
-            if (lds_pc(t7) <= 156 * 1024) {
-                SmallCinArgs sa;
-                sa.x = x; sa.w = w; sa.bias = bias; sa.y = y;
-                sa.N = N; sa.Cin = Cin; sa.H = H; sa.W = W; sa.Cout = Cout; sa.Ho = Ho; sa.Wo = Wo; sa.pad = pt;
-                sa.x_bytes = (int)(in_elems * 4);
-                sa.y_bytes = (int)(out_elems * 4);
-                sa.HoWo = Ho * Wo; sa.Wp = W + 2; sa.K = Cin * 9; sa.steps = (sa.K + 1) / 2; sa.tpw = t7;
-                sa.divWo = FastDiv(Wo); sa.divK = FastDiv(sa.K);
-                void (*kern)(const SmallCinArgs) = Cin == 1 ? conv_smallcin_pc_kernel<5> : Cin == 2 ? conv_smallcin_pc_kernel<9>
-                                                   : Cin == 3 ? conv_smallcin_pc_kernel<14> : conv_smallcin_pc_kernel<18>;
-                int rc = ensure_lds_attr((const void *)kern, 156 * 1024);
-                if (rc != PL_OK) return rc;
-                hipLaunchKernelGGL(kern, dim3((unsigned)((tiles_img + t7 - 1) / t7), (unsigned)co_blocks, (unsigned)N), dim3(512),
-                                   lds_pc(t7), ctx->stream, sa);
-                PL_LAUNCH_CHECK();
-                ctx->last_plan = "smallcin3x3pc " + std::to_string(t7) + "x256px x 64co";
-                ctx->last_gemm[0] = 1; ctx->last_gemm[1] = (long long)co_blocks * SC_CO;
-                ctx->last_gemm[2] = (long long)N * tiles_img * SC_PIX; ctx->last_gemm[3] = (long long)sa.steps * 2;
-                return PL_OK;
-            }
-        }
         // 16-byte stores through a wave-private LDS exchange (conv_smallcin_nchw_kernel<true>): PLANER_HIP_SMALLCIN_WIDE=0 / 1
         const char *wide_env = getenv("PLANER_HIP_SMALLCIN_WIDE");        // read per call: tests switch it
         const bool wide = (Ho * Wo) % 4 == 0 && (wide_env ? atoi(wide_env) != 0 : true);
@@ -2375,12 +2388,19 @@ int wf4_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const
     // against 51.4 us for register-staged operands with the waves in step, layer1 of ResNet-18 at batch 32); one instantiation
     // per block width, so that every patch read is base + immediate
     void (*kern)(const Wf4Args) = nullptr;
-    switch (lBC) {
-    case 4: kern = conv_wf4_kernel<true, false, true, 4>; break;
-    case 3: kern = conv_wf4_kernel<true, false, true, 3>; break;
-    case 2: kern = conv_wf4_kernel<true, false, true, 2>; break;
-    case 1: kern = conv_wf4_kernel<true, false, true, 1>; break;
-    default: kern = conv_wf4_kernel<true, false, true, 0>; break;
+    const char *sp_env = getenv("PLANER_HIP_WF4_SPREAD");
+    const bool spread = sp_env ? atoi(sp_env) != 0 : true;
+    switch (lBC * 2 + (spread ? 1 : 0)) {
+    case 9: kern = conv_wf4_kernel<true, false, true, 4, true>; break;
+    case 8: kern = conv_wf4_kernel<true, false, true, 4, false>; break;
+    case 7: kern = conv_wf4_kernel<true, false, true, 3, true>; break;
+    case 6: kern = conv_wf4_kernel<true, false, true, 3, false>; break;
+    case 5: kern = conv_wf4_kernel<true, false, true, 2, true>; break;
+    case 4: kern = conv_wf4_kernel<true, false, true, 2, false>; break;
+    case 3: kern = conv_wf4_kernel<true, false, true, 1, true>; break;
+    case 2: kern = conv_wf4_kernel<true, false, true, 1, false>; break;
+    case 1: kern = conv_wf4_kernel<true, false, true, 0, true>; break;
+    default: kern = conv_wf4_kernel<true, false, true, 0, false>; break;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), 0, ctx->stream, a);      // LDS: static (WF4_LDS_BYTES)
     PL_LAUNCH_CHECK();

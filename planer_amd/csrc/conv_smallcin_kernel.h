@@ -229,116 +229,3 @@ __global__ void __launch_bounds__(256) conv_smallcin_nchw_kernel(const SmallCinA
         if (!prev.live && !cur.live) break;
     }
 }
-
-// ---- the same convolution with the two streams on DIFFERENT waves ---------------------------------------------------
-// Measured on the kernel above: its MFMAs (12 us) and its 4-byte store stream (14 us) add up whatever their order in a
-// wave's instruction stream.  Here a 512-thread workgroup (one per CU) splits the roles: waves 0-3 multiply -- a
-// half tile of 128 pixels x 64 channels per step, 28 MFMAs per wave -- and park the result in LDS as [channel][pixel];
-// waves 4-7 drain the previous half tile: ds_read_b128 + bias + buffer_store_dwordx4, a wave instruction = two full
-// 512-byte runs of two channel planes (the 16-byte store pattern reaches 5.9 TB/s, tools/ubench/write_pattern.hip,
-// against 4.45 TB/s for 4-byte lanes).  One s_barrier per half tile hands a buffer over.  Needs Ho*Wo % 4 == 0
-// (16-byte aligned channel planes).  STEPS = ceil(K / 2) is a template parameter.
-constexpr int SCP_PIX = 128;                                  // pixels per pipeline unit (half of a 256-pixel tile)
-
-// Hand-over barrier of the producer/consumer kernel: LDS traffic must have landed (lgkmcnt), the global stores need
-// NOT -- __syncthreads() would also wait for vmcnt(0), i.e. drain the store stream every half tile (measured: 2.0 us
-// per unit = one HBM write latency, whatever the two sides did).
-__device__ __forceinline__ void sc_unit_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-template <int STEPS>
-__global__ void __launch_bounds__(512) conv_smallcin_pc_kernel(const SmallCinArgs p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *As = smem;                         // [steps*2][64]
-    float *Bs = smem + SC_MAXK * SC_CO;       // [64] bias + 4 zeros
-    float *Out = Bs + SC_CO + 4 + 60;         // [2][64][128] results on their way out (16-byte aligned: 2304+128 floats in)
-    float *Ps = Out + 2 * SC_CO * SCP_PIX + 4;   // staged input rows; Ps[-1] = 0 (K padding)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, lhi = lane >> 5;
-    const int n = blockIdx.z, co0 = blockIdx.y * SC_CO, pw0 = blockIdx.x * SC_PIX * p.tpw;
-    const int plast = min(pw0 + SC_PIX * p.tpw, p.HoWo) - 1;
-    const int r0 = (int)p.divWo.div((unsigned)pw0), r1 = (int)p.divWo.div((unsigned)plast);
-    const int rows = r1 - r0 + 3;
-    if (tid < 4) Ps[-4 + tid] = 0.f;
-    if (tid < 256) sc_stage(p, As, Bs, Ps, tid, n, co0, r0, rows);
-    const int units = 2 * p.tpw;
-    constexpr int YOOB = (int)0x80000000;
-    __syncthreads();
-    if (wave < 4) {
-        // ---------------- multiply: unit u -> Out[u & 1] ----------------
-        int koff[STEPS];
-#pragma unroll
-        for (int s = 0; s < STEPS; ++s) {
-            const int k = 2 * s + lhi;
-            const int c = k / 9, t = k - 9 * c, dy = t / 3, dx = t - 3 * dy;
-            koff[s] = (c * rows + dy) * p.Wp + dx;
-        }
-        const bool kpad = 2 * (STEPS - 1) + lhi >= p.K;
-        // the filter fragments are the same for every unit: 2 x STEPS registers, read once (one wave per SIMD multiplies
-        // here, so an LDS round trip in front of every MFMA pair would be fully exposed)
-        float a0r[STEPS], a1r[STEPS];
-#pragma unroll
-        for (int s = 0; s < STEPS; ++s) {
-            a0r[s] = As[(2 * s + lhi) * SC_CO + l31];
-            a1r[s] = As[(2 * s + lhi) * SC_CO + 32 + l31];
-        }
-        for (int u = 0; u <= units; ++u) {
-            if (u < units) {
-                const int pix = pw0 + u * SCP_PIX + wave * 32 + l31;
-                unsigned ho, wo;
-                p.divWo.divmod((unsigned)(pix < p.HoWo ? pix : pw0), ho, wo);
-                const int pbase = ((int)ho - r0) * p.Wp + (int)wo;
-                float bv[STEPS];                             // all of the unit's im2col values in flight together
-#pragma unroll
-                for (int s = 0; s < STEPS; ++s) {
-                    int i0 = pbase + koff[s];
-                    if (s == STEPS - 1) i0 = kpad ? -1 : i0;
-                    bv[s] = Ps[i0];
-                }
-                f32x16 acc[2];
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
-#pragma unroll
-                for (int s = 0; s < STEPS; ++s) {
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0r[s], bv[s], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1r[s], bv[s], acc[1], 0, 0, 0);
-                }
-                float *ob = Out + (u & 1) * (SC_CO * SCP_PIX) + wave * 32 + l31;
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        ob[(a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * SCP_PIX] = acc[a][r];
-            }
-            sc_unit_barrier();
-        }
-    } else {
-        // ---------------- drain: unit u - 1 from Out[(u - 1) & 1] ----------------
-        const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
-        const int sw = wave - 4;                             // 16 channels per store wave, two per instruction
-        const int px4 = (lane & 31) * 4, csel = lane >> 5;
-        typedef unsigned u4 __attribute__((__vector_size__(16)));
-        for (int u = 0; u <= units; ++u) {
-            if (u >= 1) {
-                const int pt0 = pw0 + (u - 1) * SCP_PIX;
-                const bool pok = pt0 + px4 < p.HoWo;         // HoWo % 4 == 0: a lane's four pixels are in or out together
-                const float *ib = Out + ((u - 1) & 1) * (SC_CO * SCP_PIX) + px4;
-                float4 v[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float4 *>(ib + (sw * 16 + 2 * i + csel) * SCP_PIX);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int co = sw * 16 + 2 * i + csel;
-                    const float bv = Bs[co];
-                    const float4 o = make_float4(__fadd_rn(v[i].x, bv), __fadd_rn(v[i].y, bv), __fadd_rn(v[i].z, bv), __fadd_rn(v[i].w, bv));
-                    const int off = (pok && co0 + co < p.Cout)
-                                        ? (int)((((unsigned)(n * p.Cout + co0 + co)) * (unsigned)p.HoWo + (unsigned)(pt0 + px4)) << 2) : YOOB;
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, p.bias ? o : v[i]), yrsrc, off, 0, 0);
-                }
-            }
-            sc_unit_barrier();
-        }
-    }
-}

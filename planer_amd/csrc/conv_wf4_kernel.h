@@ -267,8 +267,9 @@ __device__ __forceinline__ void wf4_output_row_coalesced(const Wf4Args &p, const
 // registers; PLANAR -- the patch is stored channel-planar (transform lanes = 16 tiles x 4 channels, tile fastest: conflict-free
 // patch reads AND 2-way instead of 4-way conflicts on the V writes) instead of as 16-byte cells (lanes channel fastest);
 // STAGGER -- waves 4-7 transform before their MFMAs and waves 0-3 after, so the two waves of a SIMD alternate on its matrix pipe.
-template <bool DMA_A, bool PLANAR, bool STAGGER, int LBC>
+template <bool DMA_A, bool PLANAR, bool STAGGER, int LBC, bool SPREAD_>
 __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
+    constexpr bool SPREAD = SPREAD_ && DMA_A && !PLANAR && STAGGER;
     constexpr int S = (1 << LBC) + 1;               // 16-byte cells per x phase: compile time, so every patch read is base + immediate
     // six separate LDS objects (not one dynamic array): the compiler orders LDS-DMA against later LDS accesses object by
     // object, so a DMA into A1 / P0 does not hold up the reads of A0 / P1 / V0 and the writes of V1
@@ -358,6 +359,21 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
                     areg[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ursrc, (it * 512 + tid) << 4, soff, 0));
             }
     };
+    // one piece (1 KB per wave) of the next filter slice / of the patch after next: the K step issues them BETWEEN its MFMA
+    // groups, so that the ~100 issue cycles an LDS-DMA instruction costs a wave are spent while its SIMD partner's MFMAs
+    // keep the matrix pipe busy (all seven in a row before the first MFMA left the pipe idle at the head of every step)
+    auto load_a_piece = [&](int c, int buf, int it) {
+        const int soff = (int)(((unsigned)coutblk * (unsigned)p.nchunks + (unsigned)c) * (unsigned)(WF4_A_FLOATS * 4));
+        float *Ab = buf ? As1 : As0;
+        if (it < 4 || wave < 4)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ursrc, (lds_float *)(Ab + (it * 512 + tid - lane) * 4), 16, (it * 512 + tid) << 4, soff, 0, 0);
+    };
+    auto load_p_piece = [&](int c, int buf, int ps) {
+        const int soff = (c * HW) << 4;
+        float *Pb = buf ? Ps1 : Ps0;
+        if (ps * 512 < p.cells && ps * 512 + tid < p.cells)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_float *)(Pb + (ps * 512 + tid - lane) * 4), 16, pvoff[ps], soff, 0, 0);
+    };
     auto store_a = [&](int buf) {
         if constexpr (!DMA_A) {
             float *Ab = buf ? As1 : As0;
@@ -429,7 +445,9 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
     for (int f = 0; f < 36; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int a_off = ((wm * 4 + lk) * 16 + li) * 36;      // this lane's 36 frequencies of A[k = lk][channel 16 wm + li]
     const int b_off = ((wn * 4 + lk) * 16 + li) * 36;      // ... of V[k = lk][tile 16 wn + li]
-    auto mma = [&](int buf) {
+    // spread: the LDS-DMA requests of chunk c + 1's filter slice (into A[buf ^ 1]) and chunk c + 2's patch (into P[buf]) go
+    // out one per MFMA group
+    auto mma = [&](int buf, int c, bool more, bool more2, auto spread) {
         const float4 *Ap = reinterpret_cast<const float4 *>((buf ? As1 : As0) + a_off);
         const float4 *Vp = reinterpret_cast<const float4 *>((buf ? Vs1 : Vs0) + b_off);
         // three rotating fragment slots, requested two groups (8 MFMAs) ahead; the scheduling barriers keep that distance
@@ -448,6 +466,14 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
             acc[4 * g + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[4 * g + 2], 0, 0, 0);
             acc[4 * g + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[4 * g + 3], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (decltype(spread)::value && DMA_P) {
+                if (g < 5) {
+                    if (more) load_a_piece(c + 1, buf ^ 1, g);
+                } else if (g < 5 + WF4_P_PASSES) {
+                    if (more2) load_p_piece(c + 2, buf, g - 5);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     };
 
@@ -473,14 +499,18 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
             // ago; an LDS-DMA instruction holds a wave's issue slot ~100 cycles, seven of them would delay the transform
             // their MFMAs wait for): 38.2 -> 37.6 us
             if (more) transform_first(nxt, nxt);
-            if (more) load_a(c + 1, nxt);
-            if (more2) load_p(c + 2, cur);
-            mma(cur);
+            if constexpr (SPREAD) {
+                mma(cur, c, more, more2, std::true_type{});
+            } else {
+                if (more) load_a(c + 1, nxt);
+                if (more2) load_p(c + 2, cur);
+                mma(cur, c, more, more2, std::false_type{});
+            }
             if (more) transform_last(nxt, nxt);
         } else {
             if (more) load_a(c + 1, nxt);
             if (more2) load_p(c + 2, cur);
-            mma(cur);
+            mma(cur, c, more, more2, std::false_type{});
             if (more) {
                 transform_first(nxt, nxt);
                 transform_last(nxt, nxt);
@@ -539,9 +569,9 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
     }
 }
 
-template <bool DMA_A, bool PLANAR, bool STAGGER, int LBC>
+template <bool DMA_A, bool PLANAR, bool STAGGER, int LBC, bool SPREAD>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) conv_wf4_kernel(const Wf4Args p) {
-    conv_wf4_body<DMA_A, PLANAR, STAGGER, LBC>(p);
+    conv_wf4_body<DMA_A, PLANAR, STAGGER, LBC, SPREAD>(p);
 }
 
 // filter: OIHW 3x3 -> u[cout block][chunk][cb][kk][i][f] = (G g G^T)[f] of channel (64 blk + 16 cb + i, 4 chunk + kk); zero beyond Cout

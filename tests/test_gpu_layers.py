@@ -278,6 +278,7 @@ def test_small_cin_store_stream_kernel_matches_oracle(pa, monkeypatch):
     """conv_smallcin_nchw_kernel (forced here with PLANER_HIP_SMALLCIN=1; by default it serves big outputs only): 3x3 / stride 1 on 1..4 input channels, the
     BASELINE config-2 shape class -- ragged widths, pad 0 / 1, channel counts that are not multiples of 64."""
     monkeypatch.setenv("PLANER_HIP_SMALLCIN", "1")
+    monkeypatch.setenv("PLANER_HIP_SMALLCIN_VALU", "0")      # (the vector-ALU kernel would take the shapes with Wo % 4 == 0)
     rng = np.random.default_rng(77)
     for n, c, h, w, co, pad, bias in [(2, 3, 9, 11, 20, 1, True), (1, 1, 5, 300, 70, 0, False), (3, 4, 17, 16, 64, 1, True),
                                       (2, 2, 40, 7, 130, 1, True), (2, 3, 64, 64, 64, 1, True)]:
@@ -289,32 +290,36 @@ def test_small_cin_store_stream_kernel_matches_oracle(pa, monkeypatch):
         assert_close(y.get(), np.ascontiguousarray(onp.conv2d(x, k, b, pads=[pad] * 4)), RTOL, str((n, c, h, w, co)))
 
 
-def test_small_cin_producer_consumer_kernel_matches_oracle(pa, monkeypatch):
-    """conv_smallcin_pc_kernel (opt-in, PLANER_HIP_SMALLCIN_PC=1): MFMA waves and store waves of one 512-thread
-    workgroup hand half tiles over through LDS; maps whose Ho*Wo is a multiple of 4, every Cin 1..4, ragged channel
-    counts, several tiles per workgroup, bias / no bias; config 2 at full size bit-equal to the one-role kernel."""
-    monkeypatch.setenv("PLANER_HIP_SMALLCIN", "1")
+def test_small_cin_vector_alu_kernel_matches_oracle(pa, monkeypatch):
+    """conv_smallcin_valu_kernel (the default for big outputs whose rows are whole pixel quads; forced here): no MFMA, a lane =
+    4 pixels x 8 channels, filter broadcast from LDS.  Every Cin 1..4, pad 0 / 1, channel counts that are not multiples of
+    8 or of the workgroup's channel block, quad counts that are not multiples of 256, every channels-per-workgroup setting,
+    bias / no bias; config 2 at full size against the oracle and against the MFMA store-stream kernel (same k order: equal
+    within rounding of the different FMA grouping -- both are single fmaf chains, so bit-equal)."""
+    monkeypatch.setenv("PLANER_HIP_SMALLCIN_VALU", "1")
     rng = np.random.default_rng(78)
-    for n, c, h, w, co, pad, bias in [(3, 4, 17, 16, 64, 1, True), (2, 2, 40, 7, 130, 1, True), (2, 3, 64, 64, 64, 1, False),
-                                      (1, 1, 6, 302, 70, 0, True), (3, 3, 50, 46, 20, 1, True), (8, 3, 224, 224, 64, 1, True)]:
+    for n, c, h, w, co, pad, bias in [(3, 4, 17, 16, 64, 1, True), (2, 2, 40, 8, 130, 1, True), (2, 3, 64, 64, 64, 1, False),
+                                      (1, 1, 6, 302, 70, 0, True), (3, 3, 50, 44, 20, 1, True), (2, 3, 9, 14, 5, 0, True),
+                                      (8, 3, 224, 224, 64, 1, True)]:
         x = rng.standard_normal((n, c, h, w)).astype(np.float32)
         k = (rng.standard_normal((co, c, 3, 3)) * 0.1).astype(np.float32)
         b = rng.standard_normal(co).astype(np.float32) if bias else None
         args = (pa.asarray(x), pa.asarray(k), pa.asarray(b) if bias else None)
-        monkeypatch.setenv("PLANER_HIP_SMALLCIN_PC", "1")
-        y = pa.Conv2d(*args, pads=[pad] * 4).get()
-        assert pa.hip.context().last_conv_plan().startswith("smallcin3x3pc"), pa.hip.context().last_conv_plan()
-        monkeypatch.setenv("PLANER_HIP_SMALLCIN_PC", "0")
-        monkeypatch.setenv("PLANER_HIP_SMALLCIN_WIDE", "0")
-        y1 = pa.Conv2d(*args, pads=[pad] * 4).get()
-        assert pa.hip.context().last_conv_plan().startswith("smallcin3x3 ")
-        np.testing.assert_array_equal(y, y1)             # same k order, same bias add
-        monkeypatch.delenv("PLANER_HIP_SMALLCIN_WIDE")   # default: 16-byte stores through the wave-private LDS exchange
-        y2 = pa.Conv2d(*args, pads=[pad] * 4).get()
-        assert pa.hip.context().last_conv_plan().startswith("smallcin3x3w ")
-        np.testing.assert_array_equal(y2, y1)
-        if n * h * w <= 20000:
-            assert_close(y, np.ascontiguousarray(onp.conv2d(x, k, b, pads=[pad] * 4)), RTOL, str((n, c, h, w, co)))
+        ref = np.ascontiguousarray(onp.conv2d(x, k, b, pads=[pad] * 4))
+        first = None
+        for cpb in ("", "8", "16", "64"):
+            monkeypatch.setenv("PLANER_HIP_SCV_CPB", cpb) if cpb else monkeypatch.delenv("PLANER_HIP_SCV_CPB", raising=False)
+            y = pa.Conv2d(*args, pads=[pad] * 4).get()
+            assert pa.hip.context().last_conv_plan().startswith("smallcin3x3valu"), pa.hip.context().last_conv_plan()
+            assert_close(y, ref, RTOL, str((n, c, h, w, co, cpb)))
+            first = y if first is None else first
+            np.testing.assert_array_equal(y, first)       # the channel blocking does not change a value
+    monkeypatch.delenv("PLANER_HIP_SCV_CPB", raising=False)
+    monkeypatch.setenv("PLANER_HIP_SMALLCIN_VALU", "0")
+    monkeypatch.setenv("PLANER_HIP_SMALLCIN", "1")
+    y1 = pa.Conv2d(*args, pads=[1] * 4).get()
+    assert pa.hip.context().last_conv_plan().startswith("smallcin3x3w "), pa.hip.context().last_conv_plan()
+    np.testing.assert_array_equal(first, y1)
 
 
 def test_sorting_and_data_dependent_ops_edge_cases(pa):
