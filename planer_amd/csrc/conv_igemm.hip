@@ -2388,19 +2388,12 @@ int wf4_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const
     // against 51.4 us for register-staged operands with the waves in step, layer1 of ResNet-18 at batch 32); one instantiation
     // per block width, so that every patch read is base + immediate
     void (*kern)(const Wf4Args) = nullptr;
-    const char *sp_env = getenv("PLANER_HIP_WF4_SPREAD");
-    const bool spread = sp_env ? atoi(sp_env) != 0 : true;
-    switch (lBC * 2 + (spread ? 1 : 0)) {
-    case 9: kern = conv_wf4_kernel<true, false, true, 4, true>; break;
-    case 8: kern = conv_wf4_kernel<true, false, true, 4, false>; break;
-    case 7: kern = conv_wf4_kernel<true, false, true, 3, true>; break;
-    case 6: kern = conv_wf4_kernel<true, false, true, 3, false>; break;
-    case 5: kern = conv_wf4_kernel<true, false, true, 2, true>; break;
-    case 4: kern = conv_wf4_kernel<true, false, true, 2, false>; break;
-    case 3: kern = conv_wf4_kernel<true, false, true, 1, true>; break;
-    case 2: kern = conv_wf4_kernel<true, false, true, 1, false>; break;
-    case 1: kern = conv_wf4_kernel<true, false, true, 0, true>; break;
-    default: kern = conv_wf4_kernel<true, false, true, 0, false>; break;
+    switch (lBC) {
+    case 4: kern = conv_wf4_kernel<true, false, true, 4>; break;
+    case 3: kern = conv_wf4_kernel<true, false, true, 3>; break;
+    case 2: kern = conv_wf4_kernel<true, false, true, 2>; break;
+    case 1: kern = conv_wf4_kernel<true, false, true, 1>; break;
+    default: kern = conv_wf4_kernel<true, false, true, 0>; break;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), 0, ctx->stream, a);      // LDS: static (WF4_LDS_BYTES)
     PL_LAUNCH_CHECK();

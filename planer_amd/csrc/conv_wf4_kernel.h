@@ -267,9 +267,11 @@ __device__ __forceinline__ void wf4_output_row_coalesced(const Wf4Args &p, const
 // registers; PLANAR -- the patch is stored channel-planar (transform lanes = 16 tiles x 4 channels, tile fastest: conflict-free
 // patch reads AND 2-way instead of 4-way conflicts on the V writes) instead of as 16-byte cells (lanes channel fastest);
 // STAGGER -- waves 4-7 transform before their MFMAs and waves 0-3 after, so the two waves of a SIMD alternate on its matrix pipe.
-template <bool DMA_A, bool PLANAR, bool STAGGER, int LBC, bool SPREAD_>
+template <bool DMA_A, bool PLANAR, bool STAGGER, int LBC>
 __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
-    constexpr bool SPREAD = SPREAD_ && DMA_A && !PLANAR && STAGGER;
+    // the LDS-DMA requests of a step go out one per MFMA group (measured: 40.9 -> 39.8 us per layer1 conv against all seven
+    // in a row at the head of the step)
+    constexpr bool SPREAD = DMA_A && !PLANAR && STAGGER;
     constexpr int S = (1 << LBC) + 1;               // 16-byte cells per x phase: compile time, so every patch read is base + immediate
     // six separate LDS objects (not one dynamic array): the compiler orders LDS-DMA against later LDS accesses object by
     // object, so a DMA into A1 / P0 does not hold up the reads of A0 / P1 / V0 and the writes of V1
@@ -520,6 +522,9 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
         if (more2) store_p(cur);
         __syncthreads();
     };
+    // static priority for the waves that multiply first (0-3; their SIMD partners 4-7 open every step with the patch
+    // transform): 39.2 -> 38.5-38.8 us per layer1 conv; the other half at priority 1 instead: 41.3 us
+    if (wave < 4) __builtin_amdgcn_s_setprio(1);
     for (int c = 0; c < p.nchunks; c += 2) {
         kstep(std::integral_constant<int, 0>{}, c);
         if (c + 1 < p.nchunks) kstep(std::integral_constant<int, 1>{}, c + 1);
@@ -569,9 +574,9 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
     }
 }
 
-template <bool DMA_A, bool PLANAR, bool STAGGER, int LBC, bool SPREAD>
+template <bool DMA_A, bool PLANAR, bool STAGGER, int LBC>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) conv_wf4_kernel(const Wf4Args p) {
-    conv_wf4_body<DMA_A, PLANAR, STAGGER, LBC, SPREAD>(p);
+    conv_wf4_body<DMA_A, PLANAR, STAGGER, LBC>(p);
 }
 
 // filter: OIHW 3x3 -> u[cout block][chunk][cb][kk][i][f] = (G g G^T)[f] of channel (64 blk + 16 cb + i, 4 chunk + kk); zero beyond Cout
