@@ -188,18 +188,6 @@ int pl_conv2d_rowpacked_q4_f32(pl_ctx *ctx, const float *xp, int N, int Cin, int
                                const float *wq, int Cout, int kh, int kw, const float *bias,
                                float *yq, int sh, int sw, int pt, int pl, const float *scale,
                                const float *shift, const float *resq, int act, double alpha);
-/* conv + layer.Maxpool(w = 3x3, strides 2, pads 1) (layer.py:71-72 -> util.py:79-95) in ONE kernel: the conv tile is
- * max-pooled through LDS (zero padding, -1e4 start, the reference's tap order) and yq is the POOLED Q4 tensor
- * (N, Cout, (Ho+1)/2, (Wo+1)/2): the full-resolution conv output never reaches HBM.  No residual.  Emitted by the
- * plan compiler for conv -> [batchnorm] -> [relu] -> maxpool chains (ResNet's stem); results are bit-identical to
- * pl_conv2d_q4_f32 / pl_conv2d_rowpack_q4_f32 (on an unsplit launch plan: same K order) followed by pl_pool2d_q4_f32. */
-int pl_conv2d_pool_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const float *wq, int Cout, int kh,
-                          int kw, const float *bias, float *yq, int sh, int sw, int dh, int dw, int pt, int pl, int group,
-                          const float *scale, const float *shift, int act, double alpha);
-int pl_conv2d_rowpack_pool_q4_f32(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const float *wq, int Cout,
-                                  int kh, int kw, const float *bias, float *yq, int sh, int sw, int pt, int pl,
-                                  const float *scale, const float *shift, int act, double alpha);
-
 /* Winograd F(4x4,3x3) on Q4 tensors (same constraints as the F(2x2,3x3) entry points): 6x6 input
  * tiles, 36 grouped GEMMs, 4x fewer multiplies than the direct conv and less transform traffic
  * than F(2x2,3x3); larger transform constants, error a few 1e-6 of max|y| in fp32.
@@ -260,19 +248,10 @@ int pl_conv2d_wf4_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int H, in
                          const float *scale, const float *shift, const float *resq,
                          int act, double alpha);
 
-/* Fused 1-D Winograd F(2,3) along W on Q4 tensors (3x3 / stride 1 / pad 1 / group 1, Cin %% 4 == 0):
- * 1.5x fewer multiplies than the direct conv with NO extra HBM traffic -- the input transform
- * happens between the global load and LDS, the output transform in registers (conv_w1d_kernel.h).
- * uq = [4][k-quad][Cout][4], k-quad = row*Cin/4 + cin/4, made once per model. */
-int pl_conv2d_w1d_q4_filter_elems(int Cout, int Cin, size_t *elems);
-int pl_conv2d_prepare_w1d_q4_f32(pl_ctx *ctx, const float *w, int Cout, int Cin, float *out);
-int pl_conv2d_w1d_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W,
-                         const float *uq, int Cout, const float *bias, float *yq,
-                         const float *scale, const float *shift, const float *resq,
-                         int act, double alpha);
-
-/* The same fused kernel with F(4,3) along W: 6 frequencies, 4 outputs per tile, 2x fewer multiplies
- * than the direct conv; uq = [6][k-quad][Cout][4]. */
+/* Fused 1-D Winograd F(4,3) along W on Q4 tensors (3x3 / stride 1 / pad 1 / group 1, Cin %% 4 == 0): 6 frequencies,
+ * 4 outputs per tile, 2x fewer multiplies than the direct conv with NO extra HBM traffic -- the input transform happens
+ * between the global load and LDS, the output transform in registers (conv_w1d_kernel.h).
+ * uq = [6][k-quad][Cout][4], k-quad = row*Cin/4 + cin/4, made once per model. */
 int pl_conv2d_w1d4_q4_filter_elems(int Cout, int Cin, size_t *elems);
 int pl_conv2d_prepare_w1d4_q4_f32(pl_ctx *ctx, const float *w, int Cout, int Cin, float *out);
 int pl_conv2d_w1d4_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W,

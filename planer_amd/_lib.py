@@ -81,14 +81,9 @@ SIGNATURES = {
     "pl_conv2d_rowpack_filter_elems": [_I, _I, _I, _I, POINTER(c_size_t)],
     "pl_conv2d_prepare_rowpack_f32": [_P, _P, _I, _I, _I, _I, _P],
     "pl_conv2d_rowpack_q4_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, c_double],
-    "pl_conv2d_pool_q4_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P] + [_I] * 7 + [_P, _P, _I, c_double],
     "pl_rowpack_input_elems": [_I, _I, _I, _I, _I, _I, _I, _I, POINTER(c_size_t)],
     "pl_rowpack_input_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I],
     "pl_conv2d_rowpacked_q4_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, c_double],
-    "pl_conv2d_rowpack_pool_q4_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _I, c_double],
-    "pl_conv2d_w1d_q4_filter_elems": [_I, _I, POINTER(c_size_t)],
-    "pl_conv2d_prepare_w1d_q4_f32": [_P, _P, _I, _I, _P],
-    "pl_conv2d_w1d_q4_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, c_double],
     "pl_conv2d_w1d4_q4_filter_elems": [_I, _I, POINTER(c_size_t)],
     "pl_conv2d_prepare_w1d4_q4_f32": [_P, _P, _I, _I, _P],
     "pl_conv2d_w1d4_q4_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, c_double],

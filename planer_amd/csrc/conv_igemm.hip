@@ -64,14 +64,6 @@ struct ConvArgs {
     FastDiv divKhw, divKw, divHoWo, divWo, divMt, divCpt;
     Epilogue ep;
 };
-// conv + maxpool(3x3, stride 2, pad 1) fused (conv_q4_pool_kernel): a column tile = one patch of (2*ph+1) x (2*pw+1)
-// conv pixels = ph x pw pooled pixels; y is the POOLED Q4 tensor (Hp x Wp).  A second kernel argument, so the
-// kernarg block of every other conv launch stays as small as it was (hundreds of graph launches can be in flight).
-struct PoolArgs {
-    int ph, pw, npx, Hp, Wp;
-    FastDiv divPatches, divPpx, divCw, divPerQuad, divPw;
-};
-
 // blockIdx.x -> (group, m-tile, n-tile).  XCD-aware: the 8 XCDs (private L2s)
 // each walk a contiguous range of tiles, M-tiles fastest, so workgroups that
 // are co-resident on an XCD share input pixels and filter panels in its L2.
@@ -642,7 +634,6 @@ __global__ void __launch_bounds__(256) permute_weights_kernel(const float *w, fl
 
 #include "conv_q4_kernel.h"
 #include "conv_ks_kernel.h"
-#include "conv_pcg_kernel.h"
 #include "conv_smallcin_kernel.h"
 #include "conv_smallcin_valu_kernel.h"
 
@@ -692,7 +683,6 @@ struct CfgInfo {
     void (*scl)(const ConvArgs);
     void (*reduce)(const ConvArgs, const float *, float *);
     void (*reduce4)(const ConvArgs, const float *, float *);
-    bool pc;     // persistent producer/consumer kernel (conv_pcg_kernel.h): 512 threads, one workgroup per CU
     bool ks;     // intra-workgroup K split (conv_ks_kernel.h): 1024 threads, 32x32 tile, no split-K plans
     void (*pair)(const ConvArgs, const ConvArgs);    // two convs on one input in one launch (conv_q4_pair_kernel), or null
 };
@@ -708,15 +698,10 @@ struct CfgInfo {
 
 #define Q4_ENTRY(T, nm) \
     { nm, 2, T::BM, T::BN, T::BK, T::LDS_BYTES, conv_q4_kernel<T>, conv_q4_kernel<T>, \
-      reduce_tiles_q4_kernel<T::BM, T::BN>, reduce_tiles_q4_kernel<T::BM, T::BN>, false }
+      reduce_tiles_q4_kernel<T::BM, T::BN>, reduce_tiles_q4_kernel<T::BM, T::BN> }
 #define Q4P_ENTRY(T, nm) \
     { nm, 2, T::BM, T::BN, T::BK, T::LDS_BYTES, conv_q4_kernel<T>, conv_q4_kernel<T>, \
-      reduce_tiles_q4_kernel<T::BM, T::BN>, reduce_tiles_q4_kernel<T::BM, T::BN>, false, false, conv_q4_pair_kernel<T> }
-#define PC_ENTRY(T, nm) \
-    { nm, 2, T::BM, T::BN, T::BK, T::LDS_BYTES, conv_pc_kernel<T>, conv_pc_kernel<T>, nullptr, nullptr, true }
-typedef PcCfg<128, 128> P128x128;
-typedef PcCfg<64, 256> P64x256;
-typedef PcCfg<256, 64> P256x64;
+      reduce_tiles_q4_kernel<T::BM, T::BN>, reduce_tiles_q4_kernel<T::BM, T::BN>, false, conv_q4_pair_kernel<T> }
 
 const CfgInfo kCfgs[] = {
     CFG_ENTRY(C128x128, "128x128"), CFG_ENTRY(C64x128, "64x128"), CFG_ENTRY(C128x64, "128x64"),
@@ -734,25 +719,16 @@ const CfgInfo kCfgs[] = {
     Q4P_ENTRY(Q64x64x16, "q64x64x16"),      Q4P_ENTRY(Q64x64x32, "q64x64x32"),
     Q4P_ENTRY(Q128x32x32, "q128x32x32"),    Q4_ENTRY(Q32x128x32, "q32x128x32"),
     Q4_ENTRY(Q256x64x16, "q256x64x16"),    Q4_ENTRY(Q64x256x16, "q64x256x16"),
-    PC_ENTRY(P128x128, "p128x128x16"),     PC_ENTRY(P64x256, "p64x256x16"),     PC_ENTRY(P256x64, "p256x64x16"),
 #define KS_ENTRY(TM, TN, nm) \
     { nm, 2, KsCfg<TM, TN>::BM, KsCfg<TM, TN>::BN, KsCfg<TM, TN>::BK, KsCfg<TM, TN>::LDS_BYTES, conv_ks_kernel<KsCfg<TM, TN> >, \
-      conv_ks_kernel<KsCfg<TM, TN> >, nullptr, nullptr, false, true }
+      conv_ks_kernel<KsCfg<TM, TN> >, nullptr, nullptr, true }
     KS_ENTRY(1, 1, "k32x32x8"), KS_ENTRY(2, 1, "k64x32x8"), KS_ENTRY(1, 2, "k32x64x8"), KS_ENTRY(2, 2, "k64x64x8"),
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 constexpr int kLdsPerCu = 160 * 1024;
 
 // weight layouts: 0 OIHW (generic kernel), 1 tap-major, 2 Q4 (activations AND filter in quad form)
-bool pc_enabled() {
-    static const bool on = !getenv("PLANER_HIP_PC") || atoi(getenv("PLANER_HIP_PC")) != 0;
-    return on;
-}
-
 bool cfg_applies(const CfgInfo &ci, int layout, int cin_g, int q_pad = 1 << 20) {
-    // the persistent kernel: plain channel-quad gather only, and at least 4 chunks per tile (its
-    // per-tile parameter hand-off is three tiles deep)
-    if (ci.pc && (layout != 2 || q_pad / 4 < 4 || !pc_enabled())) return false;
     if (ci.ks && (layout != 2 || (getenv("PLANER_HIP_KS") && atoi(getenv("PLANER_HIP_KS")) == 0))) return false;
     if (layout == 6) layout = 2;            // row-packed input: the channel-quad kernel with another gather
     if (ci.tap != layout) return false;
@@ -818,24 +794,6 @@ int launch_pass(pl_ctx *ctx, ConvArgs a, const CfgInfo &ci, bool avec, int tile_
     a.tile_offset = tile_offset;
     a.tile_count = tile_count;
     a.y = out;
-    if (ci.pc) {
-        // persistent: every workgroup walks tiles blockIdx.x, +grid, ...; no split-K, whole conv in one launch
-        if (splits != 1 || tile_offset != 0 || tile_count != a.tiles * a.groups) {
-            pl_set_error("conv: the persistent kernel runs whole, unsplit convolutions only");
-            return PL_EINVAL;
-        }
-        int rc = ensure_lds_attr((const void *)ci.vec, ci.lds);
-        if (rc != PL_OK) return rc;
-        const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
-        hipLaunchKernelGGL(ci.vec, dim3((unsigned)std::min(tile_count, cus)), dim3(512), ci.lds, ctx->stream, a);
-        hipError_t le = hipGetLastError();
-        if (le != hipSuccess) {
-            pl_set_error("conv launch (%s): %s", ci.name, hipGetErrorString(le));
-            return PL_EHIP;
-        }
-        *used_splits = 1;
-        return PL_OK;
-    }
     if (ci.ks) {
         if (splits != 1) {
             pl_set_error("conv: the K-split-inside-the-workgroup kernel takes no split-K plan");
@@ -933,7 +891,7 @@ Plan choose_plan(pl_ctx *ctx, int layout, const ConvArgs &a) {
     Plan pl{-1, 0, 1, 0};
     for (int c = 0; c < kNumCfgs; ++c) {
         const CfgInfo &ci = kCfgs[c];
-        if (ci.pc || ci.ks || !cfg_applies(ci, layout, a.cin_g)) continue;
+        if (ci.ks || !cfg_applies(ci, layout, a.cin_g)) continue;
         const double mt = (a.cout_g + ci.bm - 1) / ci.bm, nt = (a.cols + ci.bn - 1) / ci.bn;
         const double tiles = mt * nt * a.groups;
         const double kch = std::ceil((double)a.K / ci.bk);
@@ -1007,7 +965,7 @@ Plan tune_plan(pl_ctx *ctx, int layout, const ConvArgs &a, bool avec, float *y, 
         if ((double)T * ci.bm * ci.bn > 2.5 * work + 1e5) continue;               // mostly padding
         Plan dp{c, T, 1, 0};
         stage1.push_back({time_plan(ctx, a, dp, avec, y, e0, e1, 2), dp});
-        if (ci.pc || ci.ks) continue;                                             // persistent / intra-workgroup split: no split-K variants
+        if (ci.ks) continue;                                                       // intra-workgroup split: no split-K variants
         const int chunks = (a.K + ci.bk - 1) / ci.bk;
         const char *ms_env = getenv("PLANER_CONV_MAX_SPLIT");     // experiments: cap split-K
         const int max_split = ms_env ? atoi(ms_env) : 1 << 20;
@@ -1025,20 +983,6 @@ Plan tune_plan(pl_ctx *ctx, int layout, const ConvArgs &a, bool avec, float *y, 
     }
     std::sort(stage1.begin(), stage1.end(), [](const Cand &x, const Cand &y2) { return x.ms < y2.ms; });
     Cand best = stage1[0];
-    // experiment (PLANER_HIP_PC_PREFER=<factor>): take the fastest persistent config when it is within `factor` of
-    // the fastest plan -- an isolated launch charges it the tile quantisation that concurrent streams give back
-    if (const char *pf = getenv("PLANER_HIP_PC_PREFER")) {
-        const double factor = atof(pf);
-        for (const Cand &c : stage1)
-            if (kCfgs[c.pl.cfg].pc && c.ms <= factor * stage1[0].ms) {
-                (void)hipEventDestroy(e0);
-                (void)hipEventDestroy(e1);
-                if (getenv("PLANER_CONV_TUNE_LOG"))
-                    fprintf(stderr, "[planer_hip] conv N%d C%d %dx%d -> %d k%dx%d s%d g%d: prefer %s (%.3f vs %.3f ms)\n", a.N, a.Cin,
-                            a.H, a.W, a.Cout, a.kh, a.kw, a.sh, a.groups, kCfgs[c.pl.cfg].name, c.ms, stage1[0].ms);
-                return c.pl;
-            }
-    }
     // stage 2: for the most promising tile shapes, an exactly balanced
     // data-parallel prefix (occ tiles on every CU) plus a split-K tail
     std::vector<int> tried;
@@ -1047,7 +991,7 @@ Plan tune_plan(pl_ctx *ctx, int layout, const ConvArgs &a, bool avec, float *y, 
         if (std::find(tried.begin(), tried.end(), c) != tried.end()) continue;
         tried.push_back(c);
         const CfgInfo &ci = kCfgs[c];
-        if (ci.pc || ci.ks) continue;
+        if (ci.ks) continue;
         const int T = ((a.cout_g + ci.bm - 1) / ci.bm) * ((a.cols + ci.bn - 1) / ci.bn) * a.groups;
         const int chunks = (a.K + ci.bk - 1) / ci.bk;
         const int maxocc = std::min(8, kLdsPerCu / ci.lds);
@@ -1101,16 +1045,11 @@ int winograd_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, c
                     const float *bias, float *y, const float *scale, const float *shift, const float *res, int act,
                     double alpha);
 
-int conv_pool_run(pl_ctx *ctx, ConvArgs a);
-
-// pool != 0: the conv is followed by maxpool(3x3, stride 2, pad 1) and y is the POOLED Q4 tensor (layouts 2 / 6)
 int conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const float *w, int Cout, int kh, int kw,
                 const float *bias, float *y, int sh, int sw, int dh, int dw, int pt, int pl, int pb, int pr,
                 int group, const float *scale, const float *shift, const float *res, int act, double alpha,
-                int layout, int pool = 0) {
+                int layout) {
     PL_REQUIRE(ctx && x && w && y, PL_EINVAL, "conv2d: null pointer");
-    PL_REQUIRE(!pool || ((layout == 2 || layout == 6) && !res), PL_EUNSUPPORTED,
-               "conv + maxpool: channel-quad direct conv without a residual only");
     PL_REQUIRE(N >= 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0 && kh > 0 && kw > 0, PL_EINVAL, "conv2d: bad shape");
     PL_REQUIRE(sh > 0 && sw > 0 && dh > 0 && dw > 0 && pt >= 0 && pl >= 0 && group > 0, PL_EINVAL, "conv2d: bad parameter");
     // util.pad only honours pads[0]/pads[1] (util.py:8): anything else is undefined there
@@ -1268,7 +1207,6 @@ int conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const
     a.divMt = FastDiv(1); a.divCpt = FastDiv(1);
     a.ep = make_epilogue(bias, scale, shift, res, act, alpha);
     const bool avec = (a.K % 4 == 0) && ((reinterpret_cast<uintptr_t>(w) & 15u) == 0);
-    if (pool) return conv_pool_run(ctx, a);
 
     // forced configuration (tests / tuning tools): split > 1 means split-K over all tiles
     if (ctx->conv_cfg >= 0 && ctx->conv_cfg < kNumCfgs && cfg_applies(kCfgs[ctx->conv_cfg], layout, a.cin_g, a.Qpad)) {
@@ -1427,64 +1365,6 @@ int pair_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const
     return pair_run(ctx, a, b, cfg);
 }
 
-// conv + maxpool(3x3 / stride 2 / pad 1) in one launch: 64 x 256 tiles, a column tile = one patch of conv pixels.
-// The patch (ph x pw pooled pixels) is the one that covers the pooled map with the fewest tiles -- 7 x 8 on
-// ResNet's 56 x 56: 15 x 17 = 255 of 256 columns used, 14 % of the conv pixels computed twice (the halo),
-// against the 103 MB write + 107 MB read of the full-resolution tensor that no longer happen.
-template <class C>
-int conv_pool_run_t(pl_ctx *ctx, ConvArgs a);
-
-int conv_pool_run(pl_ctx *ctx, ConvArgs a) {
-    // column tile = one patch of conv pixels: 256 columns (15 x 17 pixels -> 7 x 8 pooled, 14 % of the conv pixels computed
-    // twice, 183 registers) or 128 (PLANER_HIP_POOL_TILE=128: 7 x 17 patches, 24 % halo, the occupancy of the plain kernel --
-    // measured on ResNet-18's stem at batch 32: 143.9 us against 138.7 us for the 256-column tile and 103.5 + 22.6 us unfused)
-    static const int tile = getenv("PLANER_HIP_POOL_TILE") ? atoi(getenv("PLANER_HIP_POOL_TILE")) : 256;
-    return tile == 128 ? conv_pool_run_t<Q64x128x16>(ctx, a) : conv_pool_run_t<Q64x256x16>(ctx, a);
-}
-
-template <class C>
-int conv_pool_run_t(pl_ctx *ctx, ConvArgs a) {
-    const int Hp = (a.Ho + 1) / 2, Wp = (a.Wo + 1) / 2;          // (H + 2 - 3 + 2) // 2, util.py:84-85
-    int best_ph = 1, best_pw = 1;
-    long best_tiles = -1, best_px = 0;
-    for (int ph = 1; ph <= 64; ++ph)
-        for (int pw = 1; pw <= 64; ++pw) {
-            const long px = (long)(2 * ph + 1) * (2 * pw + 1);
-            if (px > C::BN) break;
-            const long tiles = (long)((Hp + ph - 1) / ph) * ((Wp + pw - 1) / pw);
-            if (best_tiles < 0 || tiles < best_tiles || (tiles == best_tiles && px < best_px)) {
-                best_tiles = tiles; best_px = px; best_ph = ph; best_pw = pw;
-            }
-        }
-    const int ph = best_ph, pw = best_pw, ppy = (Hp + ph - 1) / ph, ppx = (Wp + pw - 1) / pw;
-    PoolArgs pa;
-    pa.ph = ph; pa.pw = pw; pa.npx = (2 * ph + 1) * (2 * pw + 1); pa.Hp = Hp; pa.Wp = Wp;
-    pa.divPatches = FastDiv(ppy * ppx); pa.divPpx = FastDiv(ppx); pa.divCw = FastDiv(2 * pw + 1);
-    pa.divPerQuad = FastDiv(ph * pw); pa.divPw = FastDiv(pw);
-    PL_REQUIRE((size_t)a.N * ppy * ppx * C::BN < (1ull << 31) && (size_t)a.N * a.Coq * Hp * Wp < (1ull << 27), PL_EUNSUPPORTED,
-               "conv + maxpool: tensor too large");
-    a.mtiles = (a.cout_g + C::BM - 1) / C::BM;
-    a.ntiles = a.N * ppy * ppx;
-    a.tiles = a.mtiles * a.ntiles;
-    a.cols = a.ntiles * C::BN;
-    a.divMt = FastDiv(a.mtiles);
-    const int kg = C::BK / 4, total_chunks = (a.Qtot + kg - 1) / kg;
-    a.splits = 1; a.k_per_split = total_chunks; a.tile_offset = 0; a.tile_count = a.tiles * a.groups;
-    a.uni = a.rp_rq ? 0 : a.cqg % kg == 0;
-    a.divCpt = FastDiv(a.rp_rq ? a.rp_rq : a.cqg);
-    const int lds = std::max<int>(C::LDS_BYTES, 1024 * ((3 * C::BM * 4 + 1023) / 1024) + (C::BM / 4) * C::BN * 16);
-    auto kern = conv_q4_pool_kernel<C>;
-    int rc = ensure_lds_attr((const void *)kern, lds);
-    if (rc != PL_OK) return rc;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles * a.groups)), dim3(256), lds, ctx->stream, a, pa);
-    PL_LAUNCH_CHECK();
-    char buf[96];
-    snprintf(buf, sizeof buf, "q64x%dx16+maxpool patch=%dx%d tiles=%d", C::BN, ph, pw, a.tiles * a.groups);
-    ctx->last_plan = buf;
-    ctx->last_gemm[0] = a.groups; ctx->last_gemm[1] = (long long)a.mtiles * C::BM; ctx->last_gemm[2] = (long long)a.ntiles * C::BN;
-    ctx->last_gemm[3] = (long long)total_chunks * C::BK;
-    return PL_OK;
-}
 
 // =============================================================================
 // Winograd F(2x2,3x3) for 3x3 / stride 1 / pad 1 / group 1 convolutions.
@@ -1982,7 +1862,7 @@ __global__ void __launch_bounds__(256) wino4_output_q4_kernel(const float4 *M, f
             for (int b = 0; b < 4; ++b) {
                 const float4 v = apply_epilogue4(p.ep, bias, scale, shift, rs[a][b], 4, o[b]);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
-                                                       yrsrc, off[a][b], 0, PLANER_STORE_AUX);
+                                                       yrsrc, off[a][b], 0, 0);
             }
         }
     }
@@ -2099,7 +1979,7 @@ __device__ __forceinline__ void wino4_output_row(const float4 *M, const WinoArgs
         for (int b = 0; b < 4; ++b) {
             const float4 v = apply_epilogue4(p.ep, bias, scale, shift, rs[b], 4, o[b]);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
-                                                   yrsrc, off[b], 0, PLANER_STORE_AUX);
+                                                   yrsrc, off[b], 0, 0);
         }
     }
 }
@@ -2289,13 +2169,12 @@ int winograd4_q4_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int
 }
 
 #include "conv_w1d_kernel.h"
-#include "conv_pc_kernel.h"
 
 int w1d_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const float *uq, int Cout, const float *bias,
-               float *yq, const float *scale, const float *shift, const float *resq, int act, double alpha, bool f43) {
+               float *yq, const float *scale, const float *shift, const float *resq, int act, double alpha) {
     ConvArgs a;
     memset(&a, 0, sizeof a);
-    const int Tw = f43 ? (W + 3) / 4 : (W + 1) / 2;          // output pixels per tile: 4 (F(4,3)) or 2 (F(2,3))
+    const int Tw = (W + 3) / 4;                              // 4 output pixels per tile
     a.x = xq; a.w = uq; a.y = yq;
     a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.Ho = H; a.Wo = W;
     a.kh = 3; a.kw = 3; a.sh = a.sw = a.dh = a.dw = 1; a.pt = a.pl = 1;
@@ -2306,49 +2185,32 @@ int w1d_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const
     a.cols = N * H * Tw;
     a.HoWo = H * W; a.HW = H * W;
     const size_t in_elems = (size_t)N * Cin * H * W, out_elems = (size_t)N * a.Coq * 4 * H * W;
-    const size_t w_elems = (size_t)(f43 ? 6 : 4) * a.Qpad * Cout * 4;
+    const size_t w_elems = (size_t)6 * a.Qpad * Cout * 4;
     // (output addressed through a 32-bit buffer offset in the F(4,3) kernels' epilogue: < 2 GiB)
     PL_REQUIRE(in_elems < (1ull << 29) && out_elems < (1ull << 29) && w_elems < (1ull << 29) &&
                    (size_t)N * H * Tw < (1ull << 31), PL_EUNSUPPORTED, "winograd-1d: tensor too large");
     a.x_bytes = (int)(in_elems * 4); a.w_bytes = (int)(w_elems * 4);
     a.divHoWo = FastDiv(H * Tw); a.divWo = FastDiv(Tw); a.divCpt = FastDiv(a.cqg);
     a.divKhw = FastDiv(1); a.divKw = FastDiv(1);
-    a.mtiles = (Cout + W1dCfg::BM - 1) / W1dCfg::BM;
-    a.ntiles = (a.cols + W1dCfg::BN - 1) / W1dCfg::BN;
+    a.mtiles = (Cout + W1d4Cfg::BM - 1) / W1d4Cfg::BM;
+    a.ntiles = (a.cols + W1d4Cfg::BN - 1) / W1d4Cfg::BN;
     a.tiles = a.mtiles * a.ntiles;
     a.divMt = FastDiv(a.mtiles);
     a.tile_offset = 0; a.tile_count = a.tiles; a.splits = 1;
     a.ep = make_epilogue(bias, scale, shift, resq, act, alpha);
-    // persistent producer/consumer variant (conv_pc_kernel.h): whole chunks only, and enough of them
-    // per tile that the parameter hand-off is race free
-    // (measured slower than conv_w1d4_kernel at batch 32 -- one 512-thread workgroup per CU quantises 392 tiles
-    //  into two rounds -- so it is opt-in: PLANER_HIP_W1D4_PC=1)
-    const bool pc_env = getenv("PLANER_HIP_W1D4_PC") && atoi(getenv("PLANER_HIP_W1D4_PC")) != 0;
-    const bool pc = f43 && pc_env && Cin % 16 == 0 && a.Qtot / W1d4PcCfg::KG >= 6;
-    int pc_grid = 0;
-    if (pc) {
-        int rc = ensure_lds_attr((const void *)conv_w1d4_pc_kernel, W1d4PcCfg::LDS_BYTES);
-        if (rc != PL_OK) return rc;
-        pc_grid = std::min(a.tiles, ctx->cu_count > 0 ? ctx->cu_count : 256);
-        hipLaunchKernelGGL(conv_w1d4_pc_kernel, dim3((unsigned)pc_grid), dim3(512), W1d4PcCfg::LDS_BYTES, ctx->stream, a);
-    } else if (f43) {
+    {
         int rc = ensure_lds_attr((const void *)conv_w1d4_kernel, W1d4Cfg::LDS_BYTES);
         if (rc != PL_OK) return rc;
         hipLaunchKernelGGL(conv_w1d4_kernel, dim3((unsigned)a.tiles), dim3(256), W1d4Cfg::LDS_BYTES, ctx->stream, a);
-    } else {
-        int rc = ensure_lds_attr((const void *)conv_w1d_kernel, W1dCfg::LDS_BYTES);
-        if (rc != PL_OK) return rc;
-        hipLaunchKernelGGL(conv_w1d_kernel, dim3((unsigned)a.tiles), dim3(256), W1dCfg::LDS_BYTES, ctx->stream, a);
     }
     PL_LAUNCH_CHECK();
     {
         char buf[96];
-        if (pc) snprintf(buf, sizeof buf, "w1d4pc 64x64x8 tiles=%d grid=%d", a.tiles, pc_grid);
-        else snprintf(buf, sizeof buf, "%s tiles=%d", f43 ? "w1d4 64x64x8" : "w1d 64x64x16", a.tiles);
+        snprintf(buf, sizeof buf, "w1d4 64x64x8 tiles=%d", a.tiles);
         ctx->last_plan = buf;
-        // 6 (F(4,3)) or 4 (F(2,3)) frequency GEMMs of (Cout x 3 Cin) . (3 Cin x column tiles), 64 x 64 tiles, whole chunks
-        const int bk = f43 ? 8 : 16;
-        ctx->last_gemm[0] = f43 ? 6 : 4;
+        // 6 frequency GEMMs of (Cout x 3 Cin) . (3 Cin x column tiles), 64 x 64 tiles, whole chunks
+        const int bk = 8;
+        ctx->last_gemm[0] = 6;
         ctx->last_gemm[1] = (long long)(Cout + 63) / 64 * 64;
         ctx->last_gemm[2] = (long long)(a.cols + 63) / 64 * 64;
         ctx->last_gemm[3] = (long long)(a.Qtot * 4 + bk - 1) / bk * bk;
@@ -2568,7 +2430,7 @@ static int rowpack_check(pl_ctx *ctx, const void *x, int N, int Cin, int H, int 
 
 static int rowpack_conv(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const float *wq, int Cout, int kh,
                         int kw, const float *bias, float *yq, int sh, int sw, int pt, int pl, const float *scale,
-                        const float *shift, const float *resq, int act, double alpha, int pool) {
+                        const float *shift, const float *resq, int act, double alpha) {
     int rc = rowpack_check(ctx, x, N, Cin, H, W, wq, Cout, kh, kw, yq, sh, sw, pt, pl, resq);
     if (rc != PL_OK) return rc;
     if (N == 0) return PL_OK;
@@ -2582,7 +2444,7 @@ static int rowpack_conv(pl_ctx *ctx, const float *x, int N, int Cin, int H, int 
     rc = rowpack_pack(ctx, x, xp, N, Cin, H, W, kw, sw, pt, pl);
     if (rc == PL_OK)
         rc = conv_launch(ctx, xp, N, Cin, H, W, wq, Cout, kh, kw, bias, yq, sh, sw, 1, 1, pt, pl, pt, pl, 1, scale, shift, resq,
-                         act, alpha, 6, pool);
+                         act, alpha, 6);
     pl_free(ctx, xp);            // stream-ordered
     return rc;
 }
@@ -2613,99 +2475,50 @@ int pl_conv2d_rowpacked_q4_f32(pl_ctx *ctx, const float *xp, int N, int Cin, int
     if (N == 0) return PL_OK;
     CtxGuard guard(ctx);
     return conv_launch(ctx, xp, N, Cin, H, W, wq, Cout, kh, kw, bias, yq, sh, sw, 1, 1, pt, pl, pt, pl, 1, scale, shift, resq, act,
-                       alpha, 6, 0);
+                       alpha, 6);
 }
 
 int pl_conv2d_rowpack_q4_f32(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const float *wq, int Cout, int kh,
                              int kw, const float *bias, float *yq, int sh, int sw, int pt, int pl, const float *scale,
                              const float *shift, const float *resq, int act, double alpha) {
-    return rowpack_conv(ctx, x, N, Cin, H, W, wq, Cout, kh, kw, bias, yq, sh, sw, pt, pl, scale, shift, resq, act, alpha, 0);
+    return rowpack_conv(ctx, x, N, Cin, H, W, wq, Cout, kh, kw, bias, yq, sh, sw, pt, pl, scale, shift, resq, act, alpha);
 }
 
-int pl_conv2d_rowpack_pool_q4_f32(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const float *wq, int Cout, int kh,
-                                  int kw, const float *bias, float *yq, int sh, int sw, int pt, int pl, const float *scale,
-                                  const float *shift, int act, double alpha) {
-    return rowpack_conv(ctx, x, N, Cin, H, W, wq, Cout, kh, kw, bias, yq, sh, sw, pt, pl, scale, shift, nullptr, act, alpha, 1);
-}
-
-int pl_conv2d_pool_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const float *wq, int Cout, int kh,
-                          int kw, const float *bias, float *yq, int sh, int sw, int dh, int dw, int pt, int pl, int group,
-                          const float *scale, const float *shift, int act, double alpha) {
-    PL_REQUIRE(!xq || !yq || ((reinterpret_cast<uintptr_t>(xq) | reinterpret_cast<uintptr_t>(yq) |
-                               reinterpret_cast<uintptr_t>(wq)) & 15u) == 0,
-               PL_EINVAL, "pl_conv2d_pool_q4_f32: Q4 tensors must be 16-byte aligned");
-    return conv_launch(ctx, xq, N, Cin, H, W, wq, Cout, kh, kw, bias, yq, sh, sw, dh, dw, pt, pl, pt, pl, group, scale, shift,
-                       nullptr, act, alpha, 2, 1);
-}
-
-static int w1d_filter_elems(int Cout, int Cin, int freqs, size_t *elems) {
+int pl_conv2d_w1d4_q4_filter_elems(int Cout, int Cin, size_t *elems) {
     PL_REQUIRE(elems && Cout > 0 && Cin > 0, PL_EINVAL, "winograd-1d filter size: bad argument");
-    *elems = (size_t)freqs * (((size_t)3 * (Cin / 4) + 7) / 8 * 8) * Cout * 4;
+    *elems = (size_t)6 * (((size_t)3 * (Cin / 4) + 7) / 8 * 8) * Cout * 4;
     return PL_OK;
 }
 
-int pl_conv2d_w1d_q4_filter_elems(int Cout, int Cin, size_t *elems) { return w1d_filter_elems(Cout, Cin, 4, elems); }
-int pl_conv2d_w1d4_q4_filter_elems(int Cout, int Cin, size_t *elems) { return w1d_filter_elems(Cout, Cin, 6, elems); }
-
-static int w1d_prepare(pl_ctx *ctx, const float *w, int Cout, int Cin, float *out, bool f43);
-
-int pl_conv2d_prepare_w1d_q4_f32(pl_ctx *ctx, const float *w, int Cout, int Cin, float *out) {
-    return w1d_prepare(ctx, w, Cout, Cin, out, false);
-}
-
 int pl_conv2d_prepare_w1d4_q4_f32(pl_ctx *ctx, const float *w, int Cout, int Cin, float *out) {
-    return w1d_prepare(ctx, w, Cout, Cin, out, true);
-}
-
-static int w1d_prepare(pl_ctx *ctx, const float *w, int Cout, int Cin, float *out, bool f43) {
-    PL_REQUIRE(ctx && w && out, PL_EINVAL, "pl_conv2d_prepare_w1d_q4_f32: null pointer");
+    PL_REQUIRE(ctx && w && out, PL_EINVAL, "pl_conv2d_prepare_w1d4_q4_f32: null pointer");
     PL_REQUIRE(Cout > 0 && Cin > 0 && Cin % 4 == 0, PL_EINVAL, "winograd-1d filters need Cin %% 4 == 0");
-    PL_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15u) == 0, PL_EINVAL, "pl_conv2d_prepare_w1d_q4_f32: unaligned output");
+    PL_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15u) == 0, PL_EINVAL, "pl_conv2d_prepare_w1d4_q4_f32: unaligned output");
     const int cqg = Cin / 4, q_tot = 3 * cqg, q_pad = (q_tot + 7) / 8 * 8;
     const size_t total = (size_t)q_pad * Cout;
     PL_REQUIRE(total * 16 < (1ull << 29), PL_EUNSUPPORTED, "filter too large");
     CtxGuard g(ctx);
     unsigned blocks = (unsigned)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    if (f43)
-        pack_filter_w1d4_kernel<<<blocks, 256, 0, ctx->stream>>>(w, out, (unsigned)total, Cout, Cin, cqg, q_tot, q_pad,
-                                                                FastDiv(Cout), FastDiv(cqg));
-    else
-        pack_filter_w1d_kernel<<<blocks, 256, 0, ctx->stream>>>(w, out, (unsigned)total, Cout, Cin, cqg, q_tot, q_pad,
-                                                               FastDiv(Cout), FastDiv(cqg));
+    pack_filter_w1d4_kernel<<<blocks, 256, 0, ctx->stream>>>(w, out, (unsigned)total, Cout, Cin, cqg, q_tot, q_pad, FastDiv(Cout),
+                                                            FastDiv(cqg));
     PL_LAUNCH_CHECK();
     return PL_OK;
-}
-
-static int w1d_entry(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const float *uq, int Cout,
-                     const float *bias, float *yq, const float *scale, const float *shift, const float *resq, int act,
-                     double alpha, bool f43);
-
-int pl_conv2d_w1d_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const float *uq, int Cout,
-                         const float *bias, float *yq, const float *scale, const float *shift, const float *resq,
-                         int act, double alpha) {
-    return w1d_entry(ctx, xq, N, Cin, H, W, uq, Cout, bias, yq, scale, shift, resq, act, alpha, false);
 }
 
 int pl_conv2d_w1d4_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const float *uq, int Cout,
                           const float *bias, float *yq, const float *scale, const float *shift, const float *resq,
                           int act, double alpha) {
-    return w1d_entry(ctx, xq, N, Cin, H, W, uq, Cout, bias, yq, scale, shift, resq, act, alpha, true);
-}
-
-static int w1d_entry(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const float *uq, int Cout,
-                     const float *bias, float *yq, const float *scale, const float *shift, const float *resq, int act,
-                     double alpha, bool f43) {
-    PL_REQUIRE(ctx && xq && uq && yq, PL_EINVAL, "pl_conv2d_w1d_q4_f32: null pointer");
+    PL_REQUIRE(ctx && xq && uq && yq, PL_EINVAL, "pl_conv2d_w1d4_q4_f32: null pointer");
     PL_REQUIRE(N >= 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0 && Cin % 4 == 0, PL_EINVAL,
-               "pl_conv2d_w1d_q4_f32: bad shape (Cin must be a multiple of 4)");
-    PL_REQUIRE(H < 16384 && W < 16384, PL_EUNSUPPORTED, "pl_conv2d_w1d_q4_f32: spatial extent above 16383");
-    PL_REQUIRE(act >= 0 && (act & 15) <= 2 && (act & ~31) == 0, PL_EINVAL, "pl_conv2d_w1d_q4_f32: bad activation code");
+               "pl_conv2d_w1d4_q4_f32: bad shape (Cin must be a multiple of 4)");
+    PL_REQUIRE(H < 16384 && W < 16384, PL_EUNSUPPORTED, "pl_conv2d_w1d4_q4_f32: spatial extent above 16383");
+    PL_REQUIRE(act >= 0 && (act & 15) <= 2 && (act & ~31) == 0, PL_EINVAL, "pl_conv2d_w1d4_q4_f32: bad activation code");
     PL_REQUIRE(((reinterpret_cast<uintptr_t>(xq) | reinterpret_cast<uintptr_t>(yq) | reinterpret_cast<uintptr_t>(uq) |
                  reinterpret_cast<uintptr_t>(resq)) & 15u) == 0, PL_EINVAL, "Q4 tensors must be 16-byte aligned");
     if (N == 0) return PL_OK;
     CtxGuard guard(ctx);
-    return w1d_launch(ctx, xq, N, Cin, H, W, uq, Cout, bias, yq, scale, shift, resq, act, alpha, f43);
+    return w1d_launch(ctx, xq, N, Cin, H, W, uq, Cout, bias, yq, scale, shift, resq, act, alpha);
 }
 
 int pl_conv2d_winograd4_q4_filter_elems(int Cout, int Cin, size_t *elems) {

@@ -165,7 +165,7 @@ __device__ __forceinline__ void store_tile_q4(const ConvArgs &p, const TileCoord
                         make_float4(acc[a][b][4 * rq], acc[a][b][4 * rq + 1], acc[a][b][4 * rq + 2], acc[a][b][4 * rq + 3]);
                     const float4 o = apply_epilogue4(p.ep, bias, scale, shift, rs[rq][b], valid, v);
                     __builtin_amdgcn_raw_buffer_store_b128(
-                        __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o), yrsrc, off[rq][b], 0, PLANER_STORE_AUX);
+                        __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o), yrsrc, off[rq][b], 0, 0);
                 }
             }
         }
@@ -214,79 +214,6 @@ __device__ __forceinline__ void store_tile_q4(const ConvArgs &p, const TileCoord
     }
 }
 
-// ---- conv + maxpool(3x3, stride 2, pad 1) in one kernel -------------------------------------------------
-// Where the patch pixel `jl` of the column tile starting at col0 sits in the conv output: tile nt = (image,
-// patch row, patch column); the patch covers conv rows 2*ph*PY - 1 .. 2*ph*(PY+1) - 1 (one row shared with each
-// neighbour -- the pool windows overlap by one) and likewise for columns.  ok = inside the patch and the map.
-struct PoolPixel {
-    int n, ho, wo, PY, PX;
-    bool ok;
-};
-template <int BN>
-__device__ __forceinline__ PoolPixel pool_pixel(const ConvArgs &p, const PoolArgs &pa, int col0, int jl) {
-    PoolPixel r;
-    unsigned n, pr, PY, PX, ly, lx;
-    pa.divPatches.divmod((unsigned)(col0 / BN), n, pr);
-    pa.divPpx.divmod(pr, PY, PX);
-    pa.divCw.divmod((unsigned)jl, ly, lx);
-    r.n = (int)n; r.PY = (int)PY; r.PX = (int)PX;
-    r.ho = 2 * pa.ph * (int)PY - 1 + (int)ly;
-    r.wo = 2 * pa.pw * (int)PX - 1 + (int)lx;
-    r.ok = jl < pa.npx && (unsigned)r.ho < (unsigned)p.Ho && (unsigned)r.wo < (unsigned)p.Wo;
-    return r;
-}
-
-// Tail of the POOL kernel: the conv tile goes through the fused epilogue into LDS as [row/4][BN] float4s
-// (pixels outside the map as the pool's zero padding, util.py:88), then every thread max-pools a few (channel
-// quad, pooled pixel) windows starting from -1e4 in the reference's tap order (util.py:79-95) and writes the
-// POOLED Q4 tensor: the full-resolution conv output never reaches HBM.  smem: [3][BM] parameters, then the stage.
-template <int BM, int BN, int TM, int TN, int WTM, int WTN>
-__device__ __forceinline__ void pool_tile_q4(const ConvArgs &p, const PoolArgs &pa, const TileCoord &tc,
-                                             f32x16 (&acc)[TM][TN], int wm, int wn, int lane, float *smem) {
-    const int l31 = lane & 31, lhi = lane >> 5;
-    const float4 *prm4 = reinterpret_cast<const float4 *>(smem);
-    float4 *stage = reinterpret_cast<float4 *>(smem + 256 * ((3 * BM + 255) / 256));
-    const float4 none = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int b = 0; b < TN; ++b) {
-        const int px = wn * WTN + b * 32 + l31;
-        const bool in_map = pool_pixel<BN>(p, pa, tc.col0, px).ok;
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const int Rt = wm * WTM + a * 32 + 8 * rq + 4 * lhi;
-                const float4 bias = prm4[Rt >> 2], scale = prm4[(BM + Rt) >> 2], shift = prm4[(2 * BM + Rt) >> 2];
-                const float4 v =
-                    make_float4(acc[a][b][4 * rq], acc[a][b][4 * rq + 1], acc[a][b][4 * rq + 2], acc[a][b][4 * rq + 3]);
-                const float4 o = apply_epilogue4(p.ep, bias, scale, shift, none, p.cout_g - (tc.m0 + Rt), v);
-                stage[(Rt >> 2) * BN + px] = in_map ? o : none;
-            }
-    }
-    __syncthreads();
-    const PoolPixel p0 = pool_pixel<BN>(p, pa, tc.col0, 0);
-    const int per_quad = pa.ph * pa.pw, items = (BM / 4) * per_quad, cw = 2 * pa.pw + 1;
-    float4 *y4 = reinterpret_cast<float4 *>(p.y);
-    for (int it = threadIdx.x; it < items; it += 256) {
-        unsigned ql, pp, py, px;
-        pa.divPerQuad.divmod((unsigned)it, ql, pp);
-        pa.divPw.divmod(pp, py, px);
-        const int oy = p0.PY * pa.ph + (int)py, ox = p0.PX * pa.pw + (int)px;
-        if (oy >= pa.Hp || ox >= pa.Wp || tc.m0 + (int)ql * 4 >= p.cout_g) continue;
-        const float4 *sp = stage + ql * BN + (2 * py) * cw + 2 * px;
-        float4 m = make_float4(-1e4f, -1e4f, -1e4f, -1e4f);
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const float4 v = sp[r * cw + q];
-                m = make_float4(fmaxf(v.x, m.x), fmaxf(v.y, m.y), fmaxf(v.z, m.z), fmaxf(v.w, m.w));
-            }
-        const unsigned coq = (unsigned)(((int)tc.g * p.cout_g + tc.m0) >> 2) + ql;
-        y4[(((size_t)p0.n * p.Coq + coq) * pa.Hp + oy) * pa.Wp + ox] = m;
-    }
-}
-
 // Sum the split-K slabs ([row/4][BN][4]) of tiles [tile_offset, +tile_count) and
 // write Q4 with the fused tail.  blockIdx.x = tile, blockIdx.y = band of row quads.
 constexpr int REDUCE_Q4_QUADS = 8;   // row quads per block: BN * 8 float4 per 256 threads
@@ -332,11 +259,8 @@ __global__ void __launch_bounds__(256) reduce_tiles_q4_kernel(const ConvArgs p, 
     }
 }
 
-// POOL: the tile's BN columns are one (2*ph+1) x (2*pw+1) patch of conv pixels (rows / columns overlap the
-// neighbouring patches by one), and the tail max-pools it 3x3 / stride 2 / pad 1 through LDS (pool_tile_q4).
-template <class C, bool POOL>
-__device__ __forceinline__ void conv_q4_body(const ConvArgs &p, const PoolArgs *pap, unsigned bid = blockIdx.x,
-                                             unsigned nblk = gridDim.x) {
+template <class C>
+__device__ __forceinline__ void conv_q4_body(const ConvArgs &p, unsigned bid = blockIdx.x, unsigned nblk = gridDim.x) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;                         // [2][KG][BM][4]
     float *Bs = smem + 2 * C::A_ELEMS;        // [2][KG][BN][4]
@@ -368,16 +292,7 @@ __device__ __forceinline__ void conv_q4_body(const ConvArgs &p, const PoolArgs *
     const int j = col0 + jl;
     bool jok = j < p.cols && (C::B_ALL_ACTIVE || kg0 < C::KG);
     int hbase = -(1 << 20), wbase = 0, cbase = 0, j_n = 0;
-    if constexpr (POOL) {
-        const PoolPixel pp = pool_pixel<C::BN>(p, *pap, col0, jl);
-        jok = pp.ok && (C::B_ALL_ACTIVE || kg0 < C::KG);
-        if (jok) {
-            hbase = pp.ho * p.sh - p.pt;
-            wbase = pp.wo * p.sw - p.pl;
-            cbase = (pp.n * p.Cq + (int)g * p.cqg) * p.HW + hbase * p.W + wbase;
-            j_n = pp.n;
-        }
-    } else if (jok) {
+    if (jok) {
         unsigned n, pix, ho, wo;
         p.divHoWo.divmod((unsigned)j, n, pix);
         p.divWo.divmod(pix, ho, wo);
@@ -604,16 +519,13 @@ __device__ __forceinline__ void conv_q4_body(const ConvArgs &p, const PoolArgs *
         }
         __syncthreads();
     }
-    if constexpr (POOL)
-        pool_tile_q4<C::BM, C::BN, C::TM, C::TN, C::WTM, C::WTN>(p, *pap, tc, acc, wm, wn, lane, smem);
-    else
-        store_tile_q4<C::BM, C::BN, C::TM, C::TN, C::WTM, C::WTN>(p, tc, acc, wm, wn, lane, smem);
+    store_tile_q4<C::BM, C::BN, C::TM, C::TN, C::WTM, C::WTN>(p, tc, acc, wm, wn, lane, smem);
 }
 
 template <class C>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C::MIN_WAVES)))
 conv_q4_kernel(const ConvArgs p) {
-    conv_q4_body<C, false>(p, nullptr);
+    conv_q4_body<C>(p);
 }
 
 // Two convolutions that read the SAME input in one launch: workgroups [0, pa.tile_count) run conv a, the rest conv b (both
@@ -624,15 +536,9 @@ template <class C>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C::MIN_WAVES)))
 conv_q4_pair_kernel(const ConvArgs pa, const ConvArgs pb) {
     if (blockIdx.x < (unsigned)pa.tile_count)
-        conv_q4_body<C, false>(pa, nullptr, blockIdx.x, (unsigned)pa.tile_count);
+        conv_q4_body<C>(pa, blockIdx.x, (unsigned)pa.tile_count);
     else
-        conv_q4_body<C, false>(pb, nullptr, blockIdx.x - (unsigned)pa.tile_count, (unsigned)pb.tile_count);
-}
-
-template <class C>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C::MIN_WAVES)))
-conv_q4_pool_kernel(const ConvArgs p, const PoolArgs pa) {
-    conv_q4_body<C, true>(p, &pa);
+        conv_q4_body<C>(pb, blockIdx.x - (unsigned)pa.tile_count, (unsigned)pb.tile_count);
 }
 
 // OIHW [g*cout_g + co][cin_g][tap]  ->  wq[g][q][co][4], q = tap*cqg + cin/4 (zero padded to Qpad

@@ -1,230 +1,15 @@
-// Fused 1-D Winograd F(2,3) convolution on channel-quad tensors -- included by conv_igemm.hip
-// inside its anonymous namespace (shares ConvArgs, tile_coord, the Q4 epilogue helpers).
+// Fused 1-D Winograd F(4,3) convolution along W on channel-quad tensors -- included by conv_igemm.hip inside its
+// anonymous namespace (shares ConvArgs, tile_coord, the Q4 epilogue helpers).
 //
-// For 3x3 / stride 1 / pad 1 / dilation 1 / group 1 convs.  The 2-D Winograd pipeline above
-// (wino_*_q4_kernel) needs 2.25x fewer multiplies but moves 4x the activation bytes through HBM for
-// its transforms, which only pays on 14x14 / 7x7 maps.  Here the transform is applied along W only:
-// for every filter row r and input channel c, with d_k = x[c][ho+r-1][2t-1+k] (k = 0..3),
-//     m0 = (d0-d2) G0,  m1 = (d1+d2) G1,  m2 = (d2-d1) G2,  m3 = (d1-d3) G3
-//     G0 = g0, G1 = (g0+g1+g2)/2, G2 = (g0-g1+g2)/2, G3 = g2          (g_s = filter[co][c][r][s])
-//     y[ho][2t] = sum_{r,c} m0+m1+m2,   y[ho][2t+1] = sum_{r,c} m1-m2-m3
-// i.e. FOUR GEMMs M_f = U_f (Cout x 3Cin) . V_f (3Cin x tiles) -- 4 products per 2 outputs per 3 taps,
-// 1.5x fewer MFMAs than the direct conv -- that SHARE ONE GATHER: a thread loads the 4 neighbouring
-// pixels of its (tile, k-quad) as four b128 loads, forms the 4 frequency values with 4 float4
-// adds and writes them to 4 LDS planes; nothing but x, the packed filter and y touches HBM.  A
-// workgroup owns 64 output channels x 64 tiles (128 output pixels of one row each); each of its 4
-// waves keeps a 32x32 accumulator block for EVERY frequency (4 x 16 registers), so the output
-// transform is lane-local: no exchange between waves, one b128 store per (4 channels, pixel).
+// For 3x3 / stride 1 / pad 1 / dilation 1 / group 1 convs (util.conv_for, util.py:17-44).  The transform is applied along W
+// only: for every filter row r and input channel c the six frequencies of a 6-pixel segment give 4 outputs -- SIX GEMMs
+// M_f = U_f (Cout x 3 Cin) . V_f (3 Cin x tiles), 6 products per 4 outputs per 3 taps = 2x fewer MFMAs than the direct conv --
+// that SHARE ONE GATHER; nothing but x, the packed filter and y touches HBM.  (Its F(2,3) sibling -- four GEMMs, 1.5x fewer
+// MFMAs, conv_w1d_kernel, w_layout 5 -- lost to this kernel on every shape it was picked for and was removed in round 4:
+// layer1 62 us against 54 us)
 // K runs (filter row, input channel); the filter is packed once per model as
 //     uq[f][q = r*Cin/4 + c/4][co][4]   (zero padded to a multiple of 8 k-quads).
 
-struct W1dCfg {
-    static constexpr int BM = 64, BN = 64, BK = 16, KG = 4, THREADS = 256, F = 4;
-    static constexpr int A_PLANE = KG * BM * 4, B_PLANE = KG * BN * 4;          // floats per frequency plane
-    static constexpr int A_ELEMS = F * A_PLANE, B_ELEMS = F * B_PLANE;
-    static constexpr int LDS_BYTES = 2 * (A_ELEMS + B_ELEMS) * 4;               // 64 KB: two workgroups per CU
-};
-
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-conv_w1d_kernel(const ConvArgs p) {
-    using C = W1dCfg;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *As = smem;                         // [2][F][KG][BM][4]
-    float *Bs = smem + 2 * C::A_ELEMS;        // [2][F][KG][BN][4]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-
-    const TileCoord tc = tile_coord<C::BM, C::BN>(p);
-    const int m0 = tc.m0, col0 = tc.col0;
-    const int nchunks = (p.Qtot + C::KG - 1) / C::KG;
-
-    // per-row epilogue parameters: requested now, parked in LDS after the K loop
-    float prm_b = 0.f, prm_sc = 1.f, prm_sh = 0.f;
-    if (tid < C::BM) load_chan_params(p.ep, min(m0 + tid, p.Cout - 1), prm_b, prm_sc, prm_sh);
-
-    // ---- B: thread -> (tile column jl, k-quad kq = wave) --------------------------------------
-    const int jl = lane, kq = wave;
-    const int j = col0 + jl;
-    const bool jok = j < p.cols;
-    int ho = -(1 << 20), pixbase = 0;
-    bool cok[4] = {false, false, false, false};
-    if (jok) {
-        unsigned n, rem, h, t;
-        p.divHoWo.divmod((unsigned)j, n, rem);          // cols = N * H * Tw
-        p.divWo.divmod(rem, h, t);
-        ho = (int)h;
-        pixbase = ((int)n * p.Cq * p.H + ho) * p.W + 2 * (int)t - 1;       // quad index of d0, channel quad 0, r = 1
-#pragma unroll
-        for (int k = 0; k < 4; ++k) cok[k] = (unsigned)(2 * (int)t - 1 + k) < (unsigned)p.W;
-    }
-    constexpr int OOB = (int)0x80000000;
-    const __amdgpu_buffer_rsrc_t xrsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wrsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, p.w_bytes, 0x00020000);
-
-    // ---- A: float4 v = tid + i*256 -> (frequency i, k-quad (tid>>6), filter row tid&63) ----------
-    int aoff[C::F];
-#pragma unroll
-    for (int i = 0; i < C::F; ++i) {
-        const int row = tid & 63;
-        aoff[i] = m0 + row < p.Cout ? (((i * p.Qpad + (tid >> 6)) * p.Cout + m0 + row) << 4) : OOB;
-    }
-
-    // two staging register sets: loads run two chunks ahead of the MFMAs (as in conv_q4_kernel)
-    float4 breg0[4], breg1[4], areg0[C::F], areg1[C::F];
-    auto load_chunk = [&](int c, float4 (&breg)[4], float4 (&areg)[C::F]) {
-        const int q = c * C::KG + kq;                            // this thread's k-quad (wave-uniform)
-        const int r = (int)p.divCpt.div((unsigned)q);            // filter row
-        const int cq = q - r * p.cqg;
-        const int dy = q < p.Qtot ? r - 1 : (1 << 15);
-        const bool rok = (unsigned)(ho + dy) < (unsigned)p.H;
-        // channel quad and row shift are wave-uniform but may be negative (row -1): added on the
-        // vector side (the buffer's scalar offset is unsigned and escapes the range check)
-        const int vrow = (int)((unsigned)(pixbase + (cq * p.H + dy) * p.W) << 4);
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            breg[k] = __builtin_bit_cast(
-                float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, rok && cok[k] ? vrow + 16 * k : OOB, 0, 0));
-        const int ksoff = (c * C::KG * p.Cout) << 4;
-#pragma unroll
-        for (int i = 0; i < C::F; ++i)
-            areg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, aoff[i], ksoff, 0));
-    };
-    // input transform between the load and LDS: V_f = B^T d for the 4 pixels of this (tile, k-quad)
-    auto store_chunk = [&](int buf, const float4 (&breg)[4], const float4 (&areg)[C::F]) {
-        float *Ab = As + buf * C::A_ELEMS, *Bb = Bs + buf * C::B_ELEMS;
-        const float4 d0 = breg[0], d1 = breg[1], d2 = breg[2], d3 = breg[3];
-        float4 *bp = reinterpret_cast<float4 *>(Bb) + kq * C::BN + jl;
-        bp[0 * (C::B_PLANE / 4)] = make_float4(d0.x - d2.x, d0.y - d2.y, d0.z - d2.z, d0.w - d2.w);
-        bp[1 * (C::B_PLANE / 4)] = make_float4(d1.x + d2.x, d1.y + d2.y, d1.z + d2.z, d1.w + d2.w);
-        bp[2 * (C::B_PLANE / 4)] = make_float4(d2.x - d1.x, d2.y - d1.y, d2.z - d1.z, d2.w - d1.w);
-        bp[3 * (C::B_PLANE / 4)] = make_float4(d1.x - d3.x, d1.y - d3.y, d1.z - d3.z, d1.w - d3.w);
-#pragma unroll
-        for (int i = 0; i < C::F; ++i) reinterpret_cast<float4 *>(Ab)[i * 256 + tid] = areg[i];
-    };
-
-    f32x16 acc[C::F];
-#pragma unroll
-    for (int f = 0; f < C::F; ++f)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
-
-    const int l31 = lane & 31, lhi = lane >> 5;
-    const int a_off = (lhi * C::BM + wm * 32 + l31) * 4;      // k-quad 2u+lhi, row of the wave's 32-row block
-    const int b_off = (lhi * C::BN + wn * 32 + l31) * 4;
-
-    // fragments of k-quad pair u of all four frequencies (8 x ds_read_b128); HEAD = pair 0, TAIL = pair 1
-    float4 ha[C::F], hb[C::F], ta[C::F], tb[C::F];
-    auto read_frags = [&](int buf, int u, float4 (&af)[C::F], float4 (&bf)[C::F]) {
-        const float *Ab = As + buf * C::A_ELEMS + a_off + 2 * u * C::BM * 4;
-        const float *Bb = Bs + buf * C::B_ELEMS + b_off + 2 * u * C::BN * 4;
-#pragma unroll
-        for (int f = 0; f < C::F; ++f) {
-            af[f] = *reinterpret_cast<const float4 *>(Ab + f * C::A_PLANE);
-            bf[f] = *reinterpret_cast<const float4 *>(Bb + f * C::B_PLANE);
-        }
-    };
-    // 16 MFMAs, frequency innermost: consecutive MFMAs never depend on each other
-    auto mma = [&](const float4 (&af)[C::F], const float4 (&bf)[C::F]) {
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-            for (int f = 0; f < C::F; ++f) {
-                const float av = s4 == 0 ? af[f].x : s4 == 1 ? af[f].y : s4 == 2 ? af[f].z : af[f].w;
-                const float bv = s4 == 0 ? bf[f].x : s4 == 1 ? bf[f].y : s4 == 2 ? bf[f].z : bf[f].w;
-                acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[f], 0, 0, 0);
-            }
-    };
-
-    // Rotated pipeline, one barrier per chunk.  Step k (chunk k is published in LDS buffer k&1):
-    //   read HEAD fragments of chunk k | TAIL MFMAs of chunk k-1 (covers that latency) | write chunk
-    //   k+1 to LDS (transformed) | read TAIL fragments of chunk k | request chunk k+2 from HBM |
-    //   HEAD MFMAs of chunk k (cover the tail reads, the LDS writes and the loads) | barrier
-    const int last = nchunks - 1;
-    auto step = [&](auto parity, int k, bool with_tail) {
-        constexpr int P = decltype(parity)::value;
-        read_frags(P, 0, ha, hb);
-        __builtin_amdgcn_sched_barrier(0);
-        if (with_tail) mma(ta, tb);
-        if constexpr (P == 0) store_chunk(1, breg1, areg1);
-        else store_chunk(0, breg0, areg0);
-        __builtin_amdgcn_sched_barrier(0);
-        read_frags(P, 1, ta, tb);
-        if constexpr (P == 0) load_chunk(min(k + 2, last), breg0, areg0);
-        else load_chunk(min(k + 2, last), breg1, areg1);
-        mma(ha, hb);
-        __builtin_amdgcn_sched_barrier(0);     // keep the barrier (and the tail reads' wait) BEHIND the head MFMAs
-        __syncthreads();
-    };
-    using P0 = std::integral_constant<int, 0>;
-    using P1 = std::integral_constant<int, 1>;
-    load_chunk(0, breg0, areg0);
-    load_chunk(min(1, last), breg1, areg1);
-    store_chunk(0, breg0, areg0);
-    __syncthreads();
-    step(P0{}, 0, false);
-    int k = 1;
-    for (; k + 1 <= last; k += 2) {
-        step(P1{}, k, true);
-        step(P0{}, k + 1, true);
-    }
-    if (k <= last) step(P1{}, k, true);
-    mma(ta, tb);
-    // (past-the-end stores of the last steps rewrite the buffer that nobody reads any more with a
-    //  clamped duplicate of the last chunk)
-
-    // ---- epilogue: lane-local output transform + fused tail ------------------------------------------
-    if (tid < C::BM) {
-        smem[tid] = prm_b;
-        smem[C::BM + tid] = prm_sc;
-        smem[2 * C::BM + tid] = prm_sh;
-    }
-    __syncthreads();
-    const int jc = col0 + wn * 32 + l31;
-    if (jc >= p.cols) return;
-    unsigned n, rem, h, t;
-    p.divHoWo.divmod((unsigned)jc, n, rem);
-    p.divWo.divmod(rem, h, t);
-    const int wo = 2 * (int)t;
-    const bool second = wo + 1 < p.W;
-    float4 *y4 = reinterpret_cast<float4 *>(p.y);
-    const float4 *res4 = reinterpret_cast<const float4 *>(p.ep.res);
-    const float4 *prm4 = reinterpret_cast<const float4 *>(smem);
-    const unsigned obase = (n * (unsigned)p.Coq * (unsigned)p.H + h) * (unsigned)p.W + (unsigned)wo;
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    unsigned idx[4];
-    bool ok[4];
-    float4 rs0[4], rs1[4];
-#pragma unroll
-    for (int rq = 0; rq < 4; ++rq) {
-        const int R = m0 + wm * 32 + 8 * rq + 4 * lhi;            // first of 4 consecutive output channels
-        ok[rq] = R < p.Cout;
-        idx[rq] = obase + (unsigned)(R >> 2) * (unsigned)(p.H * p.W);
-        rs0[rq] = (res4 && ok[rq]) ? res4[idx[rq]] : z;
-        rs1[rq] = (res4 && ok[rq] && second) ? res4[idx[rq] + 1] : z;
-    }
-#pragma unroll
-    for (int rq = 0; rq < 4; ++rq) {
-        if (!ok[rq]) continue;
-        const int Rt = wm * 32 + 8 * rq + 4 * lhi;
-        const float4 bias = prm4[Rt >> 2], scale = prm4[(C::BM + Rt) >> 2], shift = prm4[(2 * C::BM + Rt) >> 2];
-        const int valid = p.Cout - (m0 + Rt);
-        float4 y0, y1;
-        float *a0 = reinterpret_cast<float *>(&y0), *a1 = reinterpret_cast<float *>(&y1);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float mA = acc[0][4 * rq + e], mB = acc[1][4 * rq + e], mC = acc[2][4 * rq + e], mD = acc[3][4 * rq + e];
-            a0[e] = (mA + mB) + mC;
-            a1[e] = (mB - mC) - mD;
-        }
-        y4[idx[rq]] = apply_epilogue4(p.ep, bias, scale, shift, rs0[rq], valid, y0);
-        if (second) y4[idx[rq] + 1] = apply_epilogue4(p.ep, bias, scale, shift, rs1[rq], valid, y1);
-    }
-}
 
 // =====================================================================================================
 // Fused 1-D Winograd F(4,3) along W: 6 frequencies, 4 outputs per tile, 6 products per 4 outputs per 3 taps
@@ -432,7 +217,7 @@ conv_w1d4_kernel(const ConvArgs p) {
         for (int b = 0; b < 4; ++b) {
             const float4 v = apply_epilogue4(p.ep, bias, scale, shift, rs[rq][b], valid, make_float4(o[b][0], o[b][1], o[b][2], o[b][3]));
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
-                                                   yrsrc, off[rq][b], 0, PLANER_STORE_AUX);
+                                                   yrsrc, off[rq][b], 0, 0);
         }
     }
 }
@@ -471,41 +256,5 @@ __global__ void __launch_bounds__(256) pack_filter_w1d4_kernel(const float *w, f
 #pragma unroll
         for (int f = 0; f < 6; ++f)
             reinterpret_cast<float4 *>(out)[f * plane + i] = make_float4(uu[f][0], uu[f][1], uu[f][2], uu[f][3]);
-    }
-}
-
-// OIHW 3x3 -> uq[f][q = r*cqg + cin/4][co][4]  (zero padded: k-quads to Qpad, channels to 4)
-__global__ void __launch_bounds__(256) pack_filter_w1d_kernel(const float *w, float *out, unsigned total, int Cout,
-                                                              int Cin, int cqg, int Qtot, int Qpad, FastDiv divCo,
-                                                              FastDiv divCqg) {
-    const unsigned stride = gridDim.x * 256;
-    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {   // i = q*Cout + co
-        unsigned q, co;
-        divCo.divmod(i, q, co);
-        float4 u[4] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f),
-                       make_float4(0.f, 0.f, 0.f, 0.f)};
-        if ((int)q < Qtot) {
-            unsigned r, cq;
-            divCqg.divmod(q, r, cq);
-            float uu[4][4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int c = (int)cq * 4 + e;
-                float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-                if (c < Cin) {
-                    const float *g = w + (((size_t)co * Cin + c) * 3 + r) * 3;
-                    g0 = g[0]; g1 = g[1]; g2 = g[2];
-                }
-                uu[0][e] = g0;
-                uu[1][e] = 0.5f * (g0 + g1 + g2);
-                uu[2][e] = 0.5f * (g0 - g1 + g2);
-                uu[3][e] = g2;
-            }
-#pragma unroll
-            for (int f = 0; f < 4; ++f) u[f] = make_float4(uu[f][0], uu[f][1], uu[f][2], uu[f][3]);
-        }
-        const size_t plane = (size_t)Qpad * Cout;
-#pragma unroll
-        for (int f = 0; f < 4; ++f) reinterpret_cast<float4 *>(out)[f * plane + i] = u[f];
     }
 }

@@ -259,7 +259,7 @@ __device__ __forceinline__ void wf4_output_row_coalesced(const Wf4Args &p, const
             o = apply_epilogue4(rest, z4, z4, z4, RES ? rs[q] : z4, 4, v[q]);
         }
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o),
-                                               yrsrc, off[q], 0, PLANER_STORE_AUX);
+                                               yrsrc, off[q], 0, 0);
     }
 }
 

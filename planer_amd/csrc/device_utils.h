@@ -4,11 +4,6 @@
 
 // Exact unsigned 32-bit division by a launch-invariant divisor
 // (Granlund & Montgomery round-up method): q = n / d for every n < 2^32.
-// cache policy of the epilogues' output stores (raw_buffer_store aux: 1 sc0, 2 nt, 16 sc1)
-#ifndef PLANER_STORE_AUX
-#define PLANER_STORE_AUX 0
-#endif
-
 struct FastDiv {
     unsigned m, s1, s2, d;
     FastDiv() : m(1), s1(0), s2(0), d(1) {}

@@ -36,7 +36,7 @@ _ALIGN = 256
 
 # ConvQ4 / ConvFused w_layout codes -> what runs (for run reports)
 W_LAYOUT_NAMES = {0: "igemm-nchw", 1: "tap-nchw", 2: "direct-q4 (conv_q4_kernel)", 3: "wino2x2-nchw",
-                  4: "wino2x2-q4 (transforms + grouped conv_q4_kernel)", 5: "w1d F(2,3) (conv_w1d_kernel)",
+                  4: "wino2x2-q4 (transforms + grouped conv_q4_kernel)",
                   6: "rowpack-q4 (nchw_to_rowpack + conv_q4_kernel)",
                   7: "wino4x4-q4 (transforms + grouped conv_q4_kernel)", 8: "w1d4 F(4,3) (conv_w1d4_kernel)",
                   9: "wf4 fused F(4x4,3x3) (conv_wf4_kernel)"}
@@ -459,12 +459,11 @@ class Net:
                 elif (use_wino and _q4.w1d_q4_eligible(K.shape, **para)
                         and shapes.get(srcs[0].split("@")[0]) is not None):
                     lay = self._pick_conv_algo(_q4.ConvQ4, K, srcs, entry[2], shapes, wmap, q4=True)
-                key = {2: "%s@q4g%d" % (srcs[1], group), 4: srcs[1] + "@winoq4", 5: srcs[1] + "@w1dq4",
+                key = {2: "%s@q4g%d" % (srcs[1], group), 4: srcs[1] + "@winoq4",
                        6: srcs[1] + "@rowpack", 7: srcs[1] + "@wino4q4", 8: srcs[1] + "@w1d4q4", 9: srcs[1] + "@wf4q4"}[lay]
                 if key not in self._extra:
                     self._extra[key] = {2: lambda: _q4.prepare_q4_weights(K, group),
                                         4: lambda: _q4.prepare_winograd_q4_weights(K),
-                                        5: lambda: _q4.prepare_w1d_q4_weights(K),
                                         6: lambda: _q4.prepare_rowpack_weights(K),
                                         7: lambda: _q4.prepare_winograd4_q4_weights(K),
                                         8: lambda: _q4.prepare_w1d4_q4_weights(K),
@@ -484,9 +483,6 @@ class Net:
                     srcs[1] = key
                     out_body[name] = [name, "conv_fused", dict(entry[2], w_layout=lay)]
             out_flow.append([srcs, [name], dst])
-        # conv + maxpool in one kernel: bit-identical, measured SLOWER on ResNet-18's stem -> opt-in
-        if os.environ.get("PLANER_HIP_FUSE_POOL", "0") != "0":
-            out_flow = self._fuse_conv_maxpool(out_body, out_flow)
         out_flow = self._fuse_upsample_concat(out_body, out_flow)
         used = {n for _, names, _ in out_flow for n in names}
         out_list = [out_body[b[0]] for b in body if b[0] in used]
@@ -532,37 +528,9 @@ class Net:
                     drop.add(i)
         return [out.get(i, f) for i, f in enumerate(flow) if i not in drop]
 
-    @staticmethod
-    def _fuse_conv_maxpool(body, flow):
-        """conv_q4 (direct kernel, no residual) whose only reader is maxpool_q4(w=3x3, strides 2, pads 1) -> one
-        conv_q4 step with pool=True (csrc/conv_q4_kernel.h, POOL): the full-resolution tensor is never written."""
-        readers = {}
-        for i, (src, names, dst) in enumerate(flow):
-            for k in (src if isinstance(src, list) else [src]):
-                readers.setdefault(k, []).append(i)
-        drop, out = set(), []
-        for i, (src, names, dst) in enumerate(flow):
-            entry = body[names[0]]
-            if (entry[1] == "conv_q4" and entry[2].get("w_layout") in (2, 6) and isinstance(dst, str)
-                    and (len(src) < 6 or src[5] == "None") and len(readers.get(dst, [])) == 1):
-                j = readers[dst][0]
-                psrc, pnames, pdst = flow[j]
-                pe = body[pnames[0]]
-                if (pe[1] == "maxpool_q4" and len(pnames) == 1 and (psrc == dst or psrc == [dst])
-                        and [int(v) for v in pe[2].get("w", (2, 2))] == [3, 3]
-                        and [int(v) for v in pe[2].get("strides", (2, 2))] == [2, 2]
-                        and [int(v) for v in pe[2].get("pads", (0, 0, 0, 0))] == [1, 1, 1, 1]):
-                    body[names[0]] = [entry[0], "conv_q4", dict(entry[2], pool=True)]
-                    out.append([src, names, pdst])
-                    drop.add(j)
-                    continue
-            if i not in drop:
-                out.append([src, names, dst])
-        return out
-
     def _pick_conv_algo(self, ConvFused, K, srcs, para, shapes, wmap, q4=False):
         """Time the direct implicit GEMM and the Winograd variants for this conv's real shape and
-        epilogue; -> w_layout 1 or 3 (NCHW), 2 / 5 / 8 / 4 / 7 (channel-quad).  Cached per shape
+        epilogue; -> w_layout 1 or 3 (NCHW), 2 / 8 / 4 / 7 / 9 (channel-quad).  Cached per shape
         signature (and persisted, see `algo_cache`); `force_algo` bypasses the measurement."""
         from .layer import prepare_conv_weights, prepare_winograd_weights
         xs = tuple(shapes[srcs[0].split("@")[0]])
@@ -570,8 +538,8 @@ class Net:
         sig = (q4, xs, tuple(K.shape), tuple(has), para.get("act", 0))
         cands = [(1, prepare_conv_weights), (3, prepare_winograd_weights)]
         if q4:
-            # direct, fused 1-D Winograd along W (F(2,3) and F(4,3)), 2-D Winograd pipelines with separate transform kernels
-            cands = [(2, _q4.prepare_q4_weights), (5, _q4.prepare_w1d_q4_weights), (8, _q4.prepare_w1d4_q4_weights)]
+            # direct, fused 1-D Winograd F(4,3) along W, 2-D Winograd pipelines with separate transform kernels, fully fused F(4x4,3x3)
+            cands = [(2, _q4.prepare_q4_weights), (8, _q4.prepare_w1d4_q4_weights)]
             if _q4.winograd_q4_eligible(K.shape, **{k: v for k, v in para.items()
                                                    if k in ("group", "strides", "dilations", "pads")}):
                 cands.append((4, _q4.prepare_winograd_q4_weights))
@@ -912,7 +880,7 @@ class Net:
         return plan
 
     def _pack_static_inputs(self, prog, statics, inplace):
-        """A graph input whose ONLY reader is the row-packed stem conv (w_layout 6, no fused pool) gets its row-packed image
+        """A graph input whose ONLY reader is the row-packed stem conv (w_layout 6) gets its row-packed image
         as a persistent buffer beside it (`static.packed`): the captured conv reads that image, the re-layout kernel stays
         out of the graph and runs when the plan is fed (`_feed_static`) -- as the copy that brings the batch in.
         PLANER_HIP_FEED_PACK=0 keeps the re-layout inside the graph."""
@@ -925,7 +893,7 @@ class Net:
             src, names = readers[0]
             obj = prog.objs[_as_list(names)[0]]
             para = obj.para()
-            if (obj.name != "conv_q4" or para.get("w_layout") != 6 or para.get("pool") or _as_list(src)[0] != k
+            if (obj.name != "conv_q4" or para.get("w_layout") != 6 or _as_list(src)[0] != k
                     or _as_list(src).count(k) != 1):
                 continue
             kw = self._shape_of_init(_as_list(src)[1])[3]

@@ -356,7 +356,7 @@ def pair_sibling_convs(body, flow, kshape=lambda key: None):
         full = srcs + ["None"] * (6 - len(srcs))
         return (kind == "conv_q4" and para.get("w_layout") == 2 and isinstance(dst, str) and full[5] == "None"
                 and int(para.get("group", 1)) == 1 and [int(v) for v in para.get("dilations", (1, 1))] == [1, 1]
-                and not para.get("pool") and not para.get("rowpack") and not (int(para.get("act", 0)) & ~3))
+                and not para.get("rowpack") and not (int(para.get("act", 0)) & ~3))
 
     used, npairs, out = set(), 0, []
     for i in range(len(steps)):

@@ -145,20 +145,6 @@ def prepare_rowpack_weights(K):
     return out
 
 
-def prepare_w1d_q4_weights(K):
-    """OIHW 3x3 filters -> 1-D Winograd filters [4][row*Cin/4 + cin/4][Cout][4] (ConvQ4 w_layout=5)."""
-    _f32(K)
-    cout, cin, kh, kw = K.shape
-    if (kh, kw) != (3, 3) or cin % 4:
-        raise ValueError("1-D winograd filters need 3x3 kernels and Cin % 4 == 0")
-    n = ctypes.c_size_t()
-    _lib.call("pl_conv2d_w1d_q4_filter_elems", cout, cin, ctypes.byref(n))
-    out = empty((n.value,), ctx=K.ctx)
-    _lib.call("pl_conv2d_prepare_w1d_q4_f32", K.ctx.handle, K.ptr, cout, cin, out.ptr)
-    out.shape = K.shape
-    return out
-
-
 def prepare_w1d4_q4_weights(K):
     """OIHW 3x3 filters -> fused 1-D Winograd F(4,3) filters [6][row*Cin/4 + cin/4][Cout][4] (w_layout=8)."""
     _f32(K)
@@ -196,14 +182,11 @@ def pack_rows(x, geom=None, src_ptr=None, ctx=None):
 
 
 def ConvQ4(xq, Kq, B=None, scale=None, shift=None, resq=None, group=1, strides=(1, 1),
-           dilations=(1, 1), pads=(0, 0, 0, 0), act=ACT_NONE, alpha=0.0, w_layout=2, pool=False, **_):
+           dilations=(1, 1), pads=(0, 0, 0, 0), act=ACT_NONE, alpha=0.0, w_layout=2, **_):
     """layer.ConvFused on Q4 tensors: act((conv(x,K)+B)*scale + shift + res), all activations Q4.
     w_layout=2: Kq from prepare_q4_weights(); w_layout=4: Winograd filters from
-    prepare_winograd_q4_weights().  pool=True (w_layout 2 / 6, no residual): the conv is followed by
-    layer.Maxpool(w=3x3, strides 2, pads 1) inside the same kernel and the POOLED tensor comes back."""
+    prepare_winograd_q4_weights(); 6 row-packed stem, 7 staged / 9 fused F(4x4,3x3), 8 fused 1-D F(4,3)."""
     _f32(xq, Kq, B, scale, shift, resq)
-    if pool and (w_layout not in (2, 6) or resq is not None):
-        raise ValueError("conv + maxpool fusion serves the direct channel-quad kernels without a residual")
     if w_layout == 6:
         # row-packed stem: the input is the reference's NCHW tensor, the output is Q4
         if is_q4(xq) or (resq is not None and not is_q4(resq)):
@@ -216,11 +199,6 @@ def ConvQ4(xq, Kq, B=None, scale=None, shift=None, resq=None, group=1, strides=(
             raise ValueError("conv: weight %s does not match input %s" % (Kq.shape, xq.shape))
         pads, strides = [int(p) for p in pads], [int(s) for s in strides]
         ho, wo = conv_out_hw(h, w, kh, kw, strides, [1, 1], pads)
-        if pool:
-            y = _new_q4(n, cout, (ho + 1) // 2, (wo + 1) // 2, xq.ctx)
-            _lib.call("pl_conv2d_rowpack_pool_q4_f32", xq.ctx.handle, xq.ptr, n, cin, h, w, Kq.ptr, cout, kh, kw, _ptr(B), y.ptr,
-                      strides[0], strides[1], pads[0], pads[1], _ptr(scale), _ptr(shift), int(act), float(alpha))
-            return y
         y = _new_q4(n, cout, ho, wo, xq.ctx)
         if resq is not None and resq.shape != y.shape:
             raise ValueError("fused residual shape %s != conv output %s" % (resq.shape, y.shape))
@@ -242,21 +220,13 @@ def ConvQ4(xq, Kq, B=None, scale=None, shift=None, resq=None, group=1, strides=(
     strides = [int(s) for s in strides]
     dilations = [int(d) for d in dilations]
     ho, wo = conv_out_hw(h, w, kh, kw, strides, dilations, pads)
-    if pool:
-        if pads[0] != pads[2] or pads[1] != pads[3]:
-            raise NotImplementedError("asymmetric pads are undefined in the reference (util.py:8)")
-        y = _new_q4(n, cout, (ho + 1) // 2, (wo + 1) // 2, xq.ctx)
-        _lib.call("pl_conv2d_pool_q4_f32", xq.ctx.handle, xq.ptr, n, cin, h, w, Kq.ptr, cout, kh, kw, _ptr(B), y.ptr,
-                  strides[0], strides[1], dilations[0], dilations[1], pads[0], pads[1], int(group), _ptr(scale), _ptr(shift),
-                  int(act), float(alpha))
-        return y
     y = _new_q4(n, cout, ho, wo, xq.ctx)
     if resq is not None and resq.shape != y.shape:
         raise ValueError("fused residual shape %s != conv output %s" % (resq.shape, y.shape))
-    if w_layout in (5, 8):
+    if w_layout == 8:
         if not w1d_q4_eligible(Kq.shape, group, strides, dilations, pads):
             raise ValueError("1-D winograd filters serve 3x3 / stride 1 / pad 1 / group 1 convs only")
-        _lib.call("pl_conv2d_w1d_q4_f32" if w_layout == 5 else "pl_conv2d_w1d4_q4_f32", xq.ctx.handle, xq.ptr, n, cin, h, w, Kq.ptr, cout, _ptr(B), y.ptr,
+        _lib.call("pl_conv2d_w1d4_q4_f32", xq.ctx.handle, xq.ptr, n, cin, h, w, Kq.ptr, cout, _ptr(B), y.ptr,
                   _ptr(scale), _ptr(shift), _ptr(resq), int(act), float(alpha))
         return y
     if w_layout in (4, 7, 9):

@@ -52,6 +52,6 @@ def _default_plan_environment(monkeypatch):
     """Tests describe the DEFAULT plan compiler: experiment switches inherited from the caller's shell are dropped
     (a test that wants one sets it itself)."""
     for k in ("PLANER_HIP_GRAPH", "PLANER_HIP_FUSE", "PLANER_HIP_Q4", "PLANER_HIP_WINOGRAD", "PLANER_HIP_WINOGRAD4",
-              "PLANER_HIP_ROWPACK", "PLANER_HIP_TAPMAJOR", "PLANER_HIP_STREAMS", "PLANER_HIP_CONV_ALGO", "PLANER_HIP_FUSE_POOL",
+              "PLANER_HIP_ROWPACK", "PLANER_HIP_TAPMAJOR", "PLANER_HIP_STREAMS", "PLANER_HIP_CONV_ALGO",
               "PLANER_HIP_WINO_CHAIN", "PLANER_HIP_WINO_LDS", "PLANER_HIP_WINO_G", "PLANER_HIP_WINO_BD", "PLANER_HIP_FEED_PACK", "PLANER_HIP_SMALLCIN_WIDE", "PLANER_HIP_WINO_GEMM_AS"):
         monkeypatch.delenv(k, raising=False)

@@ -78,7 +78,7 @@ def test_throughput_plan_batch32_full_size(pa, r18, streams):
 
 
 LAYER_SHAPES = [(64, 56), (128, 28), (256, 14), (512, 7)]       # ResNet-18 layer1..4 stride-1 3x3 convs
-ALGOS = [2, 5, 8, 4, 7, 9]      # 9 = the fully fused F(4x4,3x3) kernel (conv_wf4_kernel), what layer1 runs
+ALGOS = [2, 8, 4, 7, 9]      # 9 = the fully fused F(4x4,3x3) kernel (conv_wf4_kernel), what layer1 runs
 
 
 @pytest.mark.parametrize("chan,size", LAYER_SHAPES, ids=["layer%d" % (i + 1) for i in range(4)])
@@ -94,7 +94,7 @@ def test_every_algorithm_at_real_layer_shapes_batch32(pa, chan, size):
     want = {True: onp.relu(onp.batchnorm(conv, sc, sh) + res), False: onp.relu(onp.batchnorm(conv, sc, sh))}
     xq, rq = q4.to_q4(pa.asarray(x)), q4.to_q4(pa.asarray(res))
     dk, dsc, dsh = pa.asarray(k), pa.asarray(sc), pa.asarray(sh)
-    prep = {2: q4.prepare_q4_weights, 5: q4.prepare_w1d_q4_weights, 8: q4.prepare_w1d4_q4_weights,
+    prep = {2: q4.prepare_q4_weights, 8: q4.prepare_w1d4_q4_weights,
             4: q4.prepare_winograd_q4_weights, 7: q4.prepare_winograd4_q4_weights, 9: q4.prepare_wf4_q4_weights}
     for lay in ALGOS:
         kq = prep[lay](dk)

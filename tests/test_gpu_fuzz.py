@@ -98,22 +98,15 @@ def test_random_conv_every_eligible_kernel_family(pa, seed):
         if q4.rowpack_eligible(K.shape, **para) and c["cin"] < 4:
             fams.append((6, lambda: q4.prepare_rowpack_weights(dK), dx))
         if q4.w1d_q4_eligible(K.shape, **para):
-            fams += [(5, lambda: q4.prepare_w1d_q4_weights(dK), xq), (8, lambda: q4.prepare_w1d4_q4_weights(dK), xq)]
+            fams += [(8, lambda: q4.prepare_w1d4_q4_weights(dK), xq)]
         if q4.winograd_q4_eligible(K.shape, **para):
-            fams += [(4, lambda: q4.prepare_winograd_q4_weights(dK), xq), (7, lambda: q4.prepare_winograd4_q4_weights(dK), xq)]
+            fams += [(4, lambda: q4.prepare_winograd_q4_weights(dK), xq), (7, lambda: q4.prepare_winograd4_q4_weights(dK), xq),
+                     (9, lambda: q4.prepare_wf4_q4_weights(dK), xq)]
         for lay, prep, xin in fams:
             yq = q4.ConvQ4(xin, prep(), dB, dsc, dsh, rq, act=act, alpha=alpha, w_layout=lay, **para)
             plan = pa.hip.context().last_conv_plan()
             assert_close(q4.from_q4(yq).get(), want, RTOL, "ConvQ4 w_layout %d [%s] %s" % (lay, plan, what))
             ran.append(lay)
-            if lay in (2, 6) and res is None:            # + the fused max-pool tail
-                pool = dict(w=[3, 3], pads=[1, 1, 1, 1], strides=[2, 2])
-                two = q4.MaxpoolQ4(yq, **pool)
-                one = q4.ConvQ4(xin, prep(), dB, dsc, dsh, None, act=act, alpha=alpha, w_layout=lay, pool=True, **para)
-                assert one.shape == two.shape
-                if plan.startswith("q") and "split=1 " in plan:     # same K order as the unsplit conv kernel: bit-identical
-                    np.testing.assert_array_equal(one.get(), two.get())
-                assert_close(q4.from_q4(one).get(), onp.maxpool(want, **pool), RTOL, "conv+maxpool w_layout %d %s" % (lay, what))
     assert len(ran) >= 1
 
 

@@ -192,34 +192,6 @@ def test_pointwise_q4_layers_match_nchw_kernels(pa):
     np.testing.assert_array_equal(q4.from_q4(q4.SigmoidQ4(q4.to_q4(pa.asarray(a)))).get(), pa.Sigmoid(pa.asarray(a)).get())
 
 
-def test_winograd_1d_fused_matches_oracle(pa):
-    """Fused 1-D Winograd F(2,3) along W (conv_w1d_kernel): odd / even widths (a half tile at the
-    right edge), Cout not a multiple of 64 or of 4, K tails, with and without the fused tail."""
-    from planer_amd import q4
-    rng = np.random.default_rng(29)
-    for (n, cin, h, w, cout) in [(2, 16, 7, 7, 24), (3, 20, 14, 13, 44), (1, 64, 9, 12, 64), (2, 48, 28, 28, 130),
-                                 (1, 8, 5, 1, 6), (2, 4, 6, 2, 3)]:
-        x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
-        k = (rng.standard_normal((cout, cin, 3, 3)) * 0.1).astype(np.float32)
-        b = rng.standard_normal(cout).astype(np.float32)
-        sc = rng.uniform(0.5, 1.5, (1, cout, 1, 1)).astype(np.float32)
-        sh = rng.standard_normal((1, cout, 1, 1)).astype(np.float32)
-        res = rng.standard_normal((n, cout, h, w)).astype(np.float32)
-        xq = q4.to_q4(pa.asarray(x))
-        U = q4.prepare_w1d_q4_weights(pa.asarray(k))
-        yq = q4.ConvQ4(xq, U, pa.asarray(b), pads=[1, 1, 1, 1], w_layout=5)
-        y = q4.from_q4(yq).get()
-        ref = np.ascontiguousarray(onp.conv2d(x, k, b, pads=[1, 1, 1, 1]))
-        assert_close(y, ref, RTOL, "winograd-1d %s" % ((n, cin, h, w, cout),))
-        np.testing.assert_array_equal(yq.get(), q4_host(y))            # padding lanes stay zero
-        y = q4.from_q4(q4.ConvQ4(xq, U, None, pa.asarray(sc), pa.asarray(sh), q4.to_q4(pa.asarray(res)),
-                                 pads=[1, 1, 1, 1], act=1, w_layout=5)).get()
-        ref = onp.relu(onp.batchnorm(np.ascontiguousarray(onp.conv2d(x, k, pads=[1, 1, 1, 1])), sc, sh) + res)
-        assert_close(y, ref, RTOL, "winograd-1d fused")
-    with pytest.raises(ValueError):
-        q4.ConvQ4(xq, U, pads=[0, 0, 0, 0], w_layout=5)
-
-
 def test_rowpack_stem_conv_matches_oracle(pa):
     """Row-packed convolution for 1..3 input channels (pl_conv2d_rowpack_q4_f32): NCHW in, Q4 out;
     K runs (filter row, quads of the kw*Cin row segment) over a zero-padded NHWC copy of the input."""
@@ -349,74 +321,6 @@ def test_winograd_1d_f43_fused_matches_oracle(pa):
     assert worst < 3e-5
 
 
-def test_persistent_producer_consumer_configs_match_oracle(pa):
-    """conv_pc_kernel (512-thread persistent workgroups, LDS-DMA producers, MFMA-only consumers): every
-    p* tile configuration on ragged shapes, groups, strides, dilation, several tiles per workgroup, and
-    the fused tail with a residual -- same tolerance as the 256-thread kernels."""
-    from planer_amd import q4
-    ctx = pa.hip.context()
-    names = _cfg_names(pa)
-    pnames = [n for n in names if n.startswith("p")]
-    assert len(pnames) >= 3
-    rng = np.random.default_rng(31)
-    shapes = [((2, 20, 13, 11), (70, 20, 3, 3), dict(strides=[2, 2], pads=[1, 1, 1, 1])),
-              ((3, 32, 14, 14), (40, 32, 3, 3), dict(strides=[1, 1], pads=[1, 1, 1, 1])),
-              ((2, 64, 7, 7), (130, 64, 1, 1), dict()),
-              ((2, 64, 9, 9), (48, 32, 3, 3), dict(pads=[2, 2, 2, 2], dilations=[2, 2], group=2)),
-              ((5, 24, 17, 19), (300, 24, 3, 3), dict(pads=[1, 1, 1, 1])),
-              ((40, 16, 40, 40), (64, 16, 3, 3), dict(pads=[1, 1, 1, 1]))]       # 1000 tiles of 64x64: many per workgroup
-    try:
-        for xs, ks, p in shapes:
-            x = rng.standard_normal(xs).astype(np.float32)
-            k = (rng.standard_normal(ks) * 0.1).astype(np.float32)
-            cout = ks[0]
-            sc = rng.uniform(0.5, 1.5, (1, cout, 1, 1)).astype(np.float32)
-            sh = rng.standard_normal((1, cout, 1, 1)).astype(np.float32)
-            conv = np.ascontiguousarray(onp.conv2d(x, k, **p))
-            res = rng.standard_normal(conv.shape).astype(np.float32)
-            ref = onp.relu(onp.batchnorm(conv, sc, sh) + res)
-            xq, rq = q4.to_q4(pa.asarray(x)), q4.to_q4(pa.asarray(res))
-            kq = q4.prepare_q4_weights(pa.asarray(k), p.get("group", 1))
-            dsc, dsh = pa.asarray(sc), pa.asarray(sh)
-            for name in pnames:
-                ctx.set_conv_config(names.index(name), 1)
-                yq = q4.ConvQ4(xq, kq, None, dsc, dsh, rq, act=1, **p)
-                assert ctx.last_conv_plan().startswith(name), ctx.last_conv_plan()
-                y = q4.from_q4(yq).get()
-                assert_close(y, ref, RTOL, "cfg %s %s" % (name, xs))
-                np.testing.assert_array_equal(yq.get(), q4_host(y))          # padding lanes stay zero
-                y2 = q4.from_q4(q4.ConvQ4(xq, kq, None, dsc, dsh, rq, act=1, **p)).get()
-                np.testing.assert_array_equal(y, y2)                         # deterministic
-        # K too short for the persistent kernel's parameter hand-off: it must step aside, not misbehave
-        ctx.set_conv_config(names.index(pnames[0]), 1)
-        x = rng.standard_normal((2, 8, 6, 6)).astype(np.float32)
-        k = rng.standard_normal((8, 8, 1, 1)).astype(np.float32)
-        y = q4.from_q4(q4.ConvQ4(q4.to_q4(pa.asarray(x)), q4.prepare_q4_weights(pa.asarray(k)), None)).get()
-        assert not ctx.last_conv_plan().startswith("p")
-        assert_close(y, np.ascontiguousarray(onp.conv2d(x, k)), RTOL)
-    finally:
-        ctx.set_conv_config(-1, 0)
-
-
-def test_w1d4_persistent_variant_matches_oracle(pa, monkeypatch):
-    """conv_w1d4_pc_kernel (opt-in, PLANER_HIP_W1D4_PC=1): same arithmetic as conv_w1d4_kernel."""
-    from planer_amd import q4
-    ctx = pa.hip.context()
-    monkeypatch.setenv("PLANER_HIP_W1D4_PC", "1")
-    rng = np.random.default_rng(41)
-    for n, c, h, w, co in [(2, 16, 9, 11, 24), (3, 32, 13, 17, 70), (8, 64, 28, 28, 64), (40, 16, 20, 36, 130)]:
-        x = rng.standard_normal((n, c, h, w)).astype(np.float32)
-        k = (rng.standard_normal((co, c, 3, 3)) * 0.1).astype(np.float32)
-        sc = rng.uniform(0.5, 1.5, (1, co, 1, 1)).astype(np.float32)
-        sh = rng.standard_normal((1, co, 1, 1)).astype(np.float32)
-        res = rng.standard_normal((n, co, h, w)).astype(np.float32)
-        ref = onp.relu(onp.batchnorm(np.ascontiguousarray(onp.conv2d(x, k, pads=[1, 1, 1, 1])), sc, sh) + res)
-        yq = q4.ConvQ4(q4.to_q4(pa.asarray(x)), q4.prepare_w1d4_q4_weights(pa.asarray(k)), None, pa.asarray(sc),
-                       pa.asarray(sh), q4.to_q4(pa.asarray(res)), pads=[1, 1, 1, 1], act=1, w_layout=8)
-        assert ctx.last_conv_plan().startswith("w1d4pc"), ctx.last_conv_plan()
-        assert_close(q4.from_q4(yq).get(), ref, RTOL, "w1d4pc %s" % ((n, c, h, w, co),))
-
-
 def test_q4_stem_maxpool_block_kernel_is_bit_exact(pa):
     """maxpool_q4_k3s2p1_2x1 (a thread = two vertically adjacent outputs from one 5x3 window): odd / even extents, negative
     inputs (zero padding and the -1e4 start of util.py:88,95 show), against the oracle and the NCHW kernel."""
@@ -429,48 +333,6 @@ def test_q4_stem_maxpool_block_kernel_is_bit_exact(pa):
         want = onp.maxpool(x, (3, 3), (1, 1, 1, 1), (2, 2))
         np.testing.assert_array_equal(q4.from_q4(yq).get(), want)
         np.testing.assert_array_equal(yq.get(), q4_host(want))
-
-
-@pytest.mark.parametrize("shape", [
-    # (N, Cin, H, W, Cout, k, stride, pad)
-    (2, 8, 23, 29, 12, 3, 1, 1),        # ragged everything: odd map, Cout under one tile, patches hang over the edge
-    (1, 16, 56, 56, 130, 3, 1, 1),      # three 64-row tiles of output channels, the last one ragged
-    (3, 3, 37, 41, 64, 7, 2, 3),        # the row-packed stem gather (Cin = 3), stride 2
-    (2, 3, 224, 224, 64, 7, 2, 3),      # ResNet-18's stem at full size: 7 x 8 patches of 56 x 56
-    (1, 4, 9, 7, 8, 1, 1, 0),           # 1x1 conv, a map smaller than one patch
-])
-def test_conv_maxpool_fused_kernel_is_bit_exact(pa, shape):
-    """conv (+bias, bn, relu) + maxpool(3x3, s2, p1) in one kernel == the conv kernel followed by the pool kernel,
-    bit for bit (same accumulation order per conv pixel; max is exact), and matches the oracle."""
-    from planer_amd import q4
-    n, cin, h, w, cout, k, st, pd = shape
-    rng = np.random.default_rng(sum(shape))
-    x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
-    K = (rng.standard_normal((cout, cin, k, k)) * 0.2).astype(np.float32)
-    B = rng.standard_normal(cout).astype(np.float32)
-    sc = rng.uniform(0.5, 1.5, (1, cout, 1, 1)).astype(np.float32)
-    sh = (rng.standard_normal((1, cout, 1, 1)) * 0.3).astype(np.float32)
-    para = dict(strides=[st, st], pads=[pd] * 4, dilations=[1, 1], group=1)
-    dK, dB, dsc, dsh = pa.asarray(K), pa.asarray(B), pa.asarray(sc), pa.asarray(sh)
-    rowpack = cin < 4 and q4.rowpack_eligible(K.shape, **para)
-    if rowpack:
-        xin, Kq, lay = pa.asarray(x), q4.prepare_rowpack_weights(dK), 6
-    else:
-        xin, Kq, lay = q4.to_q4(pa.asarray(x)), q4.prepare_q4_weights(dK), 2
-    for act in (1, 0):                      # relu / none: without relu negative maxima meet the zero padding
-        conv_q = q4.ConvQ4(xin, Kq, dB, dsc, dsh, None, act=act, w_layout=lay, **para)
-        two = q4.MaxpoolQ4(conv_q, w=[3, 3], pads=[1, 1, 1, 1], strides=[2, 2])
-        unfused_plan = pa.hip.context().last_conv_plan()
-        one = q4.ConvQ4(xin, Kq, dB, dsc, dsh, None, act=act, w_layout=lay, pool=True, **para)
-        assert "maxpool" in pa.hip.context().last_conv_plan()
-        assert one.shape == two.shape and one.chan == two.chan
-        if unfused_plan.startswith("q") and "split=1 " in unfused_plan:      # same K order as the unsplit conv kernel
-            np.testing.assert_array_equal(one.get(), two.get())
-        else:
-            assert_close(one.get(), two.get(), 1e-6, "conv+maxpool vs two kernels [%s]" % unfused_plan)
-        conv = onp.batchnorm(onp.conv2d(x, K, B, **para), sc, sh)
-        want = onp.maxpool(onp.relu(conv) if act else conv, w=[3, 3], pads=[1, 1, 1, 1], strides=[2, 2])
-        assert_close(q4.from_q4(one).get(), want, RTOL, "conv+maxpool %s act %d" % (shape, act))
 
 
 def test_upsample_concat_one_kernel_is_bit_exact(pa):

@@ -82,12 +82,9 @@ if "--resnet" in sys.argv or len(sys.argv) == 1:
             t_r = timeit(lambda: q4.ConvQ4(x, wr, None, sc, sh, resq, act=1, w_layout=6, **kw))
             extra = " | row-packed (incl. input re-layout) %7.1f us %6.1f TF" % (t_r * 1e3, fl / t_r / 1e9)
         if q4.w1d_q4_eligible(ks, **kw):
-            uq = q4.prepare_w1d_q4_weights(k)
-            t_w = timeit(lambda: q4.ConvQ4(xq, uq, None, sc, sh, resq, act=1, w_layout=5, **kw))
-            extra = " | winograd-1d %7.1f us %6.1f TF (alg.)" % (t_w * 1e3, fl / t_w / 1e9)
             u8 = q4.prepare_w1d4_q4_weights(k)
             t_8 = timeit(lambda: q4.ConvQ4(xq, u8, None, sc, sh, resq, act=1, w_layout=8, **kw))
-            extra += " | 1-D F(4,3) %7.1f us %6.1f TF" % (t_8 * 1e3, fl / t_8 / 1e9)
+            extra = " | 1-D F(4,3) %7.1f us %6.1f TF" % (t_8 * 1e3, fl / t_8 / 1e9)
             if xs[0] <= 32:
                 u2 = q4.prepare_winograd_q4_weights(k)
                 t_2 = timeit(lambda: q4.ConvQ4(xq, u2, None, sc, sh, resq, act=1, w_layout=4, **kw))

@@ -15,7 +15,7 @@ import planer_amd  # noqa: E402
 from planer_amd import hip, q4  # noqa: E402
 from tools.wino_chain_bench import timed  # noqa: E402
 
-PREP = {2: q4.prepare_q4_weights, 5: q4.prepare_w1d_q4_weights, 8: q4.prepare_w1d4_q4_weights, 4: q4.prepare_winograd_q4_weights,
+PREP = {2: q4.prepare_q4_weights, 8: q4.prepare_w1d4_q4_weights, 4: q4.prepare_winograd_q4_weights,
         7: q4.prepare_winograd4_q4_weights, 9: q4.prepare_wf4_q4_weights}
 
 
