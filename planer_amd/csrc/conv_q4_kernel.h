@@ -47,57 +47,6 @@ struct QuadCfg {
     static constexpr int MIN_WAVES = 512 / ((REGS_EST + 7) / 8 * 8) > 5 ? 5 : 512 / ((REGS_EST + 7) / 8 * 8);
 };
 
-// Fused tail on 4 consecutive output channels (layer.py:125-127, 93-95, 44-51 applied in that
-// order, each its own rounding).  `valid` < 4 marks the last quad of a channel count that is not a
-// multiple of 4: its padding lanes are written as zeros.
-__device__ __forceinline__ float4 apply_epilogue4(const Epilogue &e, float4 bias, float4 scale, float4 shift,
-                                                  float4 res, int valid, float4 v) {
-    float r[4] = {v.x, v.y, v.z, v.w};
-    const float bs[4] = {bias.x, bias.y, bias.z, bias.w}, sc[4] = {scale.x, scale.y, scale.z, scale.w};
-    const float sh[4] = {shift.x, shift.y, shift.z, shift.w}, rs[4] = {res.x, res.y, res.z, res.w};
-    if (e.bias) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) r[i] = __fadd_rn(r[i], bs[i]);
-    }
-    if (e.scale) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) r[i] = __fmul_rn(r[i], sc[i]);
-    }
-    if (e.shift) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) r[i] = __fadd_rn(r[i], sh[i]);
-    }
-    if (e.res && !e.res_post) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) r[i] = __fadd_rn(r[i], rs[i]);
-    }
-    if (e.act == 1) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) r[i] = relu_ref(r[i]);
-    } else if (e.act == 2) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) r[i] = leaky_ref(r[i], e.la, e.lb);
-    }
-    if (e.res && e.res_post) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) r[i] = __fadd_rn(r[i], rs[i]);
-    }
-    if (valid < 4) {
-#pragma unroll
-        for (int i = 1; i < 4; ++i)
-            if (i >= valid) r[i] = 0.f;
-    }
-    return make_float4(r[0], r[1], r[2], r[3]);
-}
-
-// The per-channel parameters of one output channel (clamped to the group's last channel so that
-// rows past Cout read something harmless).
-__device__ __forceinline__ void load_chan_params(const Epilogue &e, int c, float &bias, float &scale, float &shift) {
-    bias = e.bias ? e.bias[c] : 0.f;
-    scale = e.scale ? e.scale[c] : 1.f;
-    shift = e.shift ? e.shift[c] : 0.f;
-}
-
 // One wave's accumulators -> Q4 output (fused pass) or this (split, tile)'s slab, laid out
 // [row/4][BN][4] so both sides move float4s.  Fused pass: `prm` points at the tile's per-row
 // parameters in LDS ([3][BM]: bias, scale, shift -- fetched from HBM when the kernel started, so

@@ -103,7 +103,13 @@ def test_random_conv_every_eligible_kernel_family(pa, seed):
             fams += [(4, lambda: q4.prepare_winograd_q4_weights(dK), xq), (7, lambda: q4.prepare_winograd4_q4_weights(dK), xq),
                      (9, lambda: q4.prepare_wf4_q4_weights(dK), xq)]
         for lay, prep, xin in fams:
-            yq = q4.ConvQ4(xin, prep(), dB, dsc, dsh, rq, act=act, alpha=alpha, w_layout=lay, **para)
+            try:
+                yq = q4.ConvQ4(xin, prep(), dB, dsc, dsh, rq, act=act, alpha=alpha, w_layout=lay, **para)
+            except NotImplementedError:
+                # the fully fused F(4x4,3x3) kernel declines geometries whose 32-tile patch does not fit its LDS (the
+                # picker then takes another family, Net._pick_conv_algo); every other family must take what it is eligible for
+                assert lay == 9
+                continue
             plan = pa.hip.context().last_conv_plan()
             assert_close(q4.from_q4(yq).get(), want, RTOL, "ConvQ4 w_layout %d [%s] %s" % (lay, plan, what))
             ran.append(lay)

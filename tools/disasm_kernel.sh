@@ -1,9 +1,9 @@
 #!/bin/bash
 # Disassembly of one kernel out of a built object (no GPU needed):
-#   tools/disasm_kernel.sh <mangled-name regex> [object = planer_amd/build/conv_igemm.o]  > kernel.s
+#   tools/disasm_kernel.sh <mangled-name regex> [object = planer_amd/build/conv_winograd.o; conv_direct.o holds the implicit-GEMM kernels]  > kernel.s
 R=$(cd "$(dirname "$0")/.." && pwd)
 pat=$1
-obj=${2:-$R/planer_amd/build/conv_igemm.o}
+obj=${2:-$R/planer_amd/build/conv_winograd.o}
 tmp=$(mktemp -d)
 cp "$obj" $tmp/o.o
 (cd $tmp && /opt/rocm/lib/llvm/bin/llvm-objdump --offloading o.o > /dev/null 2>&1)

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Register / LDS / spill figures of the kernels in a built object (no GPU needed):
-#   tools/kernel_resources.sh [pattern] [object = planer_amd/build/conv_igemm.o]
+#   tools/kernel_resources.sh [pattern] [object = planer_amd/build/conv_winograd.o; conv_direct.o holds the implicit-GEMM kernels]
 # Extracts the gfx950 code object from the offload bundle and reads the kernel metadata notes.
 R=$(cd "$(dirname "$0")/.." && pwd)
 pat=${1:-.}
-obj=${2:-$R/planer_amd/build/conv_igemm.o}
+obj=${2:-$R/planer_amd/build/conv_winograd.o}
 tmp=$(mktemp -d)
 cp "$obj" $tmp/o.o
 (cd $tmp && /opt/rocm/lib/llvm/bin/llvm-objdump --offloading o.o > /dev/null 2>&1)
