@@ -42,7 +42,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0
 PER_GPU_BATCH = 32                 # BASELINE.json configs[2] / configs[3]: 32 images per GPU
 PROF_REPEAT = 10                   # launches of a step between its two stream markers in the per-layer passes
-PROFILE_TAG = "r03"                # profiles/<tag>_* files this build's numbers are cross-checked against
+PROFILE_TAG = "r04"                # profiles/<tag>_* files this build's numbers are cross-checked against
 
 
 def cdiv(a, b):
@@ -424,6 +424,24 @@ def main():
         for i in range(10):
             net(xs_host[i & 1])
         e2e = n * 10 / (time.perf_counter() - t0)
+    # the reference-shaped calls (net.py:94-101) on device-resident batches: net(x) one call at a time (latency plan: every
+    # call joins before it returns its outputs) and the asynchronous form net.submit(x) (replicas of the throughput plan in
+    # rotation -- the same graphs as the timed loop above, plus a private copy of the outputs per call)
+    call_rates = {}
+    if rank == 0 and not args.no_e2e:
+        net.streams = "auto"
+        for label, fn in (("net_call", lambda a: net(a)), ("net_submit", lambda a: net.submit(a))):
+            for i in range(20):
+                last = fn(xs[i & 1])
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            for i in range(100):
+                last = fn(xs[i & 1])
+            if label == "net_submit":
+                last.done()
+            sync()
+            call_rates[label] = round(n * 100 / (time.perf_counter() - t0), 1)
+            del last
     algo_list = [{"layer": a["layer"], "algo": a["algo"], "plan": a["plan"]} for a in plan.algos]
 
     if args.workload != "resnet18":
@@ -453,16 +471,29 @@ def main():
     # kernel to the plan's steps) -- it cannot be counted from inside the process, so it describes the profiled
     # run of this build with the shipped tuning database, i.e. the same kernels as this run when tune_source is "shipped"
     traffic, traffic_src = None, None
+    # ... and the same table gives the family's utilisation from the rocprofv3 kernel trace: executed FLOPs of its convs / the
+    # summed average durations of ALL its kernels (roofline.frac_rocprof; the HIP-event figure above is the in-process estimate
+    # of the same quantity and must agree with it)
+    frac_rocprof, rocprof_us = None, None
     tpath = os.path.join(ROOT, "profiles", PROFILE_TAG + "_per_layer.csv")
     if os.path.exists(tpath):
         try:
             import csv
             fam_of = {split_step(r["layer"])[0]: r["kernel"] for r in rows if r["class"].startswith("conv")}
-            tot, nk = 0.0, 0
+            tot, nk, us_sum, exe_by_layer = 0.0, 0, 0.0, {}
             for r in csv.DictReader(open(tpath)):
-                if fam_of.get(split_step(r["layer"])[0]) == dom_name and r.get("hbm_read_bytes") not in (None, ""):
+                base = split_step(r["layer"])[0]
+                if fam_of.get(base) != dom_name:
+                    continue
+                us_sum += float(r["us_rocprof_avg"])
+                if r.get("layer_executed_flops") not in (None, "", "None"):
+                    exe_by_layer[base] = float(r["layer_executed_flops"])
+                if r.get("hbm_read_bytes") not in (None, ""):
                     tot += float(r["hbm_read_bytes"]) + float(r["hbm_write_bytes"])
                     nk += 1
+            if us_sum > 0 and exe_by_layer:
+                rocprof_us = us_sum
+                frac_rocprof = round(sum(exe_by_layer.values()) / (us_sum * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
             if nk and dom["launches"]:
                 traffic = round(tot / dom["launches"])
                 traffic_src = ("profiles/%s_per_layer.csv: HBM bytes (FETCH_SIZE x 2 + WRITE_SIZE) of ALL %d kernels of the family "
@@ -482,6 +513,10 @@ def main():
         "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
         "achieved": round(tf(dom["executed"], dom["ms"]), 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
         "frac": round(tf(dom["executed"], dom["ms"]) / PEAK_FP32_MFMA_TFLOPS, 4),
+        "frac_rocprof": frac_rocprof,
+        "frac_rocprof_source": None if frac_rocprof is None else
+        "profiles/%s_per_layer.csv: executed FLOPs of the family's convs / %.1f us = the summed average durations of all its "
+        "kernels in the one-stream rocprofv3 kernel trace of this build (shipped tuning database)" % (PROFILE_TAG, rocprof_us),
         "effective_achieved": round(tf(dom["flops"], dom["ms"]), 2),
         "effective_frac": round(tf(dom["flops"], dom["ms"]) / PEAK_FP32_MFMA_TFLOPS, 4),
         "traffic": traffic, "traffic_source": traffic_src,
@@ -534,6 +569,8 @@ def main():
                       "fused_steps": plan.fused_steps,
                       "streams": plan.streams,
                       "pcie_inclusive_images_per_sec": None if e2e is None else round(e2e, 1),
+                      "net_call_images_per_sec": call_rates.get("net_call"),
+                      "net_submit_images_per_sec": call_rates.get("net_submit"),
                       "device": ctx.arch, "cu_count": ctx.cu_count,
                       "tune_cache": os.environ.get("PLANER_HIP_TUNE_CACHE"), "settle_ms": args.settle_ms,
                       "sclk_mhz_under_load": sclk_mhz,
