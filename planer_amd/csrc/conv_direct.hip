@@ -1455,10 +1455,10 @@ static int rowpack_pack(pl_ctx *ctx, const float *x, float *xp, int N, int Cin, 
     int Hp, Wp;
     size_t pelems;
     rowpack_geometry(N, Cin, H, W, kw, sw, pt, pl, Hp, Wp, pelems);
-    PL_REQUIRE(pelems < (1ull << 29), PL_EUNSUPPORTED, "row-packed input above 2 GiB");
+    PL_REQUIRE(pelems < (1ull << 29) && (size_t)N * Cin * H * W < (1ull << 29), PL_EUNSUPPORTED, "row-packed input above 2 GiB");
     const unsigned total = (unsigned)((size_t)N * Hp * Wp * Cin), total4 = (unsigned)((pelems + 3) / 4);   // incl. the slack
     nchw_to_rowpack_kernel<<<std::min<unsigned>((total4 + 255) / 256, 256 * 16), 256, 0, ctx->stream>>>(
-        x, xp, total4, total, Cin, H, W, Hp, Wp, pt, pl, FastDiv(Cin), FastDiv(Wp), FastDiv(Hp));
+        x, xp, total4, total, Cin, H, W, Hp, Wp, pt, pl, (unsigned)((size_t)N * Cin * H * W * 4), FastDiv(Cin), FastDiv(Wp), FastDiv(Hp));
     PL_LAUNCH_CHECK();
     return PL_OK;
 }
