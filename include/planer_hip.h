@@ -188,6 +188,18 @@ int pl_conv2d_rowpacked_q4_f32(pl_ctx *ctx, const float *xp, int N, int Cin, int
                                const float *wq, int Cout, int kh, int kw, const float *bias,
                                float *yq, int sh, int sw, int pt, int pl, const float *scale,
                                const float *shift, const float *resq, int act, double alpha);
+/* The row-packed stem conv FOLLOWED BY layer.Maxpool(w = 3x3, strides 2, pads 1) (layer.py:71-72 -> util.pool util.py:79-95:
+ * zero padding, running maximum from -1e4) in one kernel that writes only the pooled Q4 tensor [N][Cout/4][Hq][Wq][4]
+ * (conv_stem_pool_kernel.h: a persistent workgroup marches down an image strip, conv rows live in LDS only).  Built for the
+ * stem of an ImageNet-style net -- 3 channels, 7x7 / stride 2 / pad 3, input width 224; _supported says whether a shape
+ * qualifies, anything else is PL_EUNSUPPORTED (the plan compiler then keeps the two kernels).  bias / scale / shift are
+ * read as 16-byte channel quads; no residual. */
+int pl_conv2d_rowpacked_pool_supported(int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw, int pt,
+                                       int pl, int *ok);
+int pl_conv2d_rowpacked_pool_q4_f32(pl_ctx *ctx, const float *xp, int N, int Cin, int H, int W,
+                                    const float *wq, int Cout, int kh, int kw, const float *bias,
+                                    float *yq, int sh, int sw, int pt, int pl, const float *scale,
+                                    const float *shift, int act, double alpha);
 /* Winograd F(4x4,3x3) on Q4 tensors (same constraints as the F(2x2,3x3) entry points): 6x6 input
  * tiles, 36 grouped GEMMs, 4x fewer multiplies than the direct conv and less transform traffic
  * than F(2x2,3x3); larger transform constants, error a few 1e-6 of max|y| in fp32.

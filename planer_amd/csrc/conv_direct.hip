@@ -580,6 +580,7 @@ __global__ void __launch_bounds__(256) permute_weights_kernel(const float *w, fl
 #include "conv_ks_kernel.h"
 #include "conv_smallcin_kernel.h"
 #include "conv_smallcin_valu_kernel.h"
+#include "conv_stem_pool_kernel.h"
 
 // ---- configurations ---------------------------------------------------------
 typedef Cfg<128, 128, 16, 2, 2> C128x128;
@@ -1523,6 +1524,63 @@ int pl_conv2d_rowpacked_q4_f32(pl_ctx *ctx, const float *xp, int N, int Cin, int
     CtxGuard guard(ctx);
     return conv_launch(ctx, xp, N, Cin, H, W, wq, Cout, kh, kw, bias, yq, sh, sw, 1, 1, pt, pl, pt, pl, 1, scale, shift, resq, act,
                        alpha, 6);
+}
+
+// The row-packed stem conv + maxpool(3x3 / stride 2 / pad 1) in one kernel (conv_stem_pool_kernel.h).  The kernel is built for
+// the stem of an ImageNet-style net: 3 input channels, 7x7 / stride 2 / pad 3, a 112-pixel-wide conv map (W = 224).
+static bool stem_pool_shape_ok(int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw, int pt, int pl) {
+    const int Wo = (W + 2 * pl - kw + sw) / sw, Ho = (H + 2 * pt - kh + sh) / sh;
+    return Cin == 3 && kh == SP_KH && kw == 7 && sh == 2 && sw == 2 && pt == 3 && pl == 3 && Wo == 16 * SP_NB && Ho >= 2 && Cout > 0 &&
+           Cout % 4 == 0;
+}
+
+int pl_conv2d_rowpacked_pool_supported(int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw, int pt, int pl, int *ok) {
+    PL_REQUIRE(ok, PL_EINVAL, "pl_conv2d_rowpacked_pool_supported: null argument");
+    *ok = stem_pool_shape_ok(Cin, H, W, Cout, kh, kw, sh, sw, pt, pl) ? 1 : 0;
+    return PL_OK;
+}
+
+int pl_conv2d_rowpacked_pool_q4_f32(pl_ctx *ctx, const float *xp, int N, int Cin, int H, int W, const float *wq, int Cout, int kh,
+                                    int kw, const float *bias, float *yq, int sh, int sw, int pt, int pl, const float *scale,
+                                    const float *shift, int act, double alpha) {
+    int rc = rowpack_check(ctx, xp, N, Cin, H, W, wq, Cout, kh, kw, yq, sh, sw, pt, pl, nullptr);
+    if (rc != PL_OK) return rc;
+    PL_REQUIRE(stem_pool_shape_ok(Cin, H, W, Cout, kh, kw, sh, sw, pt, pl), PL_EUNSUPPORTED,
+               "conv + maxpool (row-packed stem): 3 channels, 7x7 / stride 2 / pad 3 on a 224-pixel-wide input, Cout %% 4 == 0");
+    PL_REQUIRE(act >= 0 && act <= 2, PL_EINVAL, "pl_conv2d_rowpacked_pool_q4_f32: bad activation code");
+    PL_REQUIRE(((reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift)) & 15u) == 0,
+               PL_EINVAL, "pl_conv2d_rowpacked_pool_q4_f32: bias / scale / shift are read as 16-byte quads");
+    if (N == 0) return PL_OK;
+    CtxGuard guard(ctx);
+    int Hp, Wp;
+    size_t pelems;
+    rowpack_geometry(N, Cin, H, W, kw, sw, pt, pl, Hp, Wp, pelems);
+    StemPoolArgs a;
+    memset(&a, 0, sizeof a);
+    a.xp = xp; a.wq = wq; a.y = yq;
+    a.N = N; a.Hp = Hp; a.rowf = Wp * Cin;
+    a.Ho = (H + 2 * pt - kh + sh) / sh; a.Wo = (W + 2 * pl - kw + sw) / sw;
+    a.Hq = (a.Ho + 1) / 2; a.Wq = (a.Wo + 1) / 2;            // (Ho + 2 - 3 + 2) // 2, util.py:84-85
+    a.Cout = Cout; a.Coq = Cout / 4;
+    a.strips = (a.Hq + SP_PROWS - 1) / SP_PROWS;
+    a.cout_blocks = (Cout + 63) / 64;
+    const int q_pad = (kh * ((kw * Cin + 3) / 4) + 7) / 8 * 8;
+    const size_t yb = (size_t)N * a.Coq * a.Hq * a.Wq * 16;
+    PL_REQUIRE(a.rowf + 3 <= SP_XROW && pelems < (1ull << 29) && yb < (1ull << 31) && 4 * SP_GROUPS <= q_pad, PL_EUNSUPPORTED,
+               "conv + maxpool (row-packed stem): tensor too large");
+    a.x_bytes = (unsigned)(pelems * 4); a.w_bytes = (unsigned)((size_t)q_pad * Cout * 16); a.y_bytes = (unsigned)yb;
+    a.ep = make_epilogue(bias, scale, shift, nullptr, act, alpha);
+    const long long blocks = (long long)N * a.strips * a.cout_blocks;
+    PL_REQUIRE(blocks < (1ll << 31), PL_EUNSUPPORTED, "conv + maxpool (row-packed stem): grid too large");
+    hipLaunchKernelGGL(conv_stem_pool_kernel, dim3((unsigned)blocks), dim3(512), 0, ctx->stream, a);
+    PL_LAUNCH_CHECK();
+    char buf[96];
+    snprintf(buf, sizeof buf, "stem+maxpool 64co x 2 rows x 112px, strips=%d blocks=%lld", a.strips, blocks);
+    ctx->last_plan = buf;
+    // executed MFMA work: 16 conv rows per strip, 112 columns, K = 176
+    ctx->last_gemm[0] = 1; ctx->last_gemm[1] = (long long)a.cout_blocks * 64;
+    ctx->last_gemm[2] = (long long)N * a.strips * 16 * 16 * SP_NB; ctx->last_gemm[3] = 16 * SP_GROUPS;
+    return PL_OK;
 }
 
 int pl_conv2d_rowpack_q4_f32(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W, const float *wq, int Cout, int kh,

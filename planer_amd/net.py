@@ -39,7 +39,7 @@ W_LAYOUT_NAMES = {0: "igemm-nchw", 1: "tap-nchw", 2: "direct-q4 (conv_q4_kernel)
                   4: "wino2x2-q4 (transforms + grouped conv_q4_kernel)",
                   6: "rowpack-q4 (nchw_to_rowpack + conv_q4_kernel)",
                   7: "wino4x4-q4 (transforms + grouped conv_q4_kernel)", 8: "w1d4 F(4,3) (conv_w1d4_kernel)",
-                  9: "wf4 fused F(4x4,3x3) (conv_wf4_kernel)"}
+                  9: "wf4 fused F(4x4,3x3) (conv_wf4_kernel)", 10: "stem + maxpool (conv_stem_pool_kernel)"}
 
 
 def _as_list(v):
@@ -373,7 +373,8 @@ class Net:
                     val = obj(*args)
                 if profile:                                  # ONE marker per step boundary: step time = marker to marker
                     events.append((name, obj.name, hip.Event(self.ctx).record()))
-                if record is not None and obj.name in ("conv", "conv_fused", "conv_q4", "dense", "matmul", "wino4_gemm", "conv_q4_pair"):
+                if record is not None and obj.name in ("conv", "conv_fused", "conv_q4", "dense", "matmul", "wino4_gemm", "conv_q4_pair",
+                                                       "conv_pool_q4"):
                     lay = obj.para().get("w_layout", 2 if obj.name == "conv_q4_pair" else 0) if obj.name != "conv" else 0
                     lname = name
                     if obj.name == "wino4_gemm":               # the GEMM stage of a staged F(4x4,3x3) conv
@@ -483,6 +484,10 @@ class Net:
                     srcs[1] = key
                     out_body[name] = [name, "conv_fused", dict(entry[2], w_layout=lay)]
             out_flow.append([srcs, [name], dst])
+        # the row-packed stem conv whose only reader is maxpool(3x3 / s2 / p1): one kernel that writes the pooled tensor only
+        # (csrc/conv_stem_pool_kernel.h); PLANER_HIP_STEM_POOL=0 keeps the two kernels
+        if os.environ.get("PLANER_HIP_STEM_POOL", "1") != "0":
+            out_flow = self._fuse_stem_pool(out_body, out_flow, shapes)
         out_flow = self._fuse_upsample_concat(out_body, out_flow)
         used = {n for _, names, _ in out_flow for n in names}
         out_list = [out_body[b[0]] for b in body if b[0] in used]
@@ -527,6 +532,36 @@ class Net:
                     out[j] = [[src[0], src[1], csrc[1]], cnames, cdst]
                     drop.add(i)
         return [out.get(i, f) for i, f in enumerate(flow) if i not in drop]
+
+    def _fuse_stem_pool(self, body, flow, shapes):
+        """conv_q4 (row-packed stem, w_layout 6, no residual) whose only reader is maxpool_q4(w=3x3, strides 2, pads 1) -> one
+        conv_pool_q4 step: the full-resolution tensor is never written."""
+        readers = {}
+        for i, (src, names, dst) in enumerate(flow):
+            for k in (src if isinstance(src, list) else [src]):
+                readers.setdefault(k, []).append(i)
+        drop, out = set(), []
+        for i, (src, names, dst) in enumerate(flow):
+            entry = body[names[0]]
+            if (entry[1] == "conv_q4" and entry[2].get("w_layout") == 6 and isinstance(dst, str)
+                    and (len(src) < 6 or src[5] == "None") and len(readers.get(dst, [])) == 1 and i != len(flow) - 1):
+                j = readers[dst][0]
+                psrc, pnames, pdst = flow[j]
+                pe = body[pnames[0]]
+                xs, ks = shapes.get(src[0].split("@")[0]), self._shape_of_init(src[1])
+                para = {k: v for k, v in entry[2].items() if k in ("group", "strides", "dilations", "pads")}
+                if (pe[1] == "maxpool_q4" and len(pnames) == 1 and (psrc == dst or psrc == [dst]) and xs is not None
+                        and [int(v) for v in pe[2].get("w", (2, 2))] == [3, 3]
+                        and [int(v) for v in pe[2].get("strides", (2, 2))] == [2, 2]
+                        and [int(v) for v in pe[2].get("pads", (0, 0, 0, 0))] == [1, 1, 1, 1]
+                        and int(entry[2].get("act", 0)) in (0, 1, 2) and _q4.stem_pool_eligible(tuple(xs), tuple(ks), **para)):
+                    body[names[0]] = [entry[0], "conv_pool_q4", dict(entry[2], w_layout=10)]
+                    out.append([src[:5], names, pdst])
+                    drop.add(j)
+                    continue
+            if i not in drop:
+                out.append([src, names, dst])
+        return out
 
     def _pick_conv_algo(self, ConvFused, K, srcs, para, shapes, wmap, q4=False):
         """Time the direct implicit GEMM and the Winograd variants for this conv's real shape and
@@ -893,7 +928,7 @@ class Net:
             src, names = readers[0]
             obj = prog.objs[_as_list(names)[0]]
             para = obj.para()
-            if (obj.name != "conv_q4" or para.get("w_layout") != 6 or _as_list(src)[0] != k
+            if (obj.name not in ("conv_q4", "conv_pool_q4") or para.get("w_layout") not in (6, 10) or _as_list(src)[0] != k
                     or _as_list(src).count(k) != 1):
                 continue
             kw = self._shape_of_init(_as_list(src)[1])[3]

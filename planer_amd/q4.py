@@ -244,6 +244,45 @@ def ConvQ4(xq, Kq, B=None, scale=None, shift=None, resq=None, group=1, strides=(
     return y
 
 
+def stem_pool_eligible(x_shape, k_shape, group=1, strides=(1, 1), dilations=(1, 1), pads=(0, 0, 0, 0), **_):
+    """Whether the row-packed conv + maxpool(3x3 / s2 / p1) kernel (csrc/conv_stem_pool_kernel.h) takes this conv."""
+    if len(x_shape) != 4 or int(group) != 1 or list(dilations) != [1, 1] or len(pads) != 4 or pads[0] != pads[2] or pads[1] != pads[3]:
+        return False
+    cout, cin, kh, kw = k_shape
+    ok = ctypes.c_int()
+    _lib.call("pl_conv2d_rowpacked_pool_supported", int(cin), int(x_shape[2]), int(x_shape[3]), int(cout), int(kh), int(kw),
+              int(strides[0]), int(strides[1]), int(pads[0]), int(pads[1]), ctypes.byref(ok))
+    return bool(ok.value) and x_shape[1] == cin
+
+
+def ConvPoolQ4(x, Kq, B=None, scale=None, shift=None, group=1, strides=(1, 1), dilations=(1, 1), pads=(0, 0, 0, 0),
+               act=ACT_NONE, alpha=0.0, **_):
+    """Row-packed stem conv (ConvQ4 w_layout 6: NCHW input, filter from prepare_rowpack_weights) with its fused tail, followed
+    by layer.Maxpool(w=(3, 3), strides=(2, 2), pads=(1, 1, 1, 1)) (layer.py:71-72), in ONE kernel: only the pooled Q4 tensor is
+    written.  Emitted by the plan compiler (Net._fuse_stem_pool) where the max-pool is the conv's only reader."""
+    _f32(x, Kq, B, scale, shift)
+    if is_q4(x) or not stem_pool_eligible(x.shape, Kq.shape, group, strides, dilations, pads):
+        raise NotImplementedError("conv + maxpool in one kernel: NCHW 3-channel input, 7x7 / stride 2 / pad 3, width 224")
+    if any(a is not None and a.ptr % 16 for a in (B, scale, shift)):
+        raise ValueError("the stem + max-pool kernel reads bias / scale / shift as 16-byte quads: misaligned parameter")
+    n, cin, h, w = x.shape
+    cout, _, kh, kw = Kq.shape
+    pads, strides = [int(p) for p in pads], [int(s) for s in strides]
+    ho, wo = conv_out_hw(h, w, kh, kw, strides, [1, 1], pads)
+    geom = (kw, strides[1], pads[0], pads[1])
+    if x.packed is not None and x.packed[0] == geom:
+        img = x.packed[1]                          # a plan's static input: whoever feeds the plan keeps the image current
+    else:
+        elems = ctypes.c_size_t()
+        _lib.call("pl_rowpack_input_elems", n, cin, h, w, geom[0], geom[1], geom[2], geom[3], ctypes.byref(elems))
+        img = empty((int(elems.value),), ctx=x.ctx)
+        _lib.call("pl_rowpack_input_f32", x.ctx.handle, x.ptr, img.ptr, n, cin, h, w, geom[0], geom[1], geom[2], geom[3])
+    y = _new_q4(n, cout, (ho + 1) // 2, (wo + 1) // 2, x.ctx)
+    _lib.call("pl_conv2d_rowpacked_pool_q4_f32", x.ctx.handle, img.ptr, n, cin, h, w, Kq.ptr, cout, kh, kw, _ptr(B), y.ptr,
+              strides[0], strides[1], pads[0], pads[1], _ptr(scale), _ptr(shift), int(act), float(alpha))
+    return y
+
+
 def ConvQ4Pair(xq, K1, B1, scale1, shift1, K2, B2, scale2, shift2, para1=None, para2=None, **_):
     """Two fused convs (ConvQ4, w_layout 2, group 1, no dilation, no residual) that read the SAME Q4 input, in one
     launch -> (y1, y2).  Emitted by plan.pair_sibling_convs where a graph forks into two convs (ResNet's stride-2
@@ -487,5 +526,5 @@ def register(layer_map):
     """Plan-internal kinds (never present in a user's IR)."""
     layer_map.update({"to_q4": to_q4, "from_q4": from_q4, "conv_q4": ConvQ4, "upconcat_q4": UpConcatQ4,
                       "wino4_in": Wino4In, "wino4_gemm": Wino4Gemm, "wino4_out": Wino4Out, "wino4_chain": Wino4Chain,
-                      "conv_q4_pair": ConvQ4Pair})
+                      "conv_q4_pair": ConvQ4Pair, "conv_pool_q4": ConvPoolQ4})
     layer_map.update({k + "_q4": f for k, f in Q4_LAYERS.items()})

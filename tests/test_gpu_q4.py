@@ -192,6 +192,44 @@ def test_pointwise_q4_layers_match_nchw_kernels(pa):
     np.testing.assert_array_equal(q4.from_q4(q4.SigmoidQ4(q4.to_q4(pa.asarray(a)))).get(), pa.Sigmoid(pa.asarray(a)).get())
 
 
+def test_stem_conv_maxpool_marching_kernel_matches_oracle(pa):
+    """conv_stem_pool_kernel (ConvPoolQ4): the row-packed 7x7 / stride 2 stem + its tail + maxpool(3x3, s2, p1) in one
+    persistent kernel.  Heights that give partial strips and odd conv maps, channel counts that are not multiples of 64,
+    relu / no activation (negative maxima then meet the zero padding and the -1e4 start, util.py:82-95), bias / bn tails;
+    against the oracle, and against the conv kernel followed by the pool kernel (same values up to the K summation order)."""
+    from planer_amd import q4
+    rng = np.random.default_rng(123)
+    para = dict(strides=[2, 2], pads=[3, 3, 3, 3], dilations=[1, 1], group=1)
+    pool = dict(w=[3, 3], pads=[1, 1, 1, 1], strides=[2, 2])
+    for n, h, cout, act, tail in [(2, 224, 64, 1, "bn"), (1, 64, 64, 0, "bias"), (3, 100, 72, 1, "bn"), (2, 30, 8, 0, "none"),
+                                  (1, 226, 132, 2, "bn"), (32, 224, 64, 1, "bn")]:
+        x = rng.standard_normal((n, 3, h, 224)).astype(np.float32)
+        K = (rng.standard_normal((cout, 3, 7, 7)) * 0.1).astype(np.float32)
+        B = rng.standard_normal(cout).astype(np.float32) if tail == "bias" else None
+        sc = rng.uniform(0.5, 1.5, (1, cout, 1, 1)).astype(np.float32) if tail == "bn" else None
+        sh = (rng.standard_normal((1, cout, 1, 1)) * 0.3).astype(np.float32) if tail == "bn" else None
+        dx, Kq = pa.asarray(x), q4.prepare_rowpack_weights(pa.asarray(K))
+        dB, dsc, dsh = (pa.asarray(a) if a is not None else None for a in (B, sc, sh))
+        assert q4.stem_pool_eligible(x.shape, K.shape, **para)
+        one = q4.ConvPoolQ4(dx, Kq, dB, dsc, dsh, act=act, alpha=0.1, **para)
+        assert "maxpool" in pa.hip.context().last_conv_plan(), pa.hip.context().last_conv_plan()
+        two = q4.MaxpoolQ4(q4.ConvQ4(dx, Kq, dB, dsc, dsh, None, act=act, alpha=0.1, w_layout=6, **para), **pool)
+        assert one.shape == two.shape and one.chan == two.chan
+        conv = np.ascontiguousarray(onp.conv2d(x, K, B, **para))
+        if tail == "bn":
+            conv = onp.batchnorm(conv, sc, sh)
+        conv = onp.relu(conv) if act == 1 else onp.leakyrelu(conv, 0.1) if act == 2 else conv
+        want = onp.maxpool(conv, **pool)
+        got = q4.from_q4(one).get()
+        assert_close(got, want, RTOL, "stem + maxpool %s" % ((n, h, cout, act, tail),))
+        assert_close(one.get(), two.get(), 1e-5, "one kernel vs conv kernel + pool kernel")
+        np.testing.assert_array_equal(one.get(), q4_host(got))                 # padding lanes of the last quad stay zero
+    assert not q4.stem_pool_eligible((1, 3, 224, 200), (64, 3, 7, 7), **para)
+    assert not q4.stem_pool_eligible((1, 3, 224, 224), (64, 3, 3, 3), **dict(para, pads=[1, 1, 1, 1]))
+    with pytest.raises(NotImplementedError):
+        q4.ConvPoolQ4(pa.asarray(np.zeros((1, 3, 64, 64), np.float32)), Kq, **para)
+
+
 def test_rowpack_stem_conv_matches_oracle(pa):
     """Row-packed convolution for 1..3 input channels (pl_conv2d_rowpack_q4_f32): NCHW in, Q4 out;
     K runs (filter row, quads of the kw*Cin row segment) over a zero-padded NHWC copy of the input."""
