@@ -29,7 +29,7 @@ def short(k):
         k = k.replace(t, "")
     k = k.replace("HIP_vector_type<float, 4u>", "f4")
     m = re.match(r"([\w:]+(?:<.*?>)?)\(", k)
-    return (m.group(1) if m else k.split("(")[0]).replace("QuadCfg", "Q").replace("PcCfg", "P")
+    return (m.group(1) if m else k.split("(")[0]).replace("QuadCfg", "Q")
 
 
 def counters(out, tag, idx):
@@ -105,7 +105,11 @@ def expected_kernels(a):
     plan = re.sub(r"^wino\d\[(.*)\]$", r"\1", plan) if algo == "direct" else plan
     if plan.startswith("as128"):
         return ["wino4_gemm_as_kernel"]      # filter-stationary GEMM stage of a 128-channel F(4x4,3x3) conv
-    gemm = ["conv_ks_kernel" if "[k" in plan or plan.startswith("k") else "conv_q4_kernel" if "[q" in plan or plan.startswith("q") else "conv_pc_kernel" if "p" in plan.split()[0] else "conv_igemm_kernel"]
+    if plan.startswith("stem+maxpool"):
+        return ["nchw_to_rowpack_kernel", "conv_stem_pool_kernel"]      # the re-layout runs when the plan is fed
+    if plan.startswith("smallcin3x3valu"):
+        return ["conv_smallcin_valu_kernel"]
+    gemm = ["conv_ks_kernel" if "[k" in plan or plan.startswith("k") else "conv_q4_kernel" if "[q" in plan or plan.startswith("q") else "conv_igemm_kernel"]
     if re.search(r"split=([2-9]|\d\d)", plan):
         gemm.append("reduce_tiles")
     if algo.startswith("wf4"):
@@ -113,9 +117,7 @@ def expected_kernels(a):
     if algo.startswith("rowpack"):
         return ["nchw_to_rowpack_kernel"] + gemm
     if algo.startswith("w1d4"):
-        return ["conv_w1d4_pc_kernel" if "w1d4pc" in plan else "conv_w1d4_kernel"]
-    if algo.startswith("w1d"):
-        return ["conv_w1d_kernel"]
+        return ["conv_w1d4_kernel"]
     if algo.startswith("wino4x4"):
         return ["wino4_input_"] + gemm + ["wino4_output_"]          # ..._q4_kernel or the row-split ..._rows_q4_kernel
     if algo.startswith("wino2x2"):
@@ -126,7 +128,7 @@ def expected_kernels(a):
 def step_kernels(step, kind, algos):
     """Kernel-name fragments a plan step launches, in order (config.plan_steps of the bench line); None = unknown kind."""
     a = algos.get(step.split("@")[0])
-    if kind in ("conv_q4", "conv_fused", "conv", "dense", "matmul", "conv_q4_pair"):
+    if kind in ("conv_q4", "conv_fused", "conv", "dense", "matmul", "conv_q4_pair", "conv_pool_q4"):
         return expected_kernels(a) if a else None
     if kind in ("wino4_in", "wino4_out", "wino4_chain"):
         return ["wino4_"]                    # wino4_chain_kernel<..> (LDS) or wino4_input_ / wino4_output_ (register kernels)
