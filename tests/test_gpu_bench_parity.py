@@ -57,8 +57,8 @@ def test_throughput_plan_batch32_full_size(pa, r18, streams):
     plan = net.compile(dev[0], mode="throughput")
     assert plan.streams == streams and len(plan.replicas) == R
     # what ran is on record: one entry per conv / dense step with its kernel family and tile plan
-    # (wino4_gemm: a staged F(4x4,3x3) conv; conv_q4_pair: two sibling convs in one launch)
-    convs = [a for a in plan.algos if a["kind"] in ("conv_q4", "wino4_gemm", "conv_q4_pair")]
+    # (wino4_gemm: a staged F(4x4,3x3) conv; conv_q4_pair: two sibling convs in one launch; conv_pool_q4: stem conv + max-pool)
+    convs = [a for a in plan.algos if a["kind"] in ("conv_q4", "wino4_gemm", "conv_q4_pair", "conv_pool_q4")]
     assert sum(2 if a["kind"] == "conv_q4_pair" else 1 for a in convs) == 20 and all(a["plan"] for a in convs), plan.algos
     for rnd in range(2):
         held = []
