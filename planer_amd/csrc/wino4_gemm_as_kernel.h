@@ -1,5 +1,5 @@
 // The 36 grouped GEMMs of a staged F(4x4,3x3) convolution with 128 input channels, filter-stationary -- included by
-// conv_igemm.hip inside its anonymous namespace.
+// conv_winograd.hip inside its anonymous namespace.
 //
 // ResNet-18's layer2 (128 -> 128 channels on 28x28) is M = 128, K = 128, N = 1568 per frequency: the tiled kernel's best
 // plan there is 128 x 32 tiles, which stage (128 + 32) x 32 x 4 bytes per 128 x 32 x 32 x 2 FLOP = 12.8 FLOP per byte --
