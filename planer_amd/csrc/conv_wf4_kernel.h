@@ -42,6 +42,11 @@ struct Wf4Args {
     Epilogue ep;
 };
 
+// probe builds only (tools/wf4_knock.sh): bit 0 no filter LDS-DMA, 1 no patch LDS-DMA, 2 no patch transform, 3 no MFMAs,
+// 4 no fragment reads, 5 no output rows -- results are garbage, the time tells what a K step's parts cost
+#ifndef WF4_KNOCK
+#define WF4_KNOCK 0
+#endif
 constexpr int WF4_A_FLOATS = 36 * 256, WF4_V_FLOATS = 2 * 36 * 64, WF4_P_PASSES = 2;      // patch passes of 512 cells
 constexpr int WF4_P_CELLS = 1024, WF4_P_FLOATS = WF4_P_CELLS * 4;
 constexpr int WF4_LDS_BYTES = (2 * WF4_A_FLOATS + 2 * WF4_V_FLOATS + 2 * WF4_P_FLOATS) * 4;
@@ -177,50 +182,31 @@ __device__ __forceinline__ void wf4_at2(const wf4_v2 (&m)[6], wf4_v2 (&o)[4]) {
 // order on every value.
 // PLAIN: that tail written straight (packed operations, no per-element option selects); otherwise the general fused tail in
 // the same two halves -- bias / scale / shift before the exchange, residual / activation / late residual after it.
-template <int A, bool RES, bool PLAIN>
-__device__ __forceinline__ void wf4_output_row_coalesced(const Wf4Args &p, const f32x4 (&acc)[36], int cqc, float4 scale,
-                                                         float4 shift, float4 *xb, int wr_cell, int rd_cell,
-                                                         const __amdgpu_buffer_rsrc_t yrsrc, const __amdgpu_buffer_rsrc_t rrsrc,
-                                                         const int (&off)[4]) {
+// second half of an output row: the six column sums s[b] (pairs lo / hi of the lane's channel quad) -> the row's four pixels,
+// tail, exchange, stores
+template <bool RES, bool PLAIN>
+__device__ __forceinline__ void wf4_row_finish(const Wf4Args &p, const wf4_v2 (&slo)[6], const wf4_v2 (&shi)[6], int cqc, float4 scale,
+                                               float4 shift, float4 *xb, int wr_cell, int rd_cell,
+                                               const __amdgpu_buffer_rsrc_t yrsrc, const __amdgpu_buffer_rsrc_t rrsrc,
+                                               const int (&off)[4]) {
     float4 rs[4];
     if constexpr (RES) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) rs[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off[q], 0, 0));
     }
     wf4_v2 olo[4], ohi[4];
-    {
-        wf4_v2 s[6];
+    wf4_at2(slo, olo);
+    wf4_at2(shi, ohi);
+    if constexpr (PLAIN) {
 #pragma unroll
-        for (int b = 0; b < 6; ++b) {
-            wf4_v2 m[6];
-#pragma unroll
-            for (int a = 0; a < 6; ++a) m[a] = __builtin_shufflevector(acc[a * 6 + b], acc[a * 6 + b], 0, 1);
-            s[b] = wf4_at_row2<A>(m);
-        }
-        wf4_at2(s, olo);
-        if constexpr (PLAIN) {
-#pragma unroll
-            for (int b = 0; b < 4; ++b) olo[b] = olo[b] * (wf4_v2){scale.x, scale.y} + (wf4_v2){shift.x, shift.y};
-        }
-    }
-    {
-        wf4_v2 s[6];
-#pragma unroll
-        for (int b = 0; b < 6; ++b) {
-            wf4_v2 m[6];
-#pragma unroll
-            for (int a = 0; a < 6; ++a) m[a] = __builtin_shufflevector(acc[a * 6 + b], acc[a * 6 + b], 2, 3);
-            s[b] = wf4_at_row2<A>(m);
-        }
-        wf4_at2(s, ohi);
-        if constexpr (PLAIN) {
-#pragma unroll
-            for (int b = 0; b < 4; ++b) ohi[b] = ohi[b] * (wf4_v2){scale.z, scale.w} + (wf4_v2){shift.z, shift.w};
+        for (int b = 0; b < 4; ++b) {
+            olo[b] = olo[b] * (wf4_v2){scale.x, scale.y} + (wf4_v2){shift.x, shift.y};
+            ohi[b] = ohi[b] * (wf4_v2){scale.z, scale.w} + (wf4_v2){shift.z, shift.w};
         }
     }
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     // (the general form fetches its quad's parameters here, row by row: twelve more registers held across the whole epilogue
-    //  would spill beside the 144 accumulators)
+    //  would spill beside the accumulators)
     float4 gbias = z4, gscale = z4, gshift = z4;
     if constexpr (!PLAIN) {
         if (p.ep.bias) gbias = reinterpret_cast<const float4 *>(p.ep.bias)[cqc];
@@ -261,6 +247,25 @@ __device__ __forceinline__ void wf4_output_row_coalesced(const Wf4Args &p, const
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o),
                                                yrsrc, off[q], 0, 0);
     }
+}
+
+template <int A, bool RES, bool PLAIN>
+__device__ __forceinline__ void wf4_output_row_coalesced(const Wf4Args &p, const f32x4 (&acc)[36], int cqc, float4 scale,
+                                                         float4 shift, float4 *xb, int wr_cell, int rd_cell,
+                                                         const __amdgpu_buffer_rsrc_t yrsrc, const __amdgpu_buffer_rsrc_t rrsrc,
+                                                         const int (&off)[4]) {
+    wf4_v2 slo[6], shi[6];
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+        wf4_v2 m[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) m[a] = __builtin_shufflevector(acc[a * 6 + b], acc[a * 6 + b], 0, 1);
+        slo[b] = wf4_at_row2<A>(m);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) m[a] = __builtin_shufflevector(acc[a * 6 + b], acc[a * 6 + b], 2, 3);
+        shi[b] = wf4_at_row2<A>(m);
+    }
+    wf4_row_finish<RES, PLAIN>(p, slo, shi, cqc, scale, shift, xb, wr_cell, rd_cell, yrsrc, rrsrc, off);
 }
 
 // Variants (compile-time; the launcher picks one): DMA_A -- the filter slice goes global -> LDS by LDS-DMA instead of through
@@ -367,12 +372,14 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
     auto load_a_piece = [&](int c, int buf, int it) {
         const int soff = (int)(((unsigned)coutblk * (unsigned)p.nchunks + (unsigned)c) * (unsigned)(WF4_A_FLOATS * 4));
         float *Ab = buf ? As1 : As0;
+        if constexpr (WF4_KNOCK & 1) return;
         if (it < 4 || wave < 4)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ursrc, (lds_float *)(Ab + (it * 512 + tid - lane) * 4), 16, (it * 512 + tid) << 4, soff, 0, 0);
     };
     auto load_p_piece = [&](int c, int buf, int ps) {
         const int soff = (c * HW) << 4;
         float *Pb = buf ? Ps1 : Ps0;
+        if constexpr (WF4_KNOCK & 2) return;
         if (ps * 512 < p.cells && ps * 512 + tid < p.cells)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_float *)(Pb + (ps * 512 + tid - lane) * 4), 16, pvoff[ps], soff, 0, 0);
     };
@@ -408,6 +415,7 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
         vb2 = ((((tj >> 4) * 4 + 2 * cp) * 16) + (tj & 15)) * 36;
     }
     auto transform_first = [&](int pbuf, int vbuf) {           // waves 4-7: a whole row (both halves)
+        if constexpr (WF4_KNOCK & 4) return;
         const float *Pb = pbuf ? Ps1 : Ps0;
         float *Vb = vbuf ? Vs1 : Vs0;
         if constexpr (!PLANAR) {
@@ -431,6 +439,7 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
     };
     const int pbw = (wave & 1) ? pb1 : pb0, vbw = (wave & 1) ? vb1 : vb0;
     auto transform_last = [&](int pbuf, int vbuf) {            // waves 0-3: row 4 or 5 of one half
+        if constexpr (WF4_KNOCK & 4) return;
         const float *Pb = pbuf ? Ps1 : Ps0;
         float *Vb = vbuf ? Vs1 : Vs0;
         if constexpr (!PLANAR) {
@@ -454,19 +463,29 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
         const float4 *Vp = reinterpret_cast<const float4 *>((buf ? Vs1 : Vs0) + b_off);
         // three rotating fragment slots, requested two groups (8 MFMAs) ahead; the scheduling barriers keep that distance
         float4 fa[3], fb[3];
-        fa[0] = Ap[0]; fb[0] = Vp[0];
-        fa[1] = Ap[1]; fb[1] = Vp[1];
+        constexpr bool NOFRAG = (WF4_KNOCK & 16) != 0, NOMMA = (WF4_KNOCK & 8) != 0;
+        if constexpr (NOFRAG) {
+            fa[0] = fa[1] = fa[2] = make_float4(1.f, 2.f, 3.f, (float)c);
+            fb[0] = fb[1] = fb[2] = make_float4(1.f, 2.f, 3.f, (float)lane);
+        } else {
+            fa[0] = Ap[0]; fb[0] = Vp[0];
+            fa[1] = Ap[1]; fb[1] = Vp[1];
+        }
 #pragma unroll
         for (int g = 0; g < 9; ++g) {
-            if (g + 2 < 9) {
+            if (!NOFRAG && g + 2 < 9) {
                 fa[(g + 2) % 3] = Ap[g + 2];
                 fb[(g + 2) % 3] = Vp[g + 2];
             }
             const float4 a = fa[g % 3], b = fb[g % 3];
+            if constexpr (NOMMA) {
+                acc[4 * g + 0].x += a.x * b.x; acc[4 * g + 1].x += a.y * b.y; acc[4 * g + 2].x += a.z * b.z; acc[4 * g + 3].x += a.w * b.w;
+            } else {
             acc[4 * g + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[4 * g + 0], 0, 0, 0);
             acc[4 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[4 * g + 1], 0, 0, 0);
             acc[4 * g + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[4 * g + 2], 0, 0, 0);
             acc[4 * g + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[4 * g + 3], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (decltype(spread)::value && DMA_P) {
                 if (g < 5) {
