@@ -870,10 +870,6 @@ int w1d_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const
 }
 
 #include "conv_wf4_kernel.h"
-#ifndef WF4X
-#define WF4X 0
-#endif
-#include "conv_wf4x_kernel.h"
 
 int wf4_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const float *u, int Cout, const float *bias,
                float *yq, const float *scale, const float *shift, const float *resq, int act, double alpha) {
@@ -905,16 +901,6 @@ int wf4_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const
     // against 51.4 us for register-staged operands with the waves in step, layer1 of ResNet-18 at batch 32); one instantiation
     // per block width, so that every patch read is base + immediate
     void (*kern)(const Wf4Args) = nullptr;
-#if WF4X
-    switch (lBC) {
-    case 4: kern = conv_wf4x_kernel<4>; break;
-    case 3: kern = conv_wf4x_kernel<3>; break;
-    case 2: kern = conv_wf4x_kernel<2>; break;
-    case 1: kern = conv_wf4x_kernel<1>; break;
-    default: kern = conv_wf4x_kernel<0>; break;
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WF4X_THREADS), 0, ctx->stream, a);
-#else
     switch (lBC) {
     case 4: kern = conv_wf4_kernel<true, false, true, 4>; break;
     case 3: kern = conv_wf4_kernel<true, false, true, 3>; break;
@@ -923,7 +909,6 @@ int wf4_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const
     default: kern = conv_wf4_kernel<true, false, true, 0>; break;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), 0, ctx->stream, a);      // LDS: static (WF4_LDS_BYTES)
-#endif
     PL_LAUNCH_CHECK();
     char buf[96];
     snprintf(buf, sizeof buf, "wf4 64co x 32tiles (%dx%dx%d) blocks=%lld", NB, BR, BC, blocks);
@@ -1029,11 +1014,7 @@ int pl_conv2d_prepare_wf4_f32(pl_ctx *ctx, const float *w, int Cout, int Cin, fl
     CtxGuard g(ctx);
     PL_HIP(hipMemsetAsync(out, 0, elems * sizeof(float), ctx->stream));       // channel padding of the last 64-block
     const size_t pairs = (size_t)Cout * Cin;
-#if WF4X
-    wf4x_filter_kernel<<<(unsigned)((pairs + 255) / 256), 256, 0, ctx->stream>>>(w, out, (unsigned)pairs, Cin, Cout);
-#else
     wf4_filter_kernel<<<(unsigned)((pairs + 255) / 256), 256, 0, ctx->stream>>>(w, out, (unsigned)pairs, Cin, Cout);
-#endif
     PL_LAUNCH_CHECK();
     return PL_OK;
 }

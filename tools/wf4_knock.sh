@@ -1,7 +1,7 @@
 #!/bin/bash
 # Probe builds of the fused F(4x4,3x3) kernel: one library per (tag, compiler flags) pair under planer_amd/build/knock/, e.g.
 # knock-out masks (-DWF4_KNOCK=<mask>: bit 0 no filter loads, 1 no patch LDS-DMA, 2 no patch transform, 3 no MFMAs, 4 no V
-# fragment reads) or variant switches (-DWF4X_TFIRST=1 ...); "run" times each with the K sweep (tools/wf4_ksweep.py --tail).
+# fragment reads, 5 no output rows); "run" times each with the K sweep (tools/wf4_ksweep.py --tail).
 #   tools/wf4_knock.sh build base "" k4 "-DWF4_KNOCK=4" ...     (here)
 #   tools/wf4_knock.sh run                                       (on the GPU box; writes gpurun_out/wf4_knock.txt)
 set -e
@@ -16,7 +16,7 @@ if [ "$1" = build ]; then
         $flags -c planer_amd/csrc/conv_winograd.hip -o $D/cw_$tag.o &&
       /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/libk_$tag.so planer_amd/build/runtime.o planer_amd/build/pointwise.o \
         planer_amd/build/head_ops.o planer_amd/build/conv_direct.o $D/cw_$tag.o -ldl && echo built $tag &&
-      tools/kernel_resources.sh "wf4x?_kernelI.*4E" $D/cw_$tag.o | sed 's/^_ZN12_GLOBAL__N_1//' ) &
+      tools/kernel_resources.sh "wf4_kernelI.*4E" $D/cw_$tag.o | sed 's/^_ZN12_GLOBAL__N_1//' ) &
     while [ $(jobs -r | wc -l) -ge 4 ]; do sleep 1; done
   done
   wait
