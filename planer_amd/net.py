@@ -175,6 +175,8 @@ class _PipelinePlan:
     def __init__(self, replicas, ctx, fused_steps):
         self.replicas, self.ctx, self.fused_steps, self.ms = replicas, ctx, fused_steps, None
         self.streams = "pipe%d" % len(replicas)
+        for rp in replicas:                  # the host's run-ahead is bounded over the whole pipeline, not per replica
+            rp.max_in_flight = max(2, 24 // len(replicas))
         self.algos = replicas[0].algos
         self.turn, self.last = 0, replicas[0]
 
@@ -736,7 +738,10 @@ class Net:
             cands = [(q, p_) if splittable and p_ >= q >= 1 and batch % p_ == 0 else (1, 1)]
         # throughput mode pipelines whole batches over R streams (R full-batch graphs); sub-batch plans
         # are dominated there (28.4 k vs 34.8 k img/s on ResNet-18), so they are not even tried
-        pipes = [2, 3] if (mode == "throughput" and want == "auto") else []
+        # (depths: 3, 7 and 15 replicas interleave best -- depths that are multiples of the four hardware queues the runtime
+        #  maps streams onto lose 3-8 %: ResNet-18 at batch 32 in steady state 52.3 / 53.1 / 53.6 k img/s at 3 / 7 / 15 against
+        #  48.4 / 50.8 k at 4 / 8; YOLO-v3 at batch 1 1.54 / 1.60 / 1.64 k; a lone write-bound conv is best at 3)
+        pipes = [2, 3, 7, 15] if (mode == "throughput" and want == "auto") else []
         if pipes:
             cands = [(1, 1)]
         if want.startswith("pipe"):
