@@ -787,11 +787,19 @@ class Net:
             else:
                 prog, nfused = program_for(1)
                 reps = []
-                for r in range(c):
-                    cx = self._side_context(r)
-                    reps.append(self._capture(prog, [DeviceArray(a.shape, a.dtype, cx).copy_from(a) for a in xs],
-                                              cx, nfused))
-                    ctx.synchronize()
+                try:
+                    for r in range(c):
+                        cx = self._side_context(r)
+                        reps.append(self._capture(prog, [DeviceArray(a.shape, a.dtype, cx).copy_from(a) for a in xs],
+                                                  cx, nfused))
+                        ctx.synchronize()
+                except MemoryError:
+                    # a deep pipeline is R full copies of the activations: a candidate the device has no room for is
+                    # skipped (a depth that was asked for by name is not)
+                    if len(todo) == 1 or best is None:
+                        raise
+                    del reps
+                    continue
                 cand = _PipelinePlan(reps, ctx, nfused)
             if len(todo) == 1:
                 best = cand
