@@ -1,6 +1,6 @@
 """Parity of exactly what bench.py times, at BASELINE's full sizes, on a real MI355X.
 
-* the throughput plan (pipe2 / pipe3, batch 32, 224x224, algorithms picked by timing): every
+* the throughput plan (pipe2 / pipe3 / pipe7, batch 32, 224x224, algorithms picked by timing): every
   replica's logits vs the oracle (BASELINE configs[2]);
 * every 3x3 algorithm (direct, fused 1-D F(2,3) / F(4,3), F(2x2,3x3), F(4x4,3x3)) forced at every
   real ResNet-18 stride-1 layer shape at batch 32, with the real fused tail (bn + residual + relu),
@@ -45,7 +45,7 @@ def elementwise_ratio(y, ref):
     return float((np.abs(y - ref) / (RTOL * np.abs(ref) + RTOL * np.abs(ref).max())).max())
 
 
-@pytest.mark.parametrize("streams", ["pipe2", "pipe3"])
+@pytest.mark.parametrize("streams", ["pipe2", "pipe3", "pipe7"])      # pipe7: what the shipped database picks for this workload
 def test_throughput_plan_batch32_full_size(pa, r18, streams):
     g, b, ref = r18
     net = pa.from_graph(g, b)

@@ -110,7 +110,7 @@ def test_sub_batch_streams_give_identical_results(pa, streams):
             assert_close(a, c, RTOL)
 
 
-@pytest.mark.parametrize("streams", ["pipe2", "pipe3"])
+@pytest.mark.parametrize("streams", ["pipe2", "pipe3", "pipe7"])
 def test_call_on_a_pipelined_plan_sees_each_new_input(pa, streams, monkeypatch):
     """`net(x)` with PLANER_HIP_STREAMS=pipeR: consecutive calls run on different replicas, and every call must run on
     the input it was given (not on what an older call left in that replica's static buffers)."""
@@ -120,7 +120,7 @@ def test_call_on_a_pipelined_plan_sees_each_new_input(pa, streams, monkeypatch):
     ref.load_weights(b)
     net = pa.from_graph(g, b)
     net.streams = streams
-    for seed in range(5):
+    for seed in range(5 if streams != "pipe7" else 9):        # more calls than replicas: every replica is reused
         x = resnet18.make_input(2, seed=40 + seed, size=64)
         got = net(pa.asarray(x))
         assert_close(got.get(), ref(x.copy()), RTOL, "device call %d" % seed)
