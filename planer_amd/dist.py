@@ -300,6 +300,8 @@ def init(ctx=None, fallback=False):
         comm = FileCommunicator(rank, world)
         comm.why = "PLANER_DIST_TRANSPORT=file"
         return comm
+    # the pipeline's side streams take their hardware-queue slots before RCCL creates streams of its own (hip.side_context)
+    hip.reserve_side_contexts(ctx.device, int(os.environ.get("PLANER_HIP_RESERVE_STREAMS", "14")))
     try:
         return RcclCommunicator(ctx, rank, world)
     except Exception as e:                    # noqa: BLE001 -- any RCCL / rendezvous failure

@@ -840,8 +840,8 @@ class Net:
 
     def _side_context(self, i):
         """Extra stream (context) number i of this net's device; 0 is the net's own."""
-        while len(self._side) < i:
-            self._side.append(hip.Context(self.ctx.device))
+        while len(self._side) < i:              # the device's shared pool, in index order (hip.side_context)
+            self._side.append(hip.side_context(self.ctx.device, len(self._side) + 1))
         return self.ctx if i == 0 else self._side[i - 1]
 
     def _build_plan(self, prog, xs, Q, S, nfused):
