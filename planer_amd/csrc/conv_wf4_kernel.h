@@ -1,27 +1,30 @@
-// Fully fused Winograd F(4x4,3x3) convolution on channel-quad tensors -- included by conv_igemm.hip inside its
-// anonymous namespace (uses Epilogue, FastDiv, apply_epilogue4, w4_at4).
+// Fully fused Winograd F(4x4,3x3) convolution on channel-quad tensors -- included by conv_winograd.hip inside its
+// anonymous namespace (uses Epilogue, FastDiv, apply_epilogue4).
 //
 // For 3x3 / stride 1 / pad 1 / group 1 convs (util.conv_for, util.py:17-44, with the fused tail of layer.py:125-127,
 // 93-95, 44-51).  The staged pipeline (input transform -> 36 grouped GEMMs -> output transform) needs 4x fewer
 // multiplies than the direct conv but moves V and M -- 2.25x the activation each, written and read -- through
 // memory; the fused 1-D kernel (conv_w1d4_kernel) moves nothing extra but only halves the multiplies.  Here ONE
 // workgroup carries a block of 32 tiles x 64 output channels through all 36 frequencies:
-//   * 4 waves, one per SIMD, 512 registers each (amdgpu_waves_per_eu(1,1)).  Wave (wm, wn) owns output channels
-//     [32 wm, 32 wm + 32) x tiles [16 wn, 16 wn + 16) as 2 x 36 accumulator blocks of v_mfma_f32_16x16x4_f32
-//     (288 registers): lane (i = lane % 16, rg = lane / 16) ends up holding, for ITS tile i and ITS channel quad
-//     4 rg .. 4 rg + 3, all 36 frequencies -- so the output transform A^T m A, the fused tail and the sixteen
-//     16-byte stores of the 4x4 output pixels are lane-local.  M never exists.
+//   * 8 waves, two per SIMD, 256 registers each (amdgpu_waves_per_eu(2,2)).  Wave (wm, wn) owns output channels
+//     [16 wm, 16 wm + 16) x tiles [16 wn, 16 wn + 16) as 36 accumulator blocks of v_mfma_f32_16x16x4_f32 (144 registers):
+//     lane (i = lane % 16, rg = lane / 16) ends up holding, for ITS tile i and ITS channel quad 4 rg .. 4 rg + 3, all 36
+//     frequencies -- so the output transform A^T m A is lane-local; the fused tail and the stores go through a wave-private
+//     LDS exchange that turns (tile, quad) lanes into (tile, pixel) lanes: one store covers a contiguous 1 KB run.  M never
+//     exists.  (The first version had 4 waves x 288 accumulators: 67 us against 48 us -- the compiler shuffled through AGPRs.)
 //   * K runs over input channel quads (one quad = one chunk = one MFMA K step of 4).  Per chunk the workgroup
-//     holds in LDS: the filter slice A[36][4 cout blocks][4 k][16] (36.9 KB, straight from a filter laid out in
+//     holds in LDS: the filter slice A[4 cout blocks][4 k][16][36] (36.9 KB, by LDS-DMA straight from a filter laid out in
 //     exactly that order), the input patch P of the block's tiles -- (4 BR + 2) x (4 BC + 2) pixels per image,
-//     halo shared between neighbouring tiles, stored [row][x mod 4][x div 4] so that consecutive tiles are
-//     consecutive 16-byte cells -- and the transformed patch V[2 wn][36][4 k][16 tiles] (18.4 KB) that the same
-//     four waves compute from P (thread = (row a of B^T d B, tile, channel), 3 items each): V never leaves the CU.
-//   * One barrier per chunk.  In iteration c a wave requests chunk c+1's filter slice and chunk c+2's patch from
-//     L2 into registers, runs the 72 MFMAs of chunk c out of A[c&1] / V[c&1], transforms P[(c+1)&1] into
-//     V[(c+1)&1], then parks the requested registers in A[(c+1)&1] / P[c&1]: every buffer written in an interval
-//     was last read in the previous one.
-//   * Fragment reads are conflict free by layout: lane (i, kk) reads dword (kk*16 + i) of a [k][16] panel.
+//     halo shared between neighbouring tiles, stored [row][x mod 4][x div 4] as 16-byte cells (by LDS-DMA, zero fill by the
+//     range check) -- and the transformed patch V[2 wn][4 k][16 tiles][36] (18.4 KB) that six wave-items compute from P
+//     (one row of B^T d B for all 32 tiles x a channel pair per lane, packed arithmetic): V never leaves the CU.
+//   * One barrier per chunk.  In iteration c the waves request chunk c+1's filter slice and chunk c+2's patch (LDS-DMA,
+//     one request per MFMA group), waves 4-7 transform P[(c+1)&1] into V[(c+1)&1] BEFORE their 36 MFMAs of chunk c and waves
+//     0-1 after theirs (rows 4-5), so that the two waves of a SIMD alternate on its matrix pipe; every buffer written in an
+//     interval was last read in the previous one.
+//   * Fragment reads are conflict free by layout: a lane's 36 frequencies of one (k, row) are 144 consecutive bytes.
+//   * What a K step costs (profiles/r04_wf4_knockout.md): 1.00 us of MFMAs + 0.36 fragment reads + 0.38 transform + 0.13 both
+//     LDS-DMA streams = 1.61 us; fp32 MFMAs do not overlap with the other vector instructions of their SIMD.
 // Executed MFMA work = 36/16 of a GEMM per output pixel = 4x fewer multiplies than the direct conv (tile and
 // channel padding aside); HBM traffic = x + y (+ residual) + the filter.
 

@@ -19,7 +19,7 @@ algo_keep = {}
 
 def measure(steps=120):
     net = planer_amd.from_graph(g, blob)
-    net.streams = "pipe3"
+    net.streams = os.environ.get("STREAMS", "pipe3")
     if algo_keep:
         net._algo_loaded, net._algo = True, dict(algo_keep)
     plan = net.compile(xs[0], mode="throughput")
