@@ -1,4 +1,4 @@
-// Channel-quad convolution for SMALL problems -- included by conv_igemm.hip inside its anonymous namespace.
+// Channel-quad convolution for SMALL problems -- included by conv_direct.hip inside its anonymous namespace.
 //
 // A batch-1 detection net is a chain of convs on 13x13 .. 52x52 maps: 169 .. 2704 output pixels.  With 64x64 tiles
 // that is a handful of workgroups, so the launch plans split K across workgroups and add a reduce kernel (two

@@ -1,4 +1,4 @@
-// Channel-quad ("Q4") implicit-GEMM convolution -- included by conv_igemm.hip
+// Channel-quad ("Q4") implicit-GEMM convolution -- included by conv_direct.hip
 // inside its anonymous namespace (shares ConvArgs, tile_coord, Plan, tuning).
 //
 // Why a second activation layout.  Measured on MI355X (tools/ubench/mfma_mix.hip,

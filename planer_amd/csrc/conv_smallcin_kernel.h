@@ -1,4 +1,4 @@
-// 3x3 / stride 1 convolution on 1..4 input channels, NCHW in and out -- included by conv_igemm.hip inside
+// 3x3 / stride 1 convolution on 1..4 input channels, NCHW in and out -- included by conv_direct.hip inside
 // its anonymous namespace.  BASELINE config 2 (Conv2d 3->64 on (8,3,224,224), reference util.conv_for,
 // util.py:17-44) is this shape: K = 27, 1.39 GFLOP against 107.6 MB of traffic of which 102.8 MB are
 // the output -- HBM-WRITE-bound (floor 13.4 us at 8 TB/s, ~17 us at the achievable 6.3 TB/s), the

@@ -1,4 +1,4 @@
-// 3x3 / stride 1 convolution on 1..4 input channels, NCHW in and out, on the VECTOR ALUs -- included by conv_igemm.hip
+// 3x3 / stride 1 convolution on 1..4 input channels, NCHW in and out, on the VECTOR ALUs -- included by conv_direct.hip
 // inside its anonymous namespace.  BASELINE config 2 (Conv2d 3->64 on (8,3,224,224); reference layer.Conv2d
 // layer.py:22-26 -> util.conv_for util.py:17-44) has K = Cin*kh*kw = 27: 1.39 GFLOP against 102.8 MB of output, i.e.
 // HBM-WRITE-bound (13.4 us at 8 TB/s) with 8.8 us of arithmetic at the fp32 peak -- and the fp32 VALU peak of gfx950 IS

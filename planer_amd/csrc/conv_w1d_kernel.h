@@ -1,4 +1,4 @@
-// Fused 1-D Winograd F(4,3) convolution along W on channel-quad tensors -- included by conv_igemm.hip inside its
+// Fused 1-D Winograd F(4,3) convolution along W on channel-quad tensors -- included by conv_winograd.hip inside its
 // anonymous namespace (shares ConvArgs, tile_coord, the Q4 epilogue helpers).
 //
 // For 3x3 / stride 1 / pad 1 / dilation 1 / group 1 convs (util.conv_for, util.py:17-44).  The transform is applied along W

@@ -1,5 +1,5 @@
 // Winograd F(4x4,3x3) transforms through LDS, chained across convolutions -- included by
-// conv_igemm.hip inside its anonymous namespace (uses w4_at4 / w4_at4_row / w4_bt / w4_bt_row,
+// conv_winograd.hip inside its anonymous namespace (uses w4_at4 / w4_at4_row / w4_bt / w4_bt_row,
 // apply_epilogue4, Epilogue, FastDiv).
 //
 // The unchained pipeline of one conv is  input transform -> 36 grouped GEMMs -> output transform

@@ -162,6 +162,17 @@ def reserve_side_contexts(device, n):
         side_context(device, n)
 
 
+def trim_side_contexts(device=None):
+    """Hand the blocks cached by the shared side contexts back to the driver (`pl_pool_trim` on each; waits for their
+    streams).  The side contexts themselves -- and so the hardware-queue slots of their streams -- stay: every Net of
+    the process shares them, which also means that two Nets pipelining on one device take turns on the same side
+    streams.  Call it after dropping a Net whose throughput plan held R replicas' worth of activations."""
+    for dev, pool in _side_pool.items():
+        if device is None or int(device) == dev:
+            for c in pool:
+                c.trim()
+
+
 def synchronize():
     context().synchronize()
 

@@ -66,7 +66,19 @@ def graph_tag_of(layers, flow, init_shapes):
     """crc32 over layer kinds and parameters, flow wiring and init shapes (Net.graph_tag)."""
     import json
     import zlib
-    text = json.dumps([layers, flow, [list(map(int, s)) for s in init_shapes]], sort_keys=True, default=repr)
+
+    def plain(v):
+        # numpy scalars / arrays print differently across numpy versions (np.float32(0.1) vs 0.1): hash plain Python values
+        if isinstance(v, numpy.ndarray):
+            return v.tolist()
+        if isinstance(v, numpy.generic):
+            return v.item()
+        if isinstance(v, dict):
+            return {str(k): plain(x) for k, x in v.items()}
+        if isinstance(v, (list, tuple)):
+            return [plain(x) for x in v]
+        return v
+    text = json.dumps(plain([layers, flow, [list(map(int, s)) for s in init_shapes]]), sort_keys=True, default=repr)
     return "%08x" % (zlib.crc32(text.encode()) & 0xffffffff)
 
 
@@ -91,21 +103,30 @@ class _Plan:
         # A free-running loop otherwise queues every batch it is asked for at once; eight batches keep the GPU fed
         # for milliseconds, and tools that intercept dispatches (rocprofv3) crash with ~2000 of them outstanding.
         self.max_in_flight, self._ring = 8, []
+        self._held = []              # per ring slot: what that launch's feed read (Net.submit), released with the slot
 
     def feed(self, xs):
         """Copy new inputs into the plan's static input buffers (on the plan's stream)."""
         for s, a in zip(self.inputs, xs):
             _feed_static(self.ctx, s, a)
 
-    def launch(self, join=True):
+    def launch(self, join=True, hold=None):
+        """`hold`: objects the feed of THIS launch read on this plan's stream (the caller's input arrays).  They stay
+        referenced until the host has seen a marker behind this launch complete: a block the caller drops right after
+        submitting must not go back to its pool -- and be overwritten through another stream -- before the asynchronous
+        feed has read it."""
         _lib.call("pl_graph_launch", self.graph)
         if self.max_in_flight:
             if len(self._ring) >= self.max_in_flight:
                 ev = self._ring.pop(0)
                 ev.synchronize()
+                self._held.pop(0)
             else:
                 ev = hip.Event(self.ctx)
             self._ring.append(ev.record())
+            self._held.append(hold)
+        elif hold is not None:       # no ring to tie the references to: wait for the launch instead
+            self.ctx.synchronize()
 
     def join(self):
         pass
@@ -193,13 +214,13 @@ class _PipelinePlan:
         for dst, a in zip(rp.inputs, xs):
             _feed_static(rp.ctx, dst, a, always=True)                           # on the replica's stream
 
-    def launch(self, join=True):
+    def launch(self, join=True, hold=None):
         rp = self.replicas[self.turn]
         self.turn = (self.turn + 1) % len(self.replicas)
         self.last = rp
         if join:
             rp.ctx.wait_for(self.ctx)
-        rp.launch()
+        rp.launch(hold=hold)
         if join:
             self.join()
 
@@ -962,12 +983,7 @@ class Net:
             plan.replicas[plan.turn].ctx.wait_for(self.ctx)
             plan.feed(xs)
         else:
-            for s, a in zip(plan.inputs, xs):      # on the main stream; launch() forks behind it
-                if isinstance(plan, _MultiPlan) or not isinstance(a, DeviceArray):
-                    if a is not s:
-                        s.copy_from(a)
-                else:
-                    _feed_static(self.ctx, s, a)
+            self._feed_on_main(plan, xs)
         plan.launch()
         out = plan.outputs
         if not private:                            # the caller copies to the host right away
@@ -976,6 +992,16 @@ class Net:
         if isinstance(out, tuple):
             return tuple(o.copy() if isinstance(o, DeviceArray) else o for o in out)
         return out.copy() if isinstance(out, DeviceArray) else out
+
+    def _feed_on_main(self, plan, xs):
+        """Inputs of a one-graph or sub-batch plan, copied on the net's OWN stream (where the caller produced them);
+        `launch()` forks the side streams behind that point."""
+        for s, a in zip(plan.inputs, xs):
+            if isinstance(plan, _MultiPlan) or not isinstance(a, DeviceArray):
+                if a is not s:
+                    s.copy_from(a)
+            else:
+                _feed_static(self.ctx, s, a)
 
     def submit(self, *x):
         """Asynchronous form of `net(x)` (net.py:94-101): enqueue one forward pass and return a `Pending` handle at once.
@@ -999,10 +1025,12 @@ class Net:
             rp = plan.replicas[plan.turn]
             rp.ctx.wait_for(self.ctx)                 # the caller produced xs on the net's own stream
             plan.feed(xs)
-            plan.launch(join=False)
+            plan.launch(join=False, hold=xs)          # xs stay referenced until the replica has read them
             cx, out = rp.ctx, rp.outputs
         else:
-            plan.feed(xs)
+            # sub-batch plans ("QxP"): the copy runs on the net's own stream, the sub-streams fork behind it and join
+            # back into it (the feed of _MultiPlan.feed on the side streams could read xs before the main stream wrote them)
+            self._feed_on_main(plan, xs)
             plan.launch()
             cx, out = self.ctx, plan.outputs
         # private copies on the replica's stream, then the marker result() waits for

@@ -363,6 +363,55 @@ def test_submit_keeps_batches_in_flight_and_matches_call(pa):
     assert rates["submit"] >= 0.93 * rates["plan"]
 
 
+def test_submit_with_temporaries_dropped_right_away(pa):
+    """Round-4 advisor finding: the feed of a submitted pass runs asynchronously on the replica's stream, so an input the
+    caller drops right after `submit` (a host array's device temporary, the result of a preprocessing kernel) must stay
+    alive until the replica has read it -- under GPU-bound load the next allocation on the net's context would take
+    its block and overwrite it.  A loop of submits with fresh host arrays and with dropped device temporaries, each
+    followed by an allocation of the same size that is filled with garbage, against net(x) one call at a time."""
+    g, b = resnet18.build()
+    net = pa.from_graph(g, b)
+    n, size, rounds = 16, 96, 24
+    xs = [resnet18.make_input(n, size=size, seed=s) for s in range(4)]
+    want = [net(pa.asarray(x)).get() for x in xs]
+    junk = np.full((n, 3, size, size), 1e6, np.float32)
+    hs = []
+    for i in range(rounds):
+        if i & 1:
+            hs.append(net.submit(xs[i % 4].copy()))                 # host array in: the device temporary is ours to keep alive
+        else:
+            d = pa.asarray(xs[i % 4], ctx=net.ctx)
+            e = d.copy()                                            # stands for a preprocessing kernel's output
+            del d
+            hs.append(net.submit(e))
+            del e                                                   # a dropped device temporary
+        t = pa.asarray(junk, ctx=net.ctx)                           # takes a free block of that size and overwrites it
+        del t
+    for i, h in enumerate(hs):
+        got = h.get()
+        np.testing.assert_array_equal(got, want[i % 4], "submit %d" % i)
+
+
+def test_submit_on_a_sub_batch_plan_copies_on_the_main_stream(pa, monkeypatch):
+    """Round-4 advisor finding: with streams="2x2" a submitted pass used to copy its rows on the side streams BEFORE they
+    forked behind the net's stream; an input still being produced there could be read early.  Inputs produced by a
+    kernel on the main stream right before the submit, many times in a row."""
+    g, b = resnet18.build()
+    net = pa.from_graph(g, b)
+    x = resnet18.make_input(8, size=64, seed=3)
+    want = net(pa.asarray(x)).get()
+    net2 = pa.from_graph(g, b)
+    net2.streams = "2x2"
+    big = pa.asarray(np.zeros((64 << 20,), np.float32), ctx=net2.ctx)
+    for i in range(6):
+        d = pa.hip.empty(x.shape, np.float32, net2.ctx)
+        pa._lib.call("pl_memset", net2.ctx.handle, big.ptr, 0, big.nbytes)      # keeps the main stream busy for a while
+        d.set(x) if i == 0 else d.copy_from(pa.asarray(x, ctx=net2.ctx))
+        h = net2.submit(d)
+        np.testing.assert_array_equal(h.get(), want, "pass %d" % i)
+    assert net2.compile(pa.asarray(x, ctx=net2.ctx), mode="throughput").streams in ("2x2", "1x1")
+
+
 def test_two_host_threads_two_contexts(pa):
     """The library is thread-compatible: one context (stream + pool) per host thread, shared launch-plan cache behind a
     mutex, thread-local error text.  Two threads run different nets on their own contexts at the same time."""
