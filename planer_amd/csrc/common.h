@@ -4,6 +4,8 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <string>
@@ -75,6 +77,7 @@ struct pl_ctx {
     void *sync_event = nullptr;      // hipEvent_t used by pl_stream_wait
     std::string last_plan;           // how the last conv on this context was launched (pl_conv2d_last_plan)
     long long last_gemm[4] = {0, 0, 0, 0};   // executed GEMM extents of that conv: groups, padded rows, cols, K (pl_conv2d_last_extents)
+    int xcd_cols_request = 0;        // columns of the next grouped GEMM that one XCD must own (conv_winograd.hip sets it around conv_launch)
     int tune_misses = 0;             // conv shapes this context had to time because no cached launch plan existed
 
     // RCCL (dlopen'ed on first use)
@@ -97,5 +100,20 @@ struct pl_event {
 struct CtxGuard {  // make the context's device current for this call
     explicit CtxGuard(pl_ctx *c) { (void)hipSetDevice(c->device); }
 };
+
+// Measurement-only switches, all behind ONE environment variable: PLANER_HIP_EXPERIMENT="key=value,key=value".  Read per call
+// (tests and tools flip it at run time); a key that is absent gives `dflt`.  Nothing the shipped plans depend on lives here.
+static inline int pl_experiment(const char *key, int dflt) {
+    const char *e = getenv("PLANER_HIP_EXPERIMENT");
+    if (!e) return dflt;
+    const size_t n = strlen(key);
+    for (const char *p = e; *p;) {
+        if (!strncmp(p, key, n) && p[n] == '=') return atoi(p + n + 1);
+        const char *c = strchr(p, ',');
+        if (!c) break;
+        p = c + 1;
+    }
+    return dflt;
+}
 
 static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }

@@ -801,6 +801,13 @@ int run_plan(pl_ctx *ctx, const ConvArgs &a0, const Plan &pl, bool avec, float *
         ctx->last_gemm[2] = (long long)a.ntiles * ci.bn;
         ctx->last_gemm[3] = (long long)(kq + ci.bk - 1) / ci.bk * ci.bk;
     }
+    // column-block ownership per XCD (set by the caller as a REQUEST = tile columns that must not straddle XCDs): honoured when
+    // the plan is one unsplit pass of a channel-quad tile kernel and the column tiles split evenly over the 8 XCDs
+    if (a.xcd_cols > 0) {
+        const int want_cols = a.xcd_cols;            // columns per XCD
+        a.xcd_cols = (t1 == T && ci.tap == 2 && !ci.ks && a.ntiles % 8 == 0 && (a.ntiles / 8) * ci.bn == want_cols) ? a.ntiles / 8 : 0;
+        if (a.xcd_cols) ctx->last_plan += " xcdcols";
+    }
     int used = 0;
     int rc = launch_pass(ctx, a, ci, avec, 0, t1, 1, pl.occ, y, &used);
     if (rc != PL_OK) return rc;
@@ -1084,6 +1091,19 @@ int plhip::conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W
             case 8: kern = conv_smallcin_valu_kernel<4, 0>; break;
             default: kern = conv_smallcin_valu_kernel<4, 1>; break;
             }
+            // measurement builds of the 3-channel / pad-1 instantiation (BASELINE config 2): PLANER_HIP_EXPERIMENT=scv_knock=<mask>
+            // (1 no input loads, 2 no FMAs, 4 no stores, 8 no per-tap filter reads; tools/scv_probe.py)
+            if (Cin == 3 && pt == 1) {
+                switch (pl_experiment("scv_knock", 0)) {
+                case 1: kern = conv_smallcin_valu_kernel<3, 1, 1>; break;
+                case 2: kern = conv_smallcin_valu_kernel<3, 1, 2>; break;
+                case 3: kern = conv_smallcin_valu_kernel<3, 1, 3>; break;
+                case 4: kern = conv_smallcin_valu_kernel<3, 1, 4>; break;
+                case 5: kern = conv_smallcin_valu_kernel<3, 1, 5>; break;
+                case 13: kern = conv_smallcin_valu_kernel<3, 1, 13>; break;
+                default: break;
+                }
+            }
             hipLaunchKernelGGL(kern, dim3((unsigned)((quads + 255) / 256), (unsigned)((Cout + cpb - 1) / cpb), (unsigned)N), dim3(256), 0,
                                ctx->stream, va);
             PL_LAUNCH_CHECK();
@@ -1154,6 +1174,7 @@ int plhip::conv_launch(pl_ctx *ctx, const float *x, int N, int Cin, int H, int W
     a.divHoWo = FastDiv(a.HoWo); a.divWo = FastDiv(Wo);
     a.divMt = FastDiv(1); a.divCpt = FastDiv(1);
     a.ep = make_epilogue(bias, scale, shift, res, act, alpha);
+    a.xcd_cols = ctx->xcd_cols_request;
     const bool avec = (a.K % 4 == 0) && ((reinterpret_cast<uintptr_t>(w) & 15u) == 0);
 
     // forced configuration (tests / tuning tools): split > 1 means split-K over all tiles

@@ -34,6 +34,8 @@ struct ConvArgs {
     int cqg, Cq, Coq, Qtot, Qpad, uni;
     int y_bytes;      // Q4 output size in bytes when it is under 2 GiB (buffer-addressed tail), else 0
     int rp_rq;        // > 0: row-packed small-Cin input (x = padded NHWC, H/W = padded extents); quads per filter row
+    int xcd_cols;     // > 0: workgroup b (XCD b % 8) takes column tiles [xcd * xcd_cols, +xcd_cols) of EVERY group: the XCD that
+                      // wrote a column block of the grouped GEMM's input also reads it (Winograd hand-offs, wino4_gemm_launch)
     FastDiv divKhw, divKw, divHoWo, divWo, divMt, divCpt;
     Epilogue ep;
 };
@@ -50,8 +52,20 @@ struct TileCoord {
 template <int BM, int BN>
 __device__ __forceinline__ TileCoord tile_coord(const ConvArgs &p, unsigned bid = blockIdx.x, unsigned nblk = gridDim.x) {
     const unsigned q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;   // bijective for any grid
     TileCoord tc;
+    if (p.xcd_cols > 0) {
+        // column-block ownership (one unsplit pass over all groups, ntiles = 8 * xcd_cols): idx -> (m-tile fastest, group,
+        // local column tile); every group's tiles of a column block run on ONE XCD
+        const unsigned mt = idx % (unsigned)p.mtiles, r2 = idx / (unsigned)p.mtiles;
+        const unsigned g = r2 % (unsigned)p.groups, ntl = r2 / (unsigned)p.groups;
+        const unsigned nt = xcd * (unsigned)p.xcd_cols + ntl;
+        tc.g = g;
+        tc.local = (g * (unsigned)p.ntiles + nt) * (unsigned)p.mtiles + mt;
+        tc.m0 = (int)mt * BM;
+        tc.col0 = (int)nt * BN;
+        return tc;
+    }
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;   // bijective for any grid
     tc.local = bid;
     const unsigned gt = bid + (unsigned)p.tile_offset;
     tc.g = gt / (unsigned)p.tiles;

@@ -42,18 +42,30 @@ __device__ __forceinline__ void scv_fma_hi(scv_v2 &acc, scv_v2 x, scv_v2 w) {
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(x), "v"(w));
 }
 
-template <int CIN, int PAD>
+// KNOCK (measurement builds only, PLANER_HIP_EXPERIMENT=scv_knock=<mask>, the 3-channel / pad-1 instantiation): bit 0 no input
+// loads, bit 1 no FMAs, bit 2 no stores, bit 3 no per-tap filter reads.  Config 2 on MI355X (tools/scv_probe.py): everything
+// 27.2 us; stores only 18.5-19.2 us (5.6-5.8 TB/s: the store pattern is not what bounds the kernel); no stores 23.1; FMAs alone
+// (no loads, no stores, no filter reads) 17-19 us where 432 v_pk_fma_f32 x 16 passes on the busiest SIMD need 13 us.
+template <int CIN, int PAD, int KNOCK = 0>
 __global__ void __launch_bounds__(256) conv_smallcin_valu_kernel(const SmallCinValuArgs p) {
     constexpr int K = CIN * 9;
     __shared__ __attribute__((aligned(16))) float Ws[K * SCV_MAXC + SCV_MAXC];        // [k][channel], then the bias
     const int tid = threadIdx.x;
     const int n = blockIdx.z, co0 = blockIdx.y * p.cpb;
-    // ---- filter block -> LDS, transposed to k-major; channels beyond Cout are zero ----
-    for (int i = tid; i < K * SCV_MAXC; i += 256) {
-        const int co = i / K, k = i - co * K;            // flat read of the block's filters (coalesced), scattered LDS write
-        Ws[k * SCV_MAXC + co] = (co < p.cpb && co0 + co < p.Cout) ? p.w[(size_t)(co0 + co) * K + k] : 0.f;
+    // ---- filter block -> LDS, transposed to k-major; channels beyond Cout are zero.  Range-checked buffer loads, all of a
+    //      thread's requests in flight before the first LDS write (a predicated plain load `c ? w[i] : 0` is a branch and a wait per
+    //      element: seven dependent round trips at the head of a 25 us kernel) ----
+    //      (the LDS writes sit behind the requests for the input window below, so both round trips overlap)
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, (unsigned)p.Cout * K * 4u, 0x00020000);
+    constexpr int WPER = (K * SCV_MAXC + 255) / 256;
+    float wreg[WPER];
+#pragma unroll
+    for (int t = 0; t < WPER; ++t) {
+        const int i = tid + t * 256, co = i / K;         // flat read of the block's filters (coalesced), scattered LDS write
+        wreg[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                wrsrc, (i < K * SCV_MAXC && co < p.cpb) ? (co0 * K + i) << 2 : (int)0x80000000, 0, 0));
     }
-    if (tid < SCV_MAXC) Ws[K * SCV_MAXC + tid] = (p.bias && tid < p.cpb && co0 + tid < p.Cout) ? p.bias[co0 + tid] : 0.f;
+    const float bvl = (tid < SCV_MAXC && p.bias && tid < p.cpb && co0 + tid < p.Cout) ? p.bias[co0 + tid] : 0.f;
 
     // ---- this lane's pixel quad and its input window ----
     const unsigned j = blockIdx.x * 256u + tid;
@@ -72,6 +84,10 @@ __global__ void __launch_bounds__(256) conv_smallcin_valu_kernel(const SmallCinV
             const bool rok = live && (unsigned)h < (unsigned)p.H;
             const int base = ((n * CIN + c) * p.H + h) * p.W + 4 * (int)q;          // column 4q of that row
             // columns 4q - PAD .. 4q - PAD + 5: one 16-byte load (always inside the row) and two single values
+            if constexpr (KNOCK & 1) {
+                xv[c][r][0] = (scv_v2){(float)tid, 1.f}; xv[c][r][1] = (scv_v2){2.f, (float)c}; xv[c][r][2] = (scv_v2){(float)r, 3.f};
+                continue;
+            }
             const float4 m = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, rok ? base << 2 : OOB, 0, 0));
             if constexpr (PAD == 1) {
                 const float lo = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, (rok && q > 0) ? (base - 1) << 2 : OOB, 0, 0));
@@ -83,6 +99,12 @@ __global__ void __launch_bounds__(256) conv_smallcin_valu_kernel(const SmallCinV
                 xv[c][r][0] = (scv_v2){m.x, m.y}; xv[c][r][1] = (scv_v2){m.z, m.w}; xv[c][r][2] = (scv_v2){h0, h1};
             }
         }
+#pragma unroll
+    for (int t = 0; t < WPER; ++t) {
+        const int i = tid + t * 256, co = i / K;
+        if (i < K * SCV_MAXC) Ws[(i - co * K) * SCV_MAXC + co] = wreg[t];
+    }
+    if (tid < SCV_MAXC) Ws[K * SCV_MAXC + tid] = bvl;
     __syncthreads();
 
     // ---- passes of eight output channels ----
@@ -99,10 +121,10 @@ __global__ void __launch_bounds__(256) conv_smallcin_valu_kernel(const SmallCinV
         // the filter values of tap k + 1 are requested before the FMAs of tap k (two ds_read_b128 broadcasts per tap)
         float4 w0 = *reinterpret_cast<const float4 *>(Ws + g), w1 = *reinterpret_cast<const float4 *>(Ws + g + 4);
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
+        for (int k = 0; k < ((KNOCK & 2) ? 1 : K); ++k) {
             const int c = k / 9, r = (k % 9) / 3, dx = k % 3;
             const scv_v2 wv[4] = {{w0.x, w0.y}, {w0.z, w0.w}, {w1.x, w1.y}, {w1.z, w1.w}};
-            if (k + 1 < K) {
+            if (k + 1 < K && !(KNOCK & 8)) {
                 w0 = *reinterpret_cast<const float4 *>(Ws + (k + 1) * SCV_MAXC + g);
                 w1 = *reinterpret_cast<const float4 *>(Ws + (k + 1) * SCV_MAXC + g + 4);
             }
@@ -127,9 +149,11 @@ __global__ void __launch_bounds__(256) conv_smallcin_valu_kernel(const SmallCinV
             // state between a buffer_store_dwordx4 and a VALU write of its data registers (its hazard model exempts stores
             // whose soffset is a register) -- measured on gfx950: lanes 12-15 of every 16 then stored the NEXT value of the
             // second data register (Cin = 1 instantiation, where the allocator reused the registers at once)
+            const bool st = (KNOCK & 4) ? (o.x == 12345.678f && live) : (live && co0 + g + cc < p.Cout);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o), yrsrc,
-                                                   (live && co0 + g + cc < p.Cout) ? yoff + cc * plane : OOB, 0, 0);
+                                                   st ? yoff + cc * plane : OOB, 0, 0);
         }
         if (live) yoff += 8 * plane;
     }
 }
+

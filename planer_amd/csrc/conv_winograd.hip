@@ -709,6 +709,7 @@ int wino4_chain_launch(pl_ctx *ctx, const float *M, const float *x, const WinoAr
     a.divPlane = FastDiv(a.plane); a.div4S = FastDiv(4 * a.S); a.divS = FastDiv(a.S);
     a.divHW = FastDiv(p.H * p.W); a.divW = FastDiv(p.W);
     a.ep = p.ep;
+    a.ipx = (pl_experiment("xcd", 0) && p.N % 8 == 0) ? p.N / 8 : 0;      // images per XCD (0: plain (quad group, image) grid)
     static const char *bd_env = getenv("PLANER_HIP_WINO_BD");
     int bd = bd_env ? atoi(bd_env) : 384;
     bd = std::max(64, std::min(512, bd / 64 * 64));
@@ -769,8 +770,13 @@ int wino4_gemm_launch(pl_ctx *ctx, const float *V, const float *Uq, float *M, co
         ctx->last_gemm[0] = 36; ctx->last_gemm[1] = p.Cout; ctx->last_gemm[2] = (long long)nsub * 32; ctx->last_gemm[3] = 128;
         return PL_OK;
     }
+    // experiment xcd=1: the tile columns of N/8 images per XCD, for every frequency (the chain kernel maps its workgroups the same
+    // way, wino4_chain_launch): M and V are handed from kernel to kernel inside one XCD.  Honoured by run_plan when the launch
+    // plan is one unsplit pass whose column tiles split evenly.
+    ctx->xcd_cols_request = (pl_experiment("xcd", 0) && p.N % 8 == 0) ? (p.N / 8) * p.th * p.tw : 0;
     int rc = conv_launch(ctx, V, 1, 36 * p.C, p.N * p.th, p.tw, Uq, 36 * p.Cout, 1, 1, nullptr, M, 1, 1, 1, 1, 0, 0, 0, 0, 36,
                          nullptr, nullptr, nullptr, PL_ACT_NONE, 0.0, 2);
+    ctx->xcd_cols_request = 0;
     ctx->last_plan = "wino4[" + ctx->last_plan + "]";
     return rc;
 }

@@ -137,7 +137,9 @@ int pl_alloc(pl_ctx *ctx, size_t bytes, void **out) {
     std::lock_guard<std::mutex> lk(ctx->mu);
     const size_t sz = round_block(bytes);
     void *p = nullptr;
-    if (ctx->capturing) p = take_fit(ctx->cap_free, sz);
+    // (experiment cap_noreuse=1: a block freed during this capture is not handed out again inside it, so no kernel of
+    //  the graph writes lines that an earlier kernel's readers may still hold in another XCD's L2)
+    if (ctx->capturing && !pl_experiment("cap_noreuse", 0)) p = take_fit(ctx->cap_free, sz);
     if (!p) p = take_fit(ctx->free_blocks, sz);
     if (!p) {
         hipError_t e = hipMalloc(&p, sz);

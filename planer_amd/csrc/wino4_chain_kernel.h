@@ -35,6 +35,8 @@ struct Wino4ChainArgs {
     int per;               // gt rounded up to 64: items of one transformed row (wave-uniform row index)
     int R, XP, S;          // plane rows (4 th + 2), plane columns (4 tw + 2), cells per x-phase (tw + 1)
     int plane;             // R * 4 * S cells of 16 bytes per channel quad
+    int ipx;               // > 0: images per XCD -- workgroup b (XCD b % 8) takes image (b % 8) * ipx + (b / 8) % ipx, so that the
+                           // images whose tile columns one XCD's GEMM workgroups produced are transformed on that XCD
     unsigned src_bytes, res_bytes;     // buffer sizes for the range check (M or x; residual)
     FastDiv divGt, divTiles, divTw, divPer, divPlane, div4S, divS, divHW, divW;
     Epilogue ep;
@@ -163,7 +165,12 @@ template <bool FROM_M>
 __global__ void __launch_bounds__(512) wino4_chain_kernel(const Wino4ChainArgs p) {
     extern __shared__ float4 wc_lds[];
     const unsigned tid = threadIdx.x, bd = blockDim.x, lane = tid & 63u;
-    const unsigned n = blockIdx.y, cq0 = blockIdx.x * (unsigned)p.G;
+    unsigned n = blockIdx.y, cq0 = blockIdx.x * (unsigned)p.G;
+    if (p.ipx > 0) {
+        const unsigned b = blockIdx.y * gridDim.x + blockIdx.x, xcd = b & 7u, idx = b >> 3;
+        n = xcd * (unsigned)p.ipx + idx % (unsigned)p.ipx;
+        cq0 = (idx / (unsigned)p.ipx) * (unsigned)p.G;
+    }
     const unsigned gt = (unsigned)p.gt, HW = (unsigned)(p.H * p.W);
     float4 *plane = wc_lds;                                   // [G][R][4][S]
     float4 *slab = wc_lds + (size_t)p.G * p.plane;            // [36][G * tiles]

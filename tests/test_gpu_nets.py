@@ -408,7 +408,7 @@ def test_submit_on_a_sub_batch_plan_copies_on_the_main_stream(pa, monkeypatch):
         pa._lib.call("pl_memset", net2.ctx.handle, big.ptr, 0, big.nbytes)      # keeps the main stream busy for a while
         d.set(x) if i == 0 else d.copy_from(pa.asarray(x, ctx=net2.ctx))
         h = net2.submit(d)
-        np.testing.assert_array_equal(h.get(), want, "pass %d" % i)
+        assert_close(h.get(), want, 1e-5, "pass %d" % i)      # (batch-4 sub-graphs pick their own kernels: not bit-equal)
     assert net2.compile(pa.asarray(x, ctx=net2.ctx), mode="throughput").streams in ("2x2", "1x1")
 
 
