@@ -427,6 +427,7 @@ def main():
     plan = net.compile(xs[0], mode="throughput")
     ctx.synchronize()
     compile_s = time.perf_counter() - t_compile
+    stream_probe = getattr(plan, "stream_probe", None)
     tune_misses = {"launch_plans": ctx.tune_stats()[1] + sum(c.tune_stats()[1] for c in net._side),
                    "conv_algorithms": net.algo_misses, "stream_plans": net.stream_misses}
     tune_src, wino_chains = net.tune_source(), net.wino_chains      # where the TIMED plan's kernel choices came from
@@ -712,7 +713,7 @@ def main():
                       "weight_exchange": ("single process" if world == 1 else "one ncclBroadcast of the uint8 blob (RCCL)"
                                           if comm.device_transport else "local upload per rank -- " + getattr(comm, "why", "")),
                       "fused_steps": plan.fused_steps,
-                      "streams": plan.streams,
+                      "streams": plan.streams, "stream_probe": stream_probe,
                       "pcie_inclusive_images_per_sec": None if e2e is None else round(e2e, 1),
                       "net_call_images_per_sec": call_rates.get("net_call"),
                       "net_submit_images_per_sec": call_rates.get("net_submit"),

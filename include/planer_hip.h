@@ -85,6 +85,10 @@ int pl_stream_wait(pl_ctx *waiter, pl_ctx *signal);
 /* the waiter's stream waits for one recorded point of another stream (Net.submit: a pending result is handed to the
  * caller's stream without waiting for what was queued behind it) */
 int pl_stream_wait_event(pl_ctx *waiter, pl_event *ev);
+/* Exchange the streams of two idle contexts of one device (each keeps its memory pool, graphs and events).  Which hardware queue
+ * a stream runs on is fixed when the runtime creates it; the plan compiler uses this to try assignments of pipeline replicas
+ * to streams without re-capturing their graphs.  No counterpart in the reference (net.py has no notion of a stream). */
+int pl_ctx_swap_streams(pl_ctx *a, pl_ctx *b);
 
 /* whole-forward capture: the HIP-native replacement for interpreting the flow
  * in Python on every call (net.py:37-72).  Between begin/end every launch and
@@ -234,6 +238,15 @@ int pl_wino4_output_q4_f32(pl_ctx *ctx, const float *M, int N, int C, int H, int
 int pl_wino4_chain_q4_f32(pl_ctx *ctx, const float *M, int N, int C, int H, int W, const float *bias,
                           const float *scale, const float *shift, const float *resq, int act, double alpha,
                           float *yq, float *Vnext);
+
+/* A 1x1 / stride 1 / group 1 channel-quad convolution with its fused tail (bias, scale, shift, ReLU / LeakyReLU; no residual)
+ * whose only reader is a staged Winograd 3x3 convolution: writes that conv's transformed input V straight away --
+ * wino = 4: F(4x4,3x3), V as pl_wino4_input_q4_f32 makes it; wino = 2: F(2x2,3x3), [16][Cout/4][T][4] with 2x2 tiles.
+ * wq from pl_conv2d_prepare_q4_f32 (group 1).  Replaces, for a Darknet block (1x1 then 3x3), layer.Conv2d + BatchNorm +
+ * LeakyReLU (reference layer.py:22-26, 125-127, 48-51) and the first stage of the next conv; plan-internal. */
+int pl_conv1x1_wino_in_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const float *wq, int Cout,
+                              const float *bias, const float *scale, const float *shift, int act, double alpha, int wino,
+                              float *V);
 
 /* Two channel-quad convolutions that read the SAME input, in one launch (both with the fused tail
  * y = act((conv + bias) * scale + shift), no residual; group 1, dilation 1, symmetric pads; filters from

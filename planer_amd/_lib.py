@@ -47,6 +47,7 @@ SIGNATURES = {
     "pl_event_destroy": [_P],
     "pl_stream_wait": [_P, _P],
     "pl_stream_wait_event": [_P, _P],
+    "pl_ctx_swap_streams": [_P, _P],
     "pl_capture_begin": [_P],
     "pl_capture_end": [_P, POINTER(_P)],
     "pl_graph_launch": [_P],
@@ -78,6 +79,7 @@ SIGNATURES = {
     "pl_wino4_gemm_q4_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _P],
     "pl_wino4_output_q4_f32": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, c_double, _P],
     "pl_wino4_chain_q4_f32": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, c_double, _P, _P],
+    "pl_conv1x1_wino_in_q4_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, c_double, _I, _P],
     "pl_conv2d_rowpack_filter_elems": [_I, _I, _I, _I, POINTER(c_size_t)],
     "pl_conv2d_prepare_rowpack_f32": [_P, _P, _I, _I, _I, _I, _P],
     "pl_conv2d_rowpack_q4_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, c_double],

@@ -650,6 +650,7 @@ __global__ void __launch_bounds__(256) wino4_output_rows_q4_kernel(const float4 
 
 #include "wino4_chain_kernel.h"
 #include "wino4_gemm_as_kernel.h"
+#include "conv1x1_wino_in_kernel.h"
 
 // ---- F(4x4,3x3) stage by stage.  winograd4_q4_launch below runs the three stages of ONE conv; the plan
 //      compiler (planer_amd/plan.py chain_winograd) calls the stages itself so that consecutive
@@ -1117,6 +1118,49 @@ int pl_wino4_chain_q4_f32(pl_ctx *ctx, const float *M, int N, int C, int H, int 
     if (rc != PL_OK) return rc;
     p.ep = make_epilogue(bias, scale, shift, resq, act, alpha);
     return wino4_chain_launch(ctx, M, nullptr, p, C, yq, Vnext);
+}
+
+// 1x1 conv + fused tail + the Winograd input transform of the 3x3 conv that follows (conv1x1_wino_in_kernel.h): xq (N, Cin, H, W)
+// -> V of the (N, Cout, H, W) activation, F(4x4,3x3) (wino = 4, [36][Cout/4][T][4]) or F(2x2,3x3) (wino = 2, [16][Cout/4][T][4])
+int pl_conv1x1_wino_in_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const float *wq, int Cout,
+                              const float *bias, const float *scale, const float *shift, int act, double alpha, int wino, float *V) {
+    PL_REQUIRE(ctx && xq && wq && V, PL_EINVAL, "pl_conv1x1_wino_in_q4_f32: null pointer");
+    PL_REQUIRE(N >= 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 4 == 0 && (wino == 4 || wino == 2), PL_EINVAL,
+               "pl_conv1x1_wino_in_q4_f32: bad shape (Cout must be a multiple of 4, wino 2 or 4)");
+    PL_REQUIRE(act >= 0 && act <= 2, PL_EINVAL, "pl_conv1x1_wino_in_q4_f32: bad activation code");
+    PL_REQUIRE(((reinterpret_cast<uintptr_t>(xq) | reinterpret_cast<uintptr_t>(wq) | reinterpret_cast<uintptr_t>(V)) & 15u) == 0, PL_EINVAL,
+               "Q4 tensors must be 16-byte aligned");
+    if (N == 0) return PL_OK;
+    CtxGuard guard(ctx);
+    C1WArgs a;
+    memset(&a, 0, sizeof a);
+    a.x = xq; a.w = wq; a.V = (float4 *)V;
+    a.N = N; a.Cq = (Cin + 3) / 4; a.H = H; a.W = W; a.Cout = Cout;
+    a.Qtot = a.Cq; a.Qpad = (a.Qtot + 7) / 8 * 8;
+    const int ts = wino == 4 ? 4 : 2;
+    a.th = (H + ts - 1) / ts; a.tw = (W + ts - 1) / ts; a.T = N * a.th * a.tw;
+    a.rty = wino == 4 ? 1 : 2; a.rtx = wino == 4 ? 2 : 4;
+    a.rh = (a.th + a.rty - 1) / a.rty; a.rw = (a.tw + a.rtx - 1) / a.rtx;
+    a.mtiles = (Cout + 31) / 32;
+    const size_t xb = (size_t)N * a.Cq * H * W * 16, wb = (size_t)a.Qpad * Cout * 16;
+    const size_t vb = (size_t)(wino == 4 ? 36 : 16) * Cout * a.T * 4;
+    const long long blocks = (long long)N * a.rh * a.rw * a.mtiles;
+    PL_REQUIRE(xb < (1ull << 31) && wb < (1ull << 31) && vb < (1ull << 33) && blocks < (1ll << 31), PL_EUNSUPPORTED,
+               "pl_conv1x1_wino_in_q4_f32: tensor too large");
+    a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
+    a.divMt = FastDiv(a.mtiles); a.divRw = FastDiv(a.rw); a.divRh = FastDiv(a.rh);
+    a.ep = make_epilogue(bias, scale, shift, nullptr, act, alpha);
+    auto kern = wino == 4 ? conv1x1_wino_in_kernel<4> : conv1x1_wino_in_kernel<2>;
+    int rc = ensure_lds_attr((const void *)kern, C1W_LDS_FLOATS * 4);
+    if (rc != PL_OK) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C1W_WAVES * 64), C1W_LDS_FLOATS * 4, ctx->stream, a);
+    PL_LAUNCH_CHECK();
+    char buf[96];
+    snprintf(buf, sizeof buf, "conv1x1+wino%d-in 32co x 6x10px regions=%d blocks=%lld", wino, N * a.rh * a.rw, blocks);
+    ctx->last_plan = buf;
+    ctx->last_gemm[0] = 1; ctx->last_gemm[1] = (long long)a.mtiles * 32;
+    ctx->last_gemm[2] = (long long)N * a.rh * a.rw * 64; ctx->last_gemm[3] = (long long)a.Qpad * 4;
+    return PL_OK;
 }
 
 int pl_conv2d_winograd_q4_filter_elems(int Cout, int Cin, size_t *elems) {

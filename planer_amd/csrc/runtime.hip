@@ -282,6 +282,23 @@ int pl_stream_wait(pl_ctx *waiter, pl_ctx *signal) {
     return PL_OK;
 }
 
+// Exchange the streams of two contexts of one device (both are drained first).  A context is a memory pool plus a stream; which
+// hardware queue a stream sits on is decided by the runtime when the stream is created, and a pipeline's rate depends on it
+// (DESIGN 4.7): the plan compiler tries assignments of its replicas to the process's side streams without re-capturing anything --
+// graphs are launched on their context's CURRENT stream, events and pools are not tied to a stream.
+int pl_ctx_swap_streams(pl_ctx *a, pl_ctx *b) {
+    PL_REQUIRE(a && b, PL_EINVAL, "pl_ctx_swap_streams: null ctx");
+    if (a == b) return PL_OK;
+    PL_REQUIRE(a->device == b->device, PL_EINVAL, "pl_ctx_swap_streams: contexts on different devices");
+    PL_REQUIRE(!a->capturing && !b->capturing, PL_EINVAL, "pl_ctx_swap_streams during capture");
+    PL_REQUIRE(!a->comm && !b->comm, PL_EINVAL, "pl_ctx_swap_streams: a context that carries a communicator keeps its stream");
+    CtxGuard g(a);
+    PL_HIP(hipStreamSynchronize(a->stream));
+    PL_HIP(hipStreamSynchronize(b->stream));
+    std::swap(a->stream, b->stream);
+    return PL_OK;
+}
+
 int pl_stream_wait_event(pl_ctx *waiter, pl_event *ev) {
     PL_REQUIRE(waiter && ev, PL_EINVAL, "pl_stream_wait_event: null argument");
     PL_REQUIRE(waiter->device == ev->ctx->device, PL_EINVAL, "pl_stream_wait_event: event of another device");

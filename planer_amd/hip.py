@@ -157,6 +157,25 @@ def side_context(device, i):
     return pool[i - 1]
 
 
+_side_perm = {}       # device -> [creation index of the stream side context i currently holds]
+
+
+def set_side_stream_shift(device, n, shift):
+    """Side context i (i < n) of `device` takes the stream that was CREATED as number (i + shift) % n (pl_ctx_swap_streams;
+    pools, graphs and events stay with their contexts).  The hardware queue of a stream follows its creation order, so a
+    shift moves a pipeline's replicas onto other queues without re-capturing anything (Net._probe_streams)."""
+    side_context(device, n)
+    pool = _side_pool[int(device)]
+    cur = _side_perm.setdefault(int(device), [])
+    cur.extend(range(len(cur), len(pool)))
+    want = [(i + int(shift)) % n for i in range(n)]
+    for i in range(n):
+        if cur[i] != want[i]:
+            j = cur.index(want[i])
+            _lib.call("pl_ctx_swap_streams", pool[i].handle, pool[j].handle)
+            cur[i], cur[j] = cur[j], cur[i]
+
+
 def reserve_side_contexts(device, n):
     if n > 0:
         side_context(device, n)

@@ -28,7 +28,7 @@ from . import hip
 from .hip import DeviceArray
 from . import q4 as _q4
 from .layer import layer_map, wrap
-from .plan import assign_layouts, chain_winograd, fuse_flow, pair_sibling_convs
+from .plan import assign_layouts, chain_winograd, fuse_conv1x1_wino_in, fuse_flow, pair_sibling_convs
 
 _q4.register(layer_map)
 
@@ -200,6 +200,7 @@ class _PipelinePlan:
             rp.max_in_flight = max(2, 24 // len(replicas))
         self.algos = replicas[0].algos
         self.turn, self.last = 0, replicas[0]
+        self.stream_probe = None             # {"shift": s, "ms_per_pass": [...]} once Net._probe_streams has placed the replicas
 
     @property
     def inputs(self):
@@ -294,6 +295,7 @@ class Net:
         self._algo = {}              # conv shape signature -> chosen w_layout
         self.wino_chains = 0         # F(4x4,3x3) output / input transform pairs the last plan runs as one kernel
         self.conv_pairs = 0          # sibling conv pairs the last plan runs as one launch
+        self.conv_wino_fused = 0     # 1x1 convs the last plan runs inside the next conv's Winograd input transform
         # force_algo: w_layout (int) every eligible 3x3/s1/p1 conv must use, or None = pick by timing
         fa = os.environ.get("PLANER_HIP_CONV_ALGO")
         self.force_algo = int(fa) if fa else None
@@ -397,8 +399,8 @@ class Net:
                 if profile:                                  # ONE marker per step boundary: step time = marker to marker
                     events.append((name, obj.name, hip.Event(self.ctx).record()))
                 if record is not None and obj.name in ("conv", "conv_fused", "conv_q4", "dense", "matmul", "wino4_gemm", "conv_q4_pair",
-                                                       "conv_pool_q4"):
-                    lay = obj.para().get("w_layout", 2 if obj.name == "conv_q4_pair" else 0) if obj.name != "conv" else 0
+                                                       "conv_pool_q4", "conv1x1_wino_in"):
+                    lay = obj.para().get("w_layout", 2 if obj.name in ("conv_q4_pair", "conv1x1_wino_in") else 0) if obj.name != "conv" else 0
                     lname = name
                     if obj.name == "wino4_gemm":               # the GEMM stage of a staged F(4x4,3x3) conv
                         lay, lname = 7, name[:-len("@gemm")]
@@ -529,6 +531,14 @@ class Net:
                 return (shp is not None and len(shp) == 4 and shp[0] * (shp[1] // 4) >= self.ctx.cu_count // 2
                         and _q4.wino4_chain_supported(tuple(shp), self.ctx))
             out_list, out_flow, self.wino_chains = chain_winograd(out_list, out_flow, fits, chain=mode != "stages")
+            # a 1x1 conv whose only reader is such a conv's input transform writes V itself (detection nets at small maps: one
+            # launch less per 3x3 conv); PLANER_HIP_CONV1X1_WINO=0 turns it off, =<tiles> moves the size limit
+            lim = os.environ.get("PLANER_HIP_CONV1X1_WINO", "4096")
+            if lim != "0":
+                def small(key):
+                    shp = shapes.get(key.split("@")[0])
+                    return shp is not None and len(shp) == 4 and shp[0] * (-(-shp[2] // 4)) * (-(-shp[3] // 4)) <= int(lim)
+                out_list, out_flow, self.conv_wino_fused = fuse_conv1x1_wino_in(out_list, out_flow, self._shape_of_init, small)
         return out_list, out_flow
 
     @staticmethod
@@ -822,6 +832,7 @@ class Net:
                     del reps
                     continue
                 cand = _PipelinePlan(reps, ctx, nfused)
+                self._probe_streams(cand, xs)
             if len(todo) == 1:
                 best = cand
                 break
@@ -858,6 +869,47 @@ class Net:
             self.save_algo_cache()
             self._algo_dirty = False
         return best
+
+    def _probe_streams(self, plan, xs):
+        """Which hardware queue the runtime put a stream on follows the order in which the process created its streams, and a
+        pipeline's rate depends on where its replicas land (depth 7: 53.1 k img/s or 50.4 k) -- a host that
+        created streams of its own first, or RCCL at world > 1, shifts the map.  So the replicas are not tied to the streams they
+        were captured on: with three spare side streams behind the ones the pipeline needs, every rotation of the assignment
+        (hip.set_side_stream_shift, 0..3 = one period of the four queues) runs the plan for a few milliseconds and the fastest
+        stays.  PLANER_HIP_STREAM_PROBE=0 keeps creation order, =<s> forces a shift."""
+        want = os.environ.get("PLANER_HIP_STREAM_PROBE", "auto")
+        nrep = len(plan.replicas)
+        if want == "0" or nrep < 2:
+            return
+        nside = nrep - 1 + 3
+        dev, ctx = self.ctx.device, self.ctx
+
+        def run(rounds):
+            for _ in range(rounds * nrep):
+                plan.feed(xs)
+                plan.launch(join=False)
+            plan.join()
+            ctx.synchronize()
+        if want != "auto":
+            hip.set_side_stream_shift(dev, nside, int(want))
+            plan.stream_probe = {"shift": int(want), "forced": True}
+            return
+        ms = []
+        for s_ in range(4):
+            hip.set_side_stream_shift(dev, nside, s_)
+            run(1)
+            best = None
+            for _ in range(2):
+                t0 = time.perf_counter()
+                run(3)
+                t = (time.perf_counter() - t0) / (3 * nrep) * 1e3
+                best = t if best is None else min(best, t)
+            ms.append(round(best, 5))
+        pick = min(range(4), key=lambda i: ms[i])
+        if ms[0] <= ms[pick] * 1.01:             # creation order unless another assignment is clearly (> 1 %) faster
+            pick = 0
+        hip.set_side_stream_shift(dev, nside, pick)
+        plan.stream_probe = {"shift": pick, "ms_per_pass": ms}
 
     def _side_context(self, i):
         """Extra stream (context) number i of this net's device; 0 is the net's own."""

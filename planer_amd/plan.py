@@ -334,6 +334,60 @@ def chain_winograd(body, flow, supported=lambda key: True, chain=True):
     return out_body, [[srcs, [name], dst] for srcs, name, kind, para, dst in steps], nchained
 
 
+# ---- 1x1 conv -> staged Winograd conv ----------------------------------------------------------------------
+def fuse_conv1x1_wino_in(body, flow, kshape=lambda key: None, small=lambda key: True):
+    """-> (body', flow', number of fused pairs).  A direct channel-quad 1x1 conv (w_layout 2, stride 1, no padding, group 1,
+    no residual) whose ONLY reader is the input-transform stage of a staged F(4x4,3x3) conv (`wino4_in`, made explicit by
+    chain_winograd) becomes one `conv1x1_wino_in` step that writes that stage's V (q4.Conv1x1WinoIn): the 1x1 -> 3x3 pairs of a
+    Darknet block.  `small(key)` says whether the activation is small enough for the launch saved to matter (the fused kernel
+    computes the 1x1 conv on overlapping patches: 1.9x its multiplies)."""
+    kinds = {b[0]: b for b in body}
+    steps = [[list(src) if isinstance(src, (list, tuple)) else [src], names[0] if isinstance(names, (list, tuple)) else names, dst]
+             for src, names, dst in flow]
+    readers, writers = {}, {}
+    for i, (srcs, name, dst) in enumerate(steps):
+        for k in set(srcs):
+            readers.setdefault(k, []).append(i)
+        for k in _as_list(dst):
+            writers.setdefault(k, []).append(i)
+    last_dsts = set(_as_list(steps[-1][2])) if steps else set()
+    drop, repl, nfused = set(), {}, 0
+    for i, (srcs, name, dst) in enumerate(steps):
+        if kinds[name][1] != "wino4_in" or len(srcs) != 1:
+            continue
+        y = srcs[0]
+        if len(writers.get(y, [])) != 1 or readers.get(y, []) != [i] or y in last_dsts:
+            continue
+        j = writers[y][0]
+        csrcs, cname, cdst = steps[j]
+        _, ckind, cpara = kinds[cname]
+        full = csrcs + ["None"] * (6 - len(csrcs))
+        k = kshape(full[1])
+        if (j >= i or j in drop or ckind != "conv_q4" or cpara.get("w_layout") != 2 or not isinstance(cdst, str) or full[5] != "None"
+                or k is None or tuple(k[2:]) != (1, 1) or k[0] % 4 or int(cpara.get("group", 1)) != 1
+                or [int(v) for v in cpara.get("strides", (1, 1))] != [1, 1] or [int(v) for v in cpara.get("dilations", (1, 1))] != [1, 1]
+                or any(int(v) for v in cpara.get("pads", (0, 0, 0, 0))) or int(cpara.get("act", 0)) & ~3 or not small(y)):
+            continue
+        fname = cname + "@v4"
+        repl[j] = (full[:5], fname, "conv1x1_wino_in", {"act": int(cpara.get("act", 0)), "alpha": float(cpara.get("alpha", 0.0)), "wino": 4}, dst)
+        drop.add(i)
+        nfused += 1
+    out = []
+    for i, (srcs, name, dst) in enumerate(steps):
+        if i in drop:
+            continue
+        if i in repl:
+            out.append(repl[i])
+        else:
+            out.append((srcs, name, kinds[name][1], kinds[name][2], dst))
+    out_body, seen = [], set()
+    for srcs, name, kind, para, dst in out:
+        if name not in seen:
+            seen.add(name)
+            out_body.append([name, kind, para])
+    return out_body, [[srcs, [name], dst] for srcs, name, kind, para, dst in out], nfused
+
+
 # ---- sibling convolutions --------------------------------------------------------------------------------
 # Where a graph forks into two direct channel-quad convs on the same tensor -- a ResNet block that changes resolution:
 # the stride-2 3x3 conv and the 1x1 stride-2 projection -- both run in ONE launch (q4.ConvQ4Pair,

@@ -380,6 +380,23 @@ def Wino4Chain(m, B=None, scale=None, shift=None, resq=None, act=ACT_NONE, alpha
     return (y, v) if keep_y else v
 
 
+def Conv1x1WinoIn(xq, Kq, B=None, scale=None, shift=None, act=ACT_NONE, alpha=0.0, wino=4, **_):
+    """ConvQ4 (1x1, stride 1, group 1, fused bias / scale / shift / activation, no residual) and the Wino4In of the 3x3 conv
+    that is its only reader, in one kernel -> V (csrc/conv1x1_wino_in_kernel.h).  Emitted by plan.fuse_conv1x1_wino_in for the
+    1x1 -> 3x3 pairs of a detection net's blocks at small maps; the 1x1 conv's own output never exists."""
+    _f32(xq, Kq, B, scale, shift)
+    if not is_q4(xq):
+        raise TypeError("Conv1x1WinoIn needs a Q4 activation")
+    n, cin, h, w = logical_shape(xq)
+    cout, cin_k, kh, kw = Kq.shape
+    if (kh, kw) != (1, 1) or cin_k != cin or cout % 4 or int(wino) != 4:
+        raise ValueError("Conv1x1WinoIn: 1x1 filter %s on input %s, Cout %% 4 == 0, F(4x4,3x3) tiles" % (Kq.shape, (n, cin, h, w)))
+    v = _wino_tensor(n, cout, h, w, xq.ctx)
+    _lib.call("pl_conv1x1_wino_in_q4_f32", xq.ctx.handle, xq.ptr, n, cin, h, w, Kq.ptr, cout, _ptr(B), _ptr(scale), _ptr(shift),
+              int(act), float(alpha), int(wino), v.ptr)
+    return v
+
+
 # ---- HBM-bound layers on Q4 tensors ---------------------------------------------------------
 def _like(x, shape=None):
     y = empty(shape or x.shape, ctx=x.ctx)
@@ -526,5 +543,5 @@ def register(layer_map):
     """Plan-internal kinds (never present in a user's IR)."""
     layer_map.update({"to_q4": to_q4, "from_q4": from_q4, "conv_q4": ConvQ4, "upconcat_q4": UpConcatQ4,
                       "wino4_in": Wino4In, "wino4_gemm": Wino4Gemm, "wino4_out": Wino4Out, "wino4_chain": Wino4Chain,
-                      "conv_q4_pair": ConvQ4Pair, "conv_pool_q4": ConvPoolQ4})
+                      "conv_q4_pair": ConvQ4Pair, "conv_pool_q4": ConvPoolQ4, "conv1x1_wino_in": Conv1x1WinoIn})
     layer_map.update({k + "_q4": f for k, f in Q4_LAYERS.items()})

@@ -389,3 +389,62 @@ def test_pair_sibling_convs_leaves_other_forks_alone():
     body, flow, kshape = _fork_prog()
     flow[2][0][5] = "ya"
     assert pair_sibling_convs(body, flow, kshape)[2] == 0
+
+
+# ---- 1x1 conv -> staged Winograd conv (plan.fuse_conv1x1_wino_in): pure host logic ---------------------
+def _darknet_pair(extra=(), act1=2, res="x"):
+    """x -> 1x1 conv (w_layout 2) -> y1 -> 3x3 conv (F(4x4,3x3) staged) + residual x -> y2 [-> extra steps]."""
+    body = [["c1", "conv_q4", {"w_layout": 2, "strides": [1, 1], "pads": [0, 0, 0, 0], "act": act1, "alpha": 0.1}],
+            ["c2", "conv_q4", {"w_layout": 7, "strides": [1, 1], "pads": [1, 1, 1, 1], "act": 2 | 16, "alpha": 0.1}]]
+    flow = [[["x", "K1", "None", "S1", "H1", "None"], ["c1"], "y1"],
+            [["y1", "K2", "None", "S2", "H2", res], ["c2"], "y2"]]
+    for b, f in extra:
+        body.append(b)
+        flow.append(f)
+    return body, flow
+
+
+KSHAPES = {"K1": (64, 128, 1, 1), "K2": (128, 64, 3, 3)}
+
+
+def test_conv1x1_feeding_a_staged_winograd_conv_writes_its_v():
+    from planer_amd.plan import chain_winograd, fuse_conv1x1_wino_in
+    body, flow = _darknet_pair()
+    b, f, _ = chain_winograd(body, flow)
+    b, f, n = fuse_conv1x1_wino_in(b, f, KSHAPES.get)
+    assert n == 1
+    assert [s[1][0] for s in f] == ["c1@v4", "c2@gemm", "c2@out"]
+    kinds = {e[0]: e for e in b}
+    assert kinds["c1@v4"][1] == "conv1x1_wino_in" and kinds["c1@v4"][2] == {"act": 2, "alpha": 0.1, "wino": 4}
+    assert f[0] == [["x", "K1", "None", "S1", "H1"], ["c1@v4"], "c2@V"]
+    assert f[1][0] == ["c2@V", "K2"]
+    assert "c1" not in kinds and "c2@in" not in kinds
+
+
+def test_conv1x1_wino_in_guards():
+    from planer_amd.plan import chain_winograd, fuse_conv1x1_wino_in
+
+    def fused(body, flow, kshape=KSHAPES.get, small=lambda key: True):
+        b, f, _ = chain_winograd(body, flow)
+        return fuse_conv1x1_wino_in(b, f, kshape, small)[2]
+    # a second reader of the 1x1 conv's output keeps it
+    body, flow = _darknet_pair(extra=[(["r", "leakyrelu_q4", {}], [["y1"], ["r"], "z"])])
+    assert fused(body, flow) == 0
+    # ... and so does being the program's result
+    body, flow = _darknet_pair()
+    flow.append([["y2", "y1"], ["cat"], "out"])
+    body.append(["cat", "concat_q4", {"axis": 1}])
+    assert fused(body, flow) == 0
+    # strided / padded / grouped / residual-carrying / 3x3 producers, or a map the caller calls large
+    for para in ({"strides": [2, 2]}, {"pads": [1, 1, 1, 1]}, {"group": 2}, {"dilations": [2, 2]}, {"w_layout": 7}, {"act": 2 | 16}):
+        body, flow = _darknet_pair()
+        body[0][2] = dict(body[0][2], **para)
+        assert fused(body, flow) == 0, para
+    body, flow = _darknet_pair()
+    flow[0][0][5] = "x"
+    assert fused(body, flow) == 0
+    body, flow = _darknet_pair()
+    assert fused(body, flow, kshape={"K1": (64, 128, 3, 3), "K2": (128, 64, 3, 3)}.get) == 0
+    assert fused(body, flow, kshape={"K1": (62, 128, 1, 1), "K2": (128, 62, 3, 3)}.get) == 0
+    assert fused(body, flow, small=lambda key: False) == 0
+    assert fused(body, flow) == 1
