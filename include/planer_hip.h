@@ -47,6 +47,7 @@ extern "C" {
 
 typedef struct pl_ctx pl_ctx;     /* one device + one stream + one memory pool */
 typedef struct pl_graph pl_graph; /* a captured forward pass (hipGraphExec)     */
+typedef struct pl_plan pl_plan;   /* a whole compiled forward pass read from a plan file (pl_plan_build) */
 typedef struct pl_event pl_event; /* hipEvent on the context stream             */
 
 /* ---- runtime --------------------------------------------------------- */
@@ -66,6 +67,7 @@ int pl_sync(pl_ctx *ctx); /* wait for the context stream */
 int pl_alloc(pl_ctx *ctx, size_t bytes, void **out); /* pooled, stream-ordered */
 int pl_free(pl_ctx *ctx, void *ptr);
 int pl_pool_stats(pl_ctx *ctx, size_t *bytes_reserved, size_t *bytes_in_use);
+int pl_pool_block(pl_ctx *ctx, const void *ptr, void **base, size_t *bytes); /* the pool block that holds ptr */
 int pl_pool_trim(pl_ctx *ctx);                       /* hipFree cached blocks */
 /* np.asarray / .get() of net.py:96-100 */
 int pl_h2d(pl_ctx *ctx, void *dst, const void *src_host, size_t bytes);
@@ -97,6 +99,23 @@ int pl_capture_begin(pl_ctx *ctx);
 int pl_capture_end(pl_ctx *ctx, pl_graph **out);
 int pl_graph_launch(pl_graph *g);
 int pl_graph_destroy(pl_graph *g);
+
+/* ---- a compiled forward pass without the Python host ----------------------------------------
+ * Replaces the reference's interpreter loop (net.Net.forward, net.py:37-72) for hosts that bind this header directly.
+ * A plan file (written once by planer_amd.export.export_plan from a loaded Net and an input shape) holds the FUSED program of
+ * the plan compiler -- fused conv epilogues, channel-quad layouts, Winograd stages and chains, paired convs -- as the flat
+ * sequence of calls of this ABI, with the constants (weights, prepared filters) and the activation arena's size.
+ *   pl_plan_build    parses the file, uploads the constants, runs the sequence once and captures it into a hipGraph
+ *   pl_plan_tensor   input / output i: the plan's own device buffer, its size, element type (0 f32, 1 i32, 2 i64, 3 u8) and shape
+ *   pl_plan_run      copies inputs[i] (device pointers; NULL = the caller wrote the plan's buffer itself) in, launches the
+ *                    graph, copies the outputs to outputs[i] (device pointers; NULL = read the plan's buffer) -- asynchronous
+ *                    on the context's stream like every other call (pl_sync waits)
+ *   pl_plan_destroy  frees graph, arena and constants */
+int pl_plan_build(pl_ctx *ctx, const void *program, size_t program_bytes, pl_plan **out);
+int pl_plan_info(pl_plan *plan, int *n_inputs, int *n_outputs, size_t *arena_bytes, size_t *const_bytes, int *n_calls);
+int pl_plan_tensor(pl_plan *plan, int output, int index, void **device_ptr, size_t *bytes, int *dtype, int *ndim, int *dims8);
+int pl_plan_run(pl_plan *plan, const void *const *inputs, void *const *outputs);
+int pl_plan_destroy(pl_plan *plan);
 
 /* ---- MFMA-bound ops --------------------------------------------------- */
 /* layer.Conv2d (layer.py:22-26) == util.conv_for (util.py:17-44) + bias add.

@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libplaner_hip.so")
-SOURCES = ["runtime.hip", "pointwise.hip", "head_ops.hip", "conv_direct.hip", "conv_winograd.hip"]
+SOURCES = ["runtime.hip", "pointwise.hip", "head_ops.hip", "conv_direct.hip", "conv_winograd.hip", "plan_exec.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall",
          "-Wno-unused-function", "-ffp-contract=off"]
 
@@ -33,7 +33,7 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=True):
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h") or f.endswith(".inc")]
     headers.append(os.path.join(HERE, "..", "include", "planer_hip.h"))
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)

@@ -35,6 +35,7 @@ SIGNATURES = {
     "pl_alloc": [_P, _Z, POINTER(_P)],
     "pl_free": [_P, _P],
     "pl_pool_stats": [_P, POINTER(c_size_t), POINTER(c_size_t)],
+    "pl_pool_block": [_P, _P, POINTER(_P), POINTER(c_size_t)],
     "pl_pool_trim": [_P],
     "pl_h2d": [_P, _P, _P, _Z],
     "pl_d2h": [_P, _P, _P, _Z],
@@ -52,6 +53,11 @@ SIGNATURES = {
     "pl_capture_end": [_P, POINTER(_P)],
     "pl_graph_launch": [_P],
     "pl_graph_destroy": [_P],
+    "pl_plan_build": [_P, _P, _Z, POINTER(_P)],
+    "pl_plan_info": [_P, POINTER(c_int), POINTER(c_int), POINTER(c_size_t), POINTER(c_size_t), POINTER(c_int)],
+    "pl_plan_tensor": [_P, _I, _I, POINTER(_P), POINTER(c_size_t), POINTER(c_int), POINTER(c_int), POINTER(c_int)],
+    "pl_plan_run": [_P, POINTER(_P), POINTER(_P)],
+    "pl_plan_destroy": [_P],
     "pl_conv2d_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P] + [_I] * 9,
     "pl_conv2d_fused_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P] + [_I] * 9
                            + [_P, _P, _P, _I, c_double, _I],
@@ -201,8 +207,13 @@ def check(rc):
     raise HipBackendError(msg)
 
 
+_recorder = None        # planer_amd.export: sees every call that goes through `call` while a plan is being recorded
+
+
 def call(name, *args):
     check(getattr(load(), name)(*args))
+    if _recorder is not None:
+        _recorder(name, args)
 
 
 __all__ = ["load", "check", "call", "HipBackendError", "NotCapturable", "SIGNATURES", "LIB_PATH",

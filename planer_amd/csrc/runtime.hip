@@ -173,6 +173,23 @@ int pl_free(pl_ctx *ctx, void *ptr) {
     return PL_OK;
 }
 
+// The pool block that holds `ptr` (any address inside it): its base and size.  planer_amd.export uses it to find the extent of
+// the constants a recorded forward pass reads (weights, prepared filters, lookup tables).
+int pl_pool_block(pl_ctx *ctx, const void *ptr, void **base, size_t *bytes) {
+    PL_REQUIRE(ctx && ptr && base && bytes, PL_EINVAL, "pl_pool_block: null argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    for (auto &kv : ctx->block_size) {
+        const char *b = (const char *)kv.first;
+        if ((const char *)ptr >= b && (const char *)ptr < b + kv.second) {
+            *base = kv.first;
+            *bytes = kv.second;
+            return PL_OK;
+        }
+    }
+    pl_set_error("pl_pool_block: %p is not inside a block of this context's pool", ptr);
+    return PL_EINVAL;
+}
+
 int pl_pool_stats(pl_ctx *ctx, size_t *bytes_reserved, size_t *bytes_in_use) {
     PL_REQUIRE(ctx, PL_EINVAL, "null ctx");
     std::lock_guard<std::mutex> lk(ctx->mu);

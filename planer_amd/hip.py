@@ -17,6 +17,7 @@ from ._lib import byref, c_int, c_size_t, c_void_p
 float32 = numpy.float32
 
 _default_ctx = None
+_free_hook = None         # planer_amd.export: told about every block a DeviceArray gives back while a plan is being recorded
 
 
 class Context:
@@ -160,20 +161,28 @@ def side_context(device, i):
 _side_perm = {}       # device -> [creation index of the stream side context i currently holds]
 
 
-def set_side_stream_shift(device, n, shift):
-    """Side context i (i < n) of `device` takes the stream that was CREATED as number (i + shift) % n (pl_ctx_swap_streams;
-    pools, graphs and events stay with their contexts).  The hardware queue of a stream follows its creation order, so a
-    shift moves a pipeline's replicas onto other queues without re-capturing anything (Net._probe_streams)."""
+def set_side_stream_perm(device, want):
+    """Side context i of `device` takes the stream that was CREATED as number want[i] (a permutation of range(len(want));
+    pl_ctx_swap_streams: pools, graphs and events stay with their contexts)."""
+    n = len(want)
     side_context(device, n)
     pool = _side_pool[int(device)]
     cur = _side_perm.setdefault(int(device), [])
     cur.extend(range(len(cur), len(pool)))
-    want = [(i + int(shift)) % n for i in range(n)]
+    if sorted(want) != list(range(n)) or sorted(cur[:n]) != list(range(n)):
+        raise ValueError("set_side_stream_perm: not a permutation of the first %d side streams: %r (current %r)" % (n, want, cur[:n]))
     for i in range(n):
         if cur[i] != want[i]:
             j = cur.index(want[i])
             _lib.call("pl_ctx_swap_streams", pool[i].handle, pool[j].handle)
             cur[i], cur[j] = cur[j], cur[i]
+
+
+def set_side_stream_shift(device, n, shift):
+    """Side context i (i < n) of `device` takes the stream created as number (i + shift) % n.  The hardware queue of a stream
+    follows its creation order, so a shift moves a pipeline's replicas onto other queues without re-capturing anything
+    (Net._probe_streams)."""
+    set_side_stream_perm(device, [(i + int(shift)) % n for i in range(n)])
 
 
 def reserve_side_contexts(device, n):
@@ -382,6 +391,8 @@ class DeviceArray:
     def __del__(self):
         try:
             if self._owned and self._p and self.ctx.handle is not None:
+                if _free_hook is not None:
+                    _free_hook(self._p)
                 _lib.load().pl_free(self.ctx.handle, self._p)
         except Exception:
             pass

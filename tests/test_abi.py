@@ -88,3 +88,13 @@ def test_operator_table_covers_every_reference_kind():
     # the importer's op table only emits kinds the operator table has
     from planer_amd.onnx_import import OP_TABLE
     assert [kind for kind, _ in OP_TABLE.values() if kind not in layer.layer_map] == []
+
+
+def test_plan_dispatch_table_is_current():
+    """csrc/plan_dispatch.inc (the thunks pl_plan_build resolves call names with) is generated from the ctypes signature table:
+    an ABI change without re-running tools/gen_plan_dispatch.py would leave a plan file calling through a stale prototype."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_plan_dispatch.py"), "--check"])
+    assert r.returncode == 0, "run tools/gen_plan_dispatch.py and rebuild"
