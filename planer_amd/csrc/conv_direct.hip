@@ -1548,10 +1548,27 @@ int pl_conv2d_rowpacked_q4_f32(pl_ctx *ctx, const float *xp, int N, int Cin, int
 }
 
 // The row-packed stem conv + maxpool(3x3 / stride 2 / pad 1) in one kernel (conv_stem_pool_kernel.h).  The kernel is built for
-// the stem of an ImageNet-style net: 3 input channels, 7x7 / stride 2 / pad 3, a 112-pixel-wide conv map (W = 224).
+// the stem of an ImageNet-style net: 3 input channels, 7x7 / stride 2 / pad 3; any height, any width (maps wider than 112 conv
+// columns are cut into column chunks).
+// -> column chunks per strip, pooled columns per chunk, 16-column blocks per workgroup (0 chunks: not supported)
+static void stem_pool_chunks(int Wo, int &chunks, int &pq, int &nb) {
+    const int Wq = (Wo + 1) / 2;
+    chunks = 0;
+    for (int c = 1; c <= 64; ++c) {
+        pq = (Wq + c - 1) / c;
+        const int cols = c == 1 ? Wo : 2 * pq + 2;                 // chunk c > 0 starts one window early
+        nb = (cols + 15) / 16;
+        if (nb <= SP_NB_MAX) {
+            chunks = c;
+            return;
+        }
+    }
+}
 static bool stem_pool_shape_ok(int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw, int pt, int pl) {
     const int Wo = (W + 2 * pl - kw + sw) / sw, Ho = (H + 2 * pt - kh + sh) / sh;
-    return Cin == 3 && kh == SP_KH && kw == 7 && sh == 2 && sw == 2 && pt == 3 && pl == 3 && Wo == 16 * SP_NB && Ho >= 2 && Cout > 0 &&
+    int chunks = 0, pq = 0, nb = 0;
+    if (Wo >= 1) stem_pool_chunks(Wo, chunks, pq, nb);
+    return Cin == 3 && kh == SP_KH && kw == 7 && sh == 2 && sw == 2 && pt == 3 && pl == 3 && Wo >= 1 && chunks > 0 && Ho >= 2 && Cout > 0 &&
            Cout % 4 == 0;
 }
 
@@ -1567,7 +1584,7 @@ int pl_conv2d_rowpacked_pool_q4_f32(pl_ctx *ctx, const float *xp, int N, int Cin
     int rc = rowpack_check(ctx, xp, N, Cin, H, W, wq, Cout, kh, kw, yq, sh, sw, pt, pl, nullptr);
     if (rc != PL_OK) return rc;
     PL_REQUIRE(stem_pool_shape_ok(Cin, H, W, Cout, kh, kw, sh, sw, pt, pl), PL_EUNSUPPORTED,
-               "conv + maxpool (row-packed stem): 3 channels, 7x7 / stride 2 / pad 3 on a 224-pixel-wide input, Cout %% 4 == 0");
+               "conv + maxpool (row-packed stem): 3 channels, 7x7 / stride 2 / pad 3, Cout %% 4 == 0");
     PL_REQUIRE(act >= 0 && act <= 2, PL_EINVAL, "pl_conv2d_rowpacked_pool_q4_f32: bad activation code");
     PL_REQUIRE(((reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift)) & 15u) == 0,
                PL_EINVAL, "pl_conv2d_rowpacked_pool_q4_f32: bias / scale / shift are read as 16-byte quads");
@@ -1587,20 +1604,32 @@ int pl_conv2d_rowpacked_pool_q4_f32(pl_ctx *ctx, const float *xp, int N, int Cin
     a.cout_blocks = (Cout + 63) / 64;
     const int q_pad = (kh * ((kw * Cin + 3) / 4) + 7) / 8 * 8;
     const size_t yb = (size_t)N * a.Coq * a.Hq * a.Wq * 16;
-    PL_REQUIRE(a.rowf + 3 <= SP_XROW && pelems < (1ull << 29) && yb < (1ull << 31) && 4 * SP_GROUPS <= q_pad, PL_EUNSUPPORTED,
+    int nb = 0;
+    stem_pool_chunks(a.Wo, a.chunks, a.pq, nb);
+    PL_REQUIRE(a.chunks > 0 && pelems < (1ull << 29) && yb < (1ull << 31) && 4 * SP_GROUPS <= q_pad, PL_EUNSUPPORTED,
                "conv + maxpool (row-packed stem): tensor too large");
     a.x_bytes = (unsigned)(pelems * 4); a.w_bytes = (unsigned)((size_t)q_pad * Cout * 16); a.y_bytes = (unsigned)yb;
     a.ep = make_epilogue(bias, scale, shift, nullptr, act, alpha);
-    const long long blocks = (long long)N * a.strips * a.cout_blocks;
+    const long long blocks = (long long)N * a.strips * a.chunks * a.cout_blocks;
     PL_REQUIRE(blocks < (1ll << 31), PL_EUNSUPPORTED, "conv + maxpool (row-packed stem): grid too large");
-    hipLaunchKernelGGL(conv_stem_pool_kernel, dim3((unsigned)blocks), dim3(512), 0, ctx->stream, a);
+    void (*kern)(const StemPoolArgs) = nullptr;
+    switch (nb) {
+    case 1: kern = conv_stem_pool_kernel<1>; break;
+    case 2: kern = conv_stem_pool_kernel<2>; break;
+    case 3: kern = conv_stem_pool_kernel<3>; break;
+    case 4: kern = conv_stem_pool_kernel<4>; break;
+    case 5: kern = conv_stem_pool_kernel<5>; break;
+    case 6: kern = conv_stem_pool_kernel<6>; break;
+    default: kern = conv_stem_pool_kernel<7>; break;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), 0, ctx->stream, a);
     PL_LAUNCH_CHECK();
-    char buf[96];
-    snprintf(buf, sizeof buf, "stem+maxpool 64co x 2 rows x 112px, strips=%d blocks=%lld", a.strips, blocks);
+    char buf[112];
+    snprintf(buf, sizeof buf, "stem+maxpool 64co x 2 rows x %dpx, strips=%d chunks=%d blocks=%lld", 16 * nb, a.strips, a.chunks, blocks);
     ctx->last_plan = buf;
-    // executed MFMA work: 16 conv rows per strip, 112 columns, K = 176
+    // executed MFMA work: 16 conv rows per strip, 16 nb columns per chunk, K = 176
     ctx->last_gemm[0] = 1; ctx->last_gemm[1] = (long long)a.cout_blocks * 64;
-    ctx->last_gemm[2] = (long long)N * a.strips * 16 * 16 * SP_NB; ctx->last_gemm[3] = 16 * SP_GROUPS;
+    ctx->last_gemm[2] = (long long)N * a.strips * a.chunks * 16 * 16 * nb; ctx->last_gemm[3] = 16 * SP_GROUPS;
     return PL_OK;
 }
 

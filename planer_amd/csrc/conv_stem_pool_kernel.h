@@ -24,6 +24,12 @@
 // starts at -1e4 (util.py:88,95).  max is exact, so the result equals conv kernel + pool kernel wherever the conv values agree
 // (the K summation order here is one fmaf chain per output in this kernel's k order: equal to the tiled kernel's within
 // rounding, tested against the oracle with the conv tolerance).
+// Width: a workgroup covers NB blocks of 16 conv columns (template parameter, 1..7: registers and LDS are sized by it) of ONE
+// column chunk of its strip.  A map up to 112 conv columns wide is one chunk starting at column 0 (the left neighbour of the
+// first window is the pool's zero padding); wider maps are cut into chunks of `pq` pooled columns, chunk c > 0 starting one
+// window early (conv column 2 c pq - 2, an even column, so window centres stay on even lanes) and not storing that first
+// window -- two recomputed conv columns per chunk border.  Columns past the map's edge count as zero padding (masked before
+// the horizontal maximum).  ResNet's 224-pixel stem is NB = 7, one chunk.
 struct StemPoolArgs {
     const float *xp;       // row-packed image [N][Hp][rowf] (zero border included)
     const float *wq;       // [Qpad][Cout][4] row-packed filter
@@ -32,26 +38,29 @@ struct StemPoolArgs {
     int Ho, Wo, Hq, Wq, Cout, Coq;
     int strips;            // strips of 7 pooled rows per image
     int cout_blocks;
+    int chunks, pq;        // column chunks per strip, pooled columns per chunk
     unsigned x_bytes, w_bytes, y_bytes;
     Epilogue ep;
 };
 
-constexpr int SP_NB = 7;                         // 16-pixel blocks per conv row (Wo = 112)
+constexpr int SP_NB_MAX = 7;                     // 16-pixel blocks per conv row a workgroup can take (registers, LDS)
 constexpr int SP_KH = 7, SP_RQ = 6;              // filter rows, k-quads per filter row (kw * Cin = 21 floats -> 6 quads)
 constexpr int SP_GROUPS = (SP_KH * SP_RQ + 3) / 4;      // 11 groups of 4 k-quads (42 real + 2 zero quads)
-constexpr int SP_XROW = 704;                     // floats per staged input row (693 used)
 constexpr int SP_XROWS = 9;                      // input rows under a conv-row pair: 2 r .. 2 r + 8
 constexpr int SP_W_FLOATS = 4 * SP_GROUPS * 64 * 4;             // 44 quads x 64 channels x 4
-constexpr int SP_X_FLOATS = SP_XROWS * SP_XROW;
-constexpr int SP_HP_CELLS = 16 * 56;             // one horizontally pooled conv row: 16 channel quads x 56 columns
 constexpr int SP_PROWS = 7;                      // pooled rows per strip
+constexpr int sp_xrow(int nb) { return 96 * nb + 32; }          // floats per staged input row: 6 per conv column + the last window's quads
 
 typedef float sp_f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float4 sp_max4(float4 a, float4 b) {
     return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
 }
+template <int SP_NB>
 __global__ void __launch_bounds__(512) conv_stem_pool_kernel(const StemPoolArgs p) {
+    constexpr int SP_XROW = sp_xrow(SP_NB), SP_X_FLOATS = SP_XROWS * SP_XROW;
+    constexpr int SP_PC = 8 * SP_NB;                 // pooled columns a workgroup's conv columns hold
+    constexpr int SP_HP_CELLS = 16 * SP_PC;          // one horizontally pooled conv row: 16 channel quads x SP_PC columns
     // separate LDS objects: an LDS-DMA into one row buffer must not hold up the fragment reads of the other (the compiler
     // orders LDS-DMA against later LDS accesses object by object)
     __shared__ __attribute__((aligned(16))) float Wf[SP_W_FLOATS];
@@ -64,11 +73,16 @@ __global__ void __launch_bounds__(512) conv_stem_pool_kernel(const StemPoolArgs 
     const int mb = wave & 3, rsel = wave >> 2;              // 16-channel block, conv row of the pair
     const int li = lane & 15, kk = lane >> 4;
 
-    unsigned t1, cob, n, strip;
+    unsigned t1, t2, cob, n, strip, chunk;
     cob = blockIdx.x % (unsigned)p.cout_blocks;
     t1 = blockIdx.x / (unsigned)p.cout_blocks;
-    n = t1 / (unsigned)p.strips;
-    strip = t1 - n * (unsigned)p.strips;
+    chunk = t1 % (unsigned)p.chunks;
+    t2 = t1 / (unsigned)p.chunks;
+    n = t2 / (unsigned)p.strips;
+    strip = t2 - n * (unsigned)p.strips;
+    const int q0 = (int)chunk * p.pq;                       // first pooled column this workgroup stores
+    const int x0 = chunk ? 2 * q0 - 2 : 0;                  // its first conv column; local pooled column l is global x0 / 2 + l
+    const int lskip = chunk ? 1 : 0, qend = min(q0 + p.pq, p.Wq);
     const int p0 = (int)strip * SP_PROWS;                   // first pooled row of the strip
     const int c0 = 2 * p0 - 1;                              // first conv row: the one above the first window's centre
     const int co0 = (int)cob * 64;
@@ -92,8 +106,8 @@ __global__ void __launch_bounds__(512) conv_stem_pool_kernel(const StemPoolArgs 
             const int idx = pc * 64 + lane;
             const int r = idx / (SP_XROW / 4), c = idx - r * (SP_XROW / 4);
             const int hr = hr0 + r;
-            const bool ok = idx < CELLS && (unsigned)hr < (unsigned)p.Hp && c * 4 < p.rowf + 3;
-            const int off = ok ? (int)((((unsigned)n * (unsigned)p.Hp + (unsigned)hr) * (unsigned)p.rowf + 4u * (unsigned)c) << 2) : OOB;
+            const bool ok = idx < CELLS && (unsigned)hr < (unsigned)p.Hp && 6 * x0 + c * 4 < p.rowf + 3;
+            const int off = ok ? (int)((((unsigned)n * (unsigned)p.Hp + (unsigned)hr) * (unsigned)p.rowf + (unsigned)(6 * x0) + 4u * (unsigned)c) << 2) : OOB;
             if (idx < CELLS) __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_float *)(Xb + pc * 256), 16, off, 0, 0, 0);
         }
     };
@@ -147,7 +161,7 @@ __global__ void __launch_bounds__(512) conv_stem_pool_kernel(const StemPoolArgs 
         } else {
             v = apply_epilogue4(p.ep, bias, scale, shift, z4, 4, make_float4(acc[nb][0], acc[nb][1], acc[nb][2], acc[nb][3]));
         }
-        if (!row_in) v = z4;
+        if (!row_in || x0 + 16 * nb + li >= p.Wo) v = z4;               // (columns past the map's edge: zero padding too)
         // window of pooled column q = 8 nb + li / 2 (even lanes): pixels 16 nb + li - 1, li, li + 1.  Neighbours by DPP within
         // the 16-lane row (one VALU move each; as ds_bpermute -- an LDS instruction -- the 84 shuffles of a step cost 6 us per
         // launch): lane li - 1 by row_shr:1, whose lane 0 keeps `old` = lane 15 of the previous pixel block (row_ror:1 of it)
@@ -165,7 +179,7 @@ __global__ void __launch_bounds__(512) conv_stem_pool_kernel(const StemPoolArgs 
             mo[e] = fmaxf(fmaxf(left, cv[e]), right);
         }
         vprev = v;
-        float4 *hp = HP + (k & 3) * SP_HP_CELLS + (mb * 4 + kk) * 56;
+        float4 *hp = HP + (k & 3) * SP_HP_CELLS + (mb * 4 + kk) * SP_PC;
         if ((li & 1) == 0) hp[8 * nb + (li >> 1)] = m;
     };
     // half of pooled row j (cells i = tid + 512 * half): rows 2 j, 2 j + 1, 2 j + 2 of the ring, running maximum from -1e4
@@ -174,11 +188,11 @@ __global__ void __launch_bounds__(512) conv_stem_pool_kernel(const StemPoolArgs 
         if (i < SP_HP_CELLS && prow < p.Hq) {
             const float4 *r0 = HP + ((2 * j) & 3) * SP_HP_CELLS, *r1 = HP + ((2 * j + 1) & 3) * SP_HP_CELLS,
                          *r2 = HP + ((2 * j + 2) & 3) * SP_HP_CELLS;
-            const int c = i / 56, q = i - c * 56;
+            const int c = i / SP_PC, ql = i - c * SP_PC, q = (x0 >> 1) + ql;
             float4 m = sp_max4(sp_max4(sp_max4(lo4, r0[i]), r1[i]), r2[i]);
             if (plain) m = make_float4(relu_ref(m.x), relu_ref(m.y), relu_ref(m.z), relu_ref(m.w));
             const int cqo = (int)cob * 16 + c;
-            const int off = (cqo < p.Coq && q < p.Wq)
+            const int off = (cqo < p.Coq && ql >= lskip && q < qend)
                                 ? (int)(((((unsigned)n * (unsigned)p.Coq + (unsigned)cqo) * (unsigned)p.Hq + (unsigned)prow) * (unsigned)p.Wq + (unsigned)q) << 4)
                                 : OOB;
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, m), yrsrc, off, 0, 0);

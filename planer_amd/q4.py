@@ -262,7 +262,7 @@ def ConvPoolQ4(x, Kq, B=None, scale=None, shift=None, group=1, strides=(1, 1), d
     written.  Emitted by the plan compiler (Net._fuse_stem_pool) where the max-pool is the conv's only reader."""
     _f32(x, Kq, B, scale, shift)
     if is_q4(x) or not stem_pool_eligible(x.shape, Kq.shape, group, strides, dilations, pads):
-        raise NotImplementedError("conv + maxpool in one kernel: NCHW 3-channel input, 7x7 / stride 2 / pad 3, width 224")
+        raise NotImplementedError("conv + maxpool in one kernel: NCHW 3-channel input, 7x7 / stride 2 / pad 3")
     if any(a is not None and a.ptr % 16 for a in (B, scale, shift)):
         raise ValueError("the stem + max-pool kernel reads bias / scale / shift as 16-byte quads: misaligned parameter")
     n, cin, h, w = x.shape

@@ -201,9 +201,14 @@ def test_stem_conv_maxpool_marching_kernel_matches_oracle(pa):
     rng = np.random.default_rng(123)
     para = dict(strides=[2, 2], pads=[3, 3, 3, 3], dilations=[1, 1], group=1)
     pool = dict(w=[3, 3], pads=[1, 1, 1, 1], strides=[2, 2])
-    for n, h, cout, act, tail in [(2, 224, 64, 1, "bn"), (1, 64, 64, 0, "bias"), (3, 100, 72, 1, "bn"), (2, 30, 8, 0, "none"),
-                                  (1, 226, 132, 2, "bn"), (32, 224, 64, 1, "bn")]:
-        x = rng.standard_normal((n, 3, h, 224)).astype(np.float32)
+    # (round 5: any width -- narrower maps take fewer 16-column blocks per workgroup, wider ones are cut into column chunks
+    #  that recompute two conv columns at each border; odd widths end in masked columns)
+    for n, h, cout, act, tail, wd in [(2, 224, 64, 1, "bn", 224), (1, 64, 64, 0, "bias", 224), (3, 100, 72, 1, "bn", 224),
+                                      (2, 30, 8, 0, "none", 224), (1, 226, 132, 2, "bn", 224), (32, 224, 64, 1, "bn", 224),
+                                      (2, 160, 64, 1, "bn", 160), (2, 256, 64, 1, "bn", 256), (1, 416, 64, 2, "bn", 416),
+                                      (2, 64, 64, 0, "bias", 64), (1, 50, 36, 1, "bn", 37), (1, 90, 64, 0, "none", 231),
+                                      (1, 70, 64, 1, "bn", 450), (1, 33, 12, 2, "bn", 1000), (2, 20, 64, 1, "bn", 12)]:
+        x = rng.standard_normal((n, 3, h, wd)).astype(np.float32)
         K = (rng.standard_normal((cout, 3, 7, 7)) * 0.1).astype(np.float32)
         B = rng.standard_normal(cout).astype(np.float32) if tail == "bias" else None
         sc = rng.uniform(0.5, 1.5, (1, cout, 1, 1)).astype(np.float32) if tail == "bn" else None
@@ -221,13 +226,14 @@ def test_stem_conv_maxpool_marching_kernel_matches_oracle(pa):
         conv = onp.relu(conv) if act == 1 else onp.leakyrelu(conv, 0.1) if act == 2 else conv
         want = onp.maxpool(conv, **pool)
         got = q4.from_q4(one).get()
-        assert_close(got, want, RTOL, "stem + maxpool %s" % ((n, h, cout, act, tail),))
+        assert_close(got, want, RTOL, "stem + maxpool %s" % ((n, h, cout, act, tail, wd),))
         assert_close(one.get(), two.get(), 1e-5, "one kernel vs conv kernel + pool kernel")
         np.testing.assert_array_equal(one.get(), q4_host(got))                 # padding lanes of the last quad stay zero
-    assert not q4.stem_pool_eligible((1, 3, 224, 200), (64, 3, 7, 7), **para)
+    assert q4.stem_pool_eligible((1, 3, 224, 200), (64, 3, 7, 7), **para)
     assert not q4.stem_pool_eligible((1, 3, 224, 224), (64, 3, 3, 3), **dict(para, pads=[1, 1, 1, 1]))
+    assert not q4.stem_pool_eligible((1, 3, 224, 224), (64, 3, 7, 7), **dict(para, strides=[1, 1]))
     with pytest.raises(NotImplementedError):
-        q4.ConvPoolQ4(pa.asarray(np.zeros((1, 3, 64, 64), np.float32)), Kq, **para)
+        q4.ConvPoolQ4(pa.asarray(np.zeros((1, 4, 64, 64), np.float32)), Kq, **para)
 
 
 def test_rowpack_stem_conv_matches_oracle(pa):
