@@ -25,7 +25,7 @@ void pl_set_error(const char *fmt, ...) {
 extern "C" {
 
 const char *pl_last_error(void) { return g_err.c_str(); }
-int pl_version(void) { return 300; }
+int pl_version(void) { return 500; }
 
 int pl_device_count(int *count) {
     PL_REQUIRE(count, PL_EINVAL, "pl_device_count: null out");

@@ -162,18 +162,20 @@ _side_perm = {}       # device -> [creation index of the stream side context i c
 
 
 def set_side_stream_perm(device, want):
-    """Side context i of `device` takes the stream that was CREATED as number want[i] (a permutation of range(len(want));
-    pl_ctx_swap_streams: pools, graphs and events stay with their contexts)."""
-    n = len(want)
-    side_context(device, n)
+    """Side context i (i < len(want)) of `device` takes the stream that was CREATED as number want[i]; the side contexts behind
+    them share out the remaining streams in creation order (pl_ctx_swap_streams: pools, graphs and events stay with their
+    contexts).  `want` holds distinct creation indices; the pool grows to cover the largest."""
+    want = [int(w) for w in want]
+    if len(set(want)) != len(want) or min(want, default=0) < 0:
+        raise ValueError("set_side_stream_perm: distinct creation indices expected, got %r" % (want,))
+    side_context(device, max(len(want), max(want, default=-1) + 1))
     pool = _side_pool[int(device)]
     cur = _side_perm.setdefault(int(device), [])
     cur.extend(range(len(cur), len(pool)))
-    if sorted(want) != list(range(n)) or sorted(cur[:n]) != list(range(n)):
-        raise ValueError("set_side_stream_perm: not a permutation of the first %d side streams: %r (current %r)" % (n, want, cur[:n]))
-    for i in range(n):
-        if cur[i] != want[i]:
-            j = cur.index(want[i])
+    full = want + [i for i in range(len(pool)) if i not in want]
+    for i in range(len(pool)):
+        if cur[i] != full[i]:
+            j = cur.index(full[i])
             _lib.call("pl_ctx_swap_streams", pool[i].handle, pool[j].handle)
             cur[i], cur[j] = cur[j], cur[i]
 

@@ -362,9 +362,10 @@ def fuse_conv1x1_wino_in(body, flow, kshape=lambda key: None, small=lambda key: 
         csrcs, cname, cdst = steps[j]
         _, ckind, cpara = kinds[cname]
         full = csrcs + ["None"] * (6 - len(csrcs))
+        if j >= i or j in drop or ckind != "conv_q4" or cpara.get("w_layout") != 2 or not isinstance(cdst, str) or full[5] != "None":
+            continue
         k = kshape(full[1])
-        if (j >= i or j in drop or ckind != "conv_q4" or cpara.get("w_layout") != 2 or not isinstance(cdst, str) or full[5] != "None"
-                or k is None or tuple(k[2:]) != (1, 1) or k[0] % 4 or int(cpara.get("group", 1)) != 1
+        if (k is None or tuple(k[2:]) != (1, 1) or k[0] % 4 or int(cpara.get("group", 1)) != 1
                 or [int(v) for v in cpara.get("strides", (1, 1))] != [1, 1] or [int(v) for v in cpara.get("dilations", (1, 1))] != [1, 1]
                 or any(int(v) for v in cpara.get("pads", (0, 0, 0, 0))) or int(cpara.get("act", 0)) & ~3 or not small(y)):
             continue

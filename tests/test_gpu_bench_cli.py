@@ -127,3 +127,25 @@ def test_throughput_plan_does_not_depend_on_stream_creation_order():
         with_probe, 100 * (max(with_probe) / min(with_probe) - 1), without, 100 * (max(without) / min(without) - 1)))
     assert min(with_probe) >= 0.97 * rates[("auto", 0)], with_probe
     assert min(with_probe) >= 0.97 * max(without), (with_probe, without)
+
+
+def test_cold_database_compile_lands_near_the_shipped_picks(tmp_path):
+    """A shape whose picks are NOT taken from the shipped database is tuned on first use (launch plans, conv algorithms, stream
+    plan).  ResNet-18 at batch 16, once with the database switched off and an empty user cache (everything measured in this
+    process: `tune_source` says so, the compile seconds are printed) and once from the shipped database (no measurement at all):
+    the cold compile's pipelined rate must be within 5 % of the tuned one."""
+    import subprocess
+    tool = os.path.join(ROOT, "tools", "tune_fill.py")
+    runs = {}
+    for tag, extra in (("cold", {"PLANER_HIP_TUNED": "0", "PLANER_HIP_TUNE_CACHE": str(tmp_path / "cold.plans")}), ("shipped", {})):
+        env = dict(os.environ, **extra)
+        env.pop("PLANER_HIP_STREAMS", None)
+        if tag == "shipped":
+            env.pop("PLANER_HIP_TUNE_CACHE", None)
+        r = subprocess.run([sys.executable, tool, "resnet18", "16"], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        runs[tag] = json.loads(r.stdout.strip().splitlines()[-1])
+        print(tag, runs[tag])
+    assert "autotuned" in runs["cold"]["tune_source"] and runs["shipped"]["tune_source"] == "shipped", runs
+    assert runs["cold"]["images_per_sec_pipelined"] >= 0.95 * runs["shipped"]["images_per_sec_pipelined"], runs
+    assert runs["cold"]["latency_ms"] <= 1.08 * runs["shipped"]["latency_ms"], runs

@@ -16,6 +16,12 @@ python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/fill_resnet18.jso
 python bench.py --workload yolov3 --steps 20 --warmup 5 > $out/fill_yolov3.json 2> $out/fill_yolov3.err
 python bench.py --workload conv2 --steps 20 --warmup 5 > $out/fill_conv2.json 2> $out/fill_conv2.err
 python tools/latency_bench.py > $out/fill_latency.log 2>&1
+# more shapes than the three BASELINE workloads: other batch sizes of ResNet-18, other resolutions of YOLO-v3 (latency and
+# throughput plan each; tools/tune_fill.py prints the cold compile time of each)
+: > $out/fill_more.jsonl
+for b in 1 8 16 64 256; do python tools/tune_fill.py resnet18 $b 2>>$out/fill_more.err | tail -1 >> $out/fill_more.jsonl; done
+for sz in 320 608; do python tools/tune_fill.py yolov3 1 $sz 2>>$out/fill_more.err | tail -1 >> $out/fill_more.jsonl; done
+cat $out/fill_more.jsonl
 # a second pass must find everything: its tune_source may not mention "autotuned"
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-e2e > $out/check_resnet18.json 2> $out/check_resnet18.err
 mv $out/$stem.plans.algo.json $out/$stem.algo.json
