@@ -112,6 +112,9 @@ def transform_bytes(prog, convs):
         tiles = c["n"] * cdiv(c["h"], 4) * cdiv(c["w"], 4)
         act_in, act_out = 4.0 * c["n"] * c["cin"] * c["h"] * c["w"], 4.0 * c["n"] * c["cout"] * c["ho"] * c["wo"]
         v_in, m_out = 4.0 * 36 * c["cin"] * tiles, 4.0 * 36 * c["cout"] * tiles
+        if obj.name.startswith("wino43"):            # mixed tiles: 121 frequency groups x (H / 7) (W / 7) tiles per image
+            cols = c["n"] * (c["h"] // 7) * (c["w"] // 7)
+            v_in, m_out = 4.0 * 121 * c["cin"] * cols, 4.0 * 121 * c["cout"] * cols
         if stage == "in":
             out[name] = act_in + v_in
         else:

@@ -258,6 +258,26 @@ int pl_wino4_chain_q4_f32(pl_ctx *ctx, const float *M, int N, int C, int H, int 
                           const float *scale, const float *shift, const float *resq, int act, double alpha,
                           float *yq, float *Vnext);
 
+/* Winograd with MIXED tiles for maps whose sides are 7, 14 or 21 pixels (csrc/wino43_kernels.h): a side of 7a is cut into a
+ * segments of 4 (F(4,3), 6 frequencies) and a segments of 3 (F(3,3), 5 frequencies), so no tile hangs over the map's edge --
+ * F(4x4,3x3) computes a 14x14 map as 16x16 and a 7x7 map as 8x8.  Four tile classes (6x6, 6x5, 5x6, 5x5 frequencies) with equally
+ * many tiles each: 121 per-frequency GEMMs of N a^2 columns, one grouped launch.  Same contract as the pl_wino4_* stages /
+ * pl_conv2d_winograd4_q4_f32 (3x3 / stride 1 / pad 1 / group 1, Cin and Cout multiples of 4, fused tail); V / M are
+ * [121][C/4][N (H/7) (W/7)][4]; replaces the same reference code (layer.py:22-26 -> util.py:17-44). */
+int pl_wino43_supported(int H, int W, int *ok);
+int pl_wino43_elems(int N, int C, int H, int W, size_t *elems);
+int pl_conv2d_winograd43_q4_filter_elems(int Cout, int Cin, size_t *elems);
+int pl_conv2d_prepare_winograd43_q4_f32(pl_ctx *ctx, const float *w, int Cout, int Cin, float *out);
+int pl_wino43_input_q4_f32(pl_ctx *ctx, const float *xq, int N, int C, int H, int W, float *V);
+int pl_wino43_gemm_q4_f32(pl_ctx *ctx, const float *V, int N, int Cin, int H, int W, const float *uq, int Cout, float *M);
+int pl_wino43_output_q4_f32(pl_ctx *ctx, const float *M, int N, int C, int H, int W, const float *bias, const float *scale,
+                            const float *shift, const float *resq, int act, double alpha, float *yq);
+int pl_wino43_chain_q4_f32(pl_ctx *ctx, const float *M, int N, int C, int H, int W, const float *bias, const float *scale,
+                           const float *shift, const float *resq, int act, double alpha, float *yq, float *Vnext);
+int pl_conv2d_winograd43_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const float *uq, int Cout,
+                                const float *bias, float *yq, const float *scale, const float *shift, const float *resq,
+                                int act, double alpha);
+
 /* A 1x1 / stride 1 / group 1 channel-quad convolution with its fused tail (bias, scale, shift, ReLU / LeakyReLU; no residual)
  * whose only reader is a staged Winograd 3x3 convolution: writes that conv's transformed input V straight away --
  * wino = 4: F(4x4,3x3), V as pl_wino4_input_q4_f32 makes it; wino = 2: F(2x2,3x3), [16][Cout/4][T][4] with 2x2 tiles.

@@ -85,6 +85,15 @@ SIGNATURES = {
     "pl_wino4_gemm_q4_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _P],
     "pl_wino4_output_q4_f32": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, c_double, _P],
     "pl_wino4_chain_q4_f32": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, c_double, _P, _P],
+    "pl_wino43_supported": [_I, _I, POINTER(c_int)],
+    "pl_wino43_elems": [_I, _I, _I, _I, POINTER(c_size_t)],
+    "pl_conv2d_winograd43_q4_filter_elems": [_I, _I, POINTER(c_size_t)],
+    "pl_conv2d_prepare_winograd43_q4_f32": [_P, _P, _I, _I, _P],
+    "pl_wino43_input_q4_f32": [_P, _P, _I, _I, _I, _I, _P],
+    "pl_wino43_gemm_q4_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _P],
+    "pl_wino43_output_q4_f32": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, c_double, _P],
+    "pl_wino43_chain_q4_f32": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, c_double, _P, _P],
+    "pl_conv2d_winograd43_q4_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, c_double],
     "pl_conv1x1_wino_in_q4_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, c_double, _I, _P],
     "pl_conv2d_rowpack_filter_elems": [_I, _I, _I, _I, POINTER(c_size_t)],
     "pl_conv2d_prepare_rowpack_f32": [_P, _P, _I, _I, _I, _I, _P],

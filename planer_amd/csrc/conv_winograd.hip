@@ -651,6 +651,7 @@ __global__ void __launch_bounds__(256) wino4_output_rows_q4_kernel(const float4 
 #include "wino4_chain_kernel.h"
 #include "wino4_gemm_as_kernel.h"
 #include "conv1x1_wino_in_kernel.h"
+#include "wino43_kernels.h"
 
 // ---- F(4x4,3x3) stage by stage.  winograd4_q4_launch below runs the three stages of ONE conv; the plan
 //      compiler (planer_amd/plan.py chain_winograd) calls the stages itself so that consecutive
@@ -775,6 +776,21 @@ int wino4_gemm_launch(pl_ctx *ctx, const float *V, const float *Uq, float *M, co
     // way, wino4_chain_launch): M and V are handed from kernel to kernel inside one XCD.  Honoured by run_plan when the launch
     // plan is one unsplit pass whose column tiles split evenly.
     ctx->xcd_cols_request = (pl_experiment("xcd", 0) && p.N % 8 == 0) ? (p.N / 8) * p.th * p.tw : 0;
+    // experiment mixed_tiles=1 (TIMING ONLY, results are garbage): the GEMM shape mixed F(4,3) x F(3,3) tiles would give maps of
+    // 14 or 7 pixels -- 121 frequency groups x a quarter of today's tile columns -- on scratch filters of the right size, to see what
+    // removing the tile padding would be worth inside the pipelined run before building the transforms (tools/mixed_tile_probe.py)
+    if (pl_experiment("mixed_tiles", 0) && (p.H == 14 || p.H == 7) && p.H == p.W) {
+        static std::map<std::pair<int, size_t>, float *> scratch;
+        const size_t elems = (size_t)121 * ((p.C / 4 + 7) / 8 * 8) * p.Cout * 4;
+        float *&u = scratch[{ctx->device, elems}];
+        if (!u && hipMalloc(&u, elems * sizeof(float)) == hipSuccess) (void)hipMemset(u, 0, elems * sizeof(float));
+        if (u) {
+            int rc = conv_launch(ctx, V, 1, 121 * p.C, p.N * p.th / 4, p.tw, u, 121 * p.Cout, 1, 1, nullptr, M, 1, 1, 1, 1, 0, 0, 0, 0, 121,
+                                 nullptr, nullptr, nullptr, PL_ACT_NONE, 0.0, 2);
+            ctx->last_plan = "wino4-mixed-probe[" + ctx->last_plan + "]";
+            return rc;
+        }
+    }
     int rc = conv_launch(ctx, V, 1, 36 * p.C, p.N * p.th, p.tw, Uq, 36 * p.Cout, 1, 1, nullptr, M, 1, 1, 1, 1, 0, 0, 0, 0, 36,
                          nullptr, nullptr, nullptr, PL_ACT_NONE, 0.0, 2);
     ctx->xcd_cols_request = 0;
@@ -824,6 +840,98 @@ int winograd4_q4_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int
     pl_free(ctx, M);
     pl_free(ctx, V);
     return rc;
+}
+
+// ---- mixed-tile Winograd (wino43_kernels.h): maps whose sides are 7, 14 or 21 ----
+bool wino43_side_ok(int d) { return d == 7 || d == 14 || d == 21; }
+int wino43_args(W43Args &a, int N, int C, int H, int W) {
+    PL_REQUIRE(wino43_side_ok(H) && wino43_side_ok(W), PL_EUNSUPPORTED, "mixed-tile winograd: map sides must be 7, 14 or 21 (got %d x %d)", H, W);
+    memset(&a, 0, sizeof a);
+    a.N = N; a.Cq = C / 4; a.H = H; a.W = W;
+    a.ar = H / 7; a.ac = W / 7; a.TC = a.ar * a.ac; a.T = N * a.TC;
+    const size_t vb = (size_t)W43_GROUPS * C * a.T * 4, xb = (size_t)N * C * H * W * 4;
+    PL_REQUIRE(vb < (1ull << 31) && xb < (1ull << 31), PL_EUNSUPPORTED, "mixed-tile winograd: tensor too large");
+    a.x_bytes = (unsigned)xb;
+    a.divCT = FastDiv((unsigned)(a.Cq * a.T)); a.divT = FastDiv((unsigned)a.T); a.divTC = FastDiv((unsigned)a.TC); a.divAc = FastDiv((unsigned)a.ac);
+    return PL_OK;
+}
+int wino43_lds_launch(pl_ctx *ctx, const float *M, const float *x, float *yq, float *V, int N, int C, int H, int W, const Epilogue &ep);
+int wino43_lds_mode();
+int wino43_input_launch(pl_ctx *ctx, const float *xq, float *V, int N, int C, int H, int W) {
+    if (wino43_lds_mode())
+        return wino43_lds_launch(ctx, nullptr, xq, nullptr, V, N, C, H, W, make_epilogue(nullptr, nullptr, nullptr, nullptr, PL_ACT_NONE, 0.0));
+    W43Args a;
+    int rc = wino43_args(a, N, C, H, W);
+    if (rc != PL_OK) return rc;
+    a.x = xq; a.V = V;
+    a.ep = make_epilogue(nullptr, nullptr, nullptr, nullptr, PL_ACT_NONE, 0.0);
+    const unsigned total = 4u * (unsigned)a.Cq * (unsigned)a.T * 4u;
+    const unsigned cap = (unsigned)(ctx->cu_count > 0 ? ctx->cu_count : 256) * 8;
+    wino43_input_q4_kernel<<<std::min(cap, (total + 255) / 256), 256, 0, ctx->stream>>>(a, total);
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
+int wino43_gemm_launch(pl_ctx *ctx, const float *V, const float *Uq, float *M, int N, int Cin, int H, int W, int Cout) {
+    PL_REQUIRE(wino43_side_ok(H) && wino43_side_ok(W), PL_EUNSUPPORTED, "mixed-tile winograd: map sides must be 7, 14 or 21");
+    const int ar = H / 7, ac = W / 7;
+    // 121 GEMMs of (Cout x Cin) . (Cin x N ar ac) as ONE grouped 1x1 conv; the tile axis is presented as an (N ar) x ac image
+    int rc = conv_launch(ctx, V, 1, W43_GROUPS * Cin, N * ar, ac, Uq, W43_GROUPS * Cout, 1, 1, nullptr, M, 1, 1, 1, 1, 0, 0, 0, 0, W43_GROUPS,
+                         nullptr, nullptr, nullptr, PL_ACT_NONE, 0.0, 2);
+    ctx->last_plan = "wino43[" + ctx->last_plan + "]";
+    return rc;
+}
+// the LDS kernel (whole planes per workgroup): M -> y and / or V (from_m), or x -> V
+int wino43_lds_launch(pl_ctx *ctx, const float *M, const float *x, float *yq, float *V, int N, int C, int H, int W, const Epilogue &ep) {
+    W43LdsArgs q;
+    int rc = wino43_args(q.a, N, C, H, W);
+    if (rc != PL_OK) return rc;
+    W43Args &a = q.a;
+    a.M = M; a.x = x; a.y = yq; a.V = V; a.ep = ep;
+    q.from_m = M != nullptr;
+    q.pcells = ((H + 2) * (W + 2) + 14) / 16 * 16 + 1;
+    // G quads per workgroup: the largest power of two that keeps the workgroup under 64 KB of LDS (two or more per CU), under
+    // ~700 row items and the grid at one workgroup per CU or more.  PLANER_HIP_WINO43_G forces.
+    static const char *g_env = getenv("PLANER_HIP_WINO43_G");
+    const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
+    // planes + the frequency slab (products, then the half-transformed patches) + tail parameters (wino43_lds_kernel's layout)
+    auto lds_of = [&](int g) { return ((size_t)g * q.pcells + (size_t)W43_GROUPS * g * a.TC + 3 * (size_t)g) * 16; };
+    int G = 1;
+    for (int g = 2; g <= a.Cq; g *= 2)
+        if (a.Cq % g == 0 && lds_of(g) <= 64 * 1024 && 22 * g * a.TC <= 704 && (long)N * (a.Cq / g) >= cus) G = g;
+    if (g_env && atoi(g_env) > 0 && a.Cq % atoi(g_env) == 0 && lds_of(atoi(g_env)) <= 150 * 1024) G = atoi(g_env);
+    PL_REQUIRE(lds_of(G) <= 150 * 1024, PL_EUNSUPPORTED, "mixed-tile winograd (LDS transforms): a plane does not fit");
+    a.G = G;
+    q.gt = G * a.TC;
+    q.divGt = FastDiv((unsigned)q.gt); q.div2Gt = FastDiv(2u * (unsigned)q.gt);
+    q.divPcells = FastDiv((unsigned)q.pcells); q.divPitch = FastDiv((unsigned)(W + 2));
+    q.divHW = FastDiv((unsigned)(H * W)); q.divW = FastDiv((unsigned)W);
+    const size_t lds = lds_of(G);
+    if (lds > 48 * 1024) {
+        rc = ensure_lds_attr((const void *)wino43_lds_kernel, 150 * 1024);
+        if (rc != PL_OK) return rc;
+    }
+    const int items = 22 * q.gt, bd = std::max(128, std::min(512, (items + 63) / 64 * 64));
+    hipLaunchKernelGGL(wino43_lds_kernel, dim3((unsigned)(a.Cq / G), (unsigned)N), dim3((unsigned)bd), lds, ctx->stream, q);
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
+// PLANER_HIP_WINO43_LDS: 0 = whole-tile register kernels for lone transforms (chains always take the LDS kernel), 1 = the LDS kernel
+// for lone transforms too
+int wino43_lds_mode() {
+    const char *e = getenv("PLANER_HIP_WINO43_LDS");
+    return e ? atoi(e) : 1;
+}
+int wino43_output_launch(pl_ctx *ctx, const float *M, float *yq, float *Vnext, int N, int C, int H, int W, const Epilogue &ep) {
+    if (Vnext || wino43_lds_mode()) return wino43_lds_launch(ctx, M, nullptr, yq, Vnext, N, C, H, W, ep);
+    W43Args a;
+    int rc = wino43_args(a, N, C, H, W);
+    if (rc != PL_OK) return rc;
+    a.M = M; a.y = yq; a.ep = ep;
+    const unsigned total = 4u * (unsigned)a.Cq * (unsigned)a.T;
+    const unsigned cap = (unsigned)(ctx->cu_count > 0 ? ctx->cu_count : 256) * 8;
+    wino43_output_q4_kernel<<<std::min(cap, (total + 255) / 256), 256, 0, ctx->stream>>>(a, total);
+    PL_LAUNCH_CHECK();
+    return PL_OK;
 }
 
 #include "conv_w1d_kernel.h"
@@ -1161,6 +1269,105 @@ int pl_conv1x1_wino_in_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int 
     ctx->last_gemm[0] = 1; ctx->last_gemm[1] = (long long)a.mtiles * 32;
     ctx->last_gemm[2] = (long long)N * a.rh * a.rw * 64; ctx->last_gemm[3] = (long long)a.Qpad * 4;
     return PL_OK;
+}
+
+// ---- mixed-tile Winograd, F(4,3) x F(3,3) segments (wino43_kernels.h): maps of 7 / 14 / 21 pixels a side ----
+int pl_wino43_supported(int H, int W, int *ok) {
+    PL_REQUIRE(ok, PL_EINVAL, "pl_wino43_supported: null argument");
+    *ok = wino43_side_ok(H) && wino43_side_ok(W);
+    return PL_OK;
+}
+int pl_wino43_elems(int N, int C, int H, int W, size_t *elems) {
+    PL_REQUIRE(elems && N >= 0 && C > 0 && C % 4 == 0 && wino43_side_ok(H) && wino43_side_ok(W), PL_EINVAL, "pl_wino43_elems: bad argument");
+    *elems = (size_t)W43_GROUPS * C * N * (H / 7) * (W / 7);
+    return PL_OK;
+}
+int pl_conv2d_winograd43_q4_filter_elems(int Cout, int Cin, size_t *elems) {
+    PL_REQUIRE(elems && Cout > 0 && Cin > 0, PL_EINVAL, "pl_conv2d_winograd43_q4_filter_elems: bad argument");
+    *elems = (size_t)W43_GROUPS * (((size_t)Cin / 4 + 7) / 8 * 8) * Cout * 4;
+    return PL_OK;
+}
+int pl_conv2d_prepare_winograd43_q4_f32(pl_ctx *ctx, const float *w, int Cout, int Cin, float *out) {
+    PL_REQUIRE(ctx && w && out, PL_EINVAL, "pl_conv2d_prepare_winograd43_q4_f32: null pointer");
+    PL_REQUIRE(Cout > 0 && Cin > 0 && Cin % 4 == 0 && Cout % 4 == 0, PL_EINVAL, "mixed-tile winograd filters need Cin %% 4 == 0 and Cout %% 4 == 0");
+    const size_t pairs = (size_t)Cout * Cin;
+    size_t elems = 0;
+    pl_conv2d_winograd43_q4_filter_elems(Cout, Cin, &elems);
+    PL_REQUIRE(elems < (1ull << 29), PL_EUNSUPPORTED, "filter too large");
+    CtxGuard g(ctx);
+    PL_HIP(hipMemsetAsync(out, 0, elems * sizeof(float), ctx->stream));
+    wino43_filter_q4_kernel<<<(unsigned)((pairs + 255) / 256), 256, 0, ctx->stream>>>(w, out, (unsigned)pairs, Cin, Cout, (Cin / 4 + 7) / 8 * 8);
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
+static int wino43_check(const char *fn, pl_ctx *ctx, int N, int C, int H, int W, const void *a, const void *b, const void *c, const void *d) {
+    int rc = wino4_stage_check(fn, ctx, N, C, H, W, a, b, c, d);
+    if (rc != PL_OK) return rc;
+    PL_REQUIRE(wino43_side_ok(H) && wino43_side_ok(W), PL_EUNSUPPORTED, "%s: map sides must be 7, 14 or 21", fn);
+    return PL_OK;
+}
+int pl_wino43_input_q4_f32(pl_ctx *ctx, const float *xq, int N, int C, int H, int W, float *V) {
+    int rc = wino43_check("pl_wino43_input_q4_f32", ctx, N, C, H, W, xq, V, nullptr, nullptr);
+    if (rc != PL_OK) return rc;
+    PL_REQUIRE(xq && V, PL_EINVAL, "pl_wino43_input_q4_f32: null pointer");
+    if (N == 0) return PL_OK;
+    CtxGuard guard(ctx);
+    return wino43_input_launch(ctx, xq, V, N, C, H, W);
+}
+int pl_wino43_gemm_q4_f32(pl_ctx *ctx, const float *V, int N, int Cin, int H, int W, const float *uq, int Cout, float *M) {
+    int rc = wino43_check("pl_wino43_gemm_q4_f32", ctx, N, Cin, H, W, V, uq, M, nullptr);
+    if (rc != PL_OK) return rc;
+    PL_REQUIRE(V && uq && M && Cout > 0 && Cout % 4 == 0, PL_EINVAL, "pl_wino43_gemm_q4_f32: bad argument");
+    if (N == 0) return PL_OK;
+    CtxGuard guard(ctx);
+    return wino43_gemm_launch(ctx, V, uq, M, N, Cin, H, W, Cout);
+}
+int pl_wino43_output_q4_f32(pl_ctx *ctx, const float *M, int N, int C, int H, int W, const float *bias, const float *scale,
+                            const float *shift, const float *resq, int act, double alpha, float *yq) {
+    int rc = wino43_check("pl_wino43_output_q4_f32", ctx, N, C, H, W, M, yq, resq, nullptr);
+    if (rc != PL_OK) return rc;
+    PL_REQUIRE(M && yq, PL_EINVAL, "pl_wino43_output_q4_f32: null pointer");
+    PL_REQUIRE(act >= 0 && (act & 15) <= 2 && (act & ~31) == 0, PL_EINVAL, "pl_wino43_output_q4_f32: bad activation code");
+    if (N == 0) return PL_OK;
+    CtxGuard guard(ctx);
+    return wino43_output_launch(ctx, M, yq, nullptr, N, C, H, W, make_epilogue(bias, scale, shift, resq, act, alpha));
+}
+int pl_wino43_chain_q4_f32(pl_ctx *ctx, const float *M, int N, int C, int H, int W, const float *bias, const float *scale,
+                           const float *shift, const float *resq, int act, double alpha, float *yq, float *Vnext) {
+    int rc = wino43_check("pl_wino43_chain_q4_f32", ctx, N, C, H, W, M, yq, resq, Vnext);
+    if (rc != PL_OK) return rc;
+    PL_REQUIRE(M && Vnext, PL_EINVAL, "pl_wino43_chain_q4_f32: null pointer");
+    PL_REQUIRE(act >= 0 && (act & 15) <= 2 && (act & ~31) == 0, PL_EINVAL, "pl_wino43_chain_q4_f32: bad activation code");
+    if (N == 0) return PL_OK;
+    CtxGuard guard(ctx);
+    return wino43_output_launch(ctx, M, yq, Vnext, N, C, H, W, make_epilogue(bias, scale, shift, resq, act, alpha));
+}
+int pl_conv2d_winograd43_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const float *uq, int Cout,
+                                const float *bias, float *yq, const float *scale, const float *shift, const float *resq,
+                                int act, double alpha) {
+    int rc = wino43_check("pl_conv2d_winograd43_q4_f32", ctx, N, Cin, H, W, xq, uq, yq, resq);
+    if (rc != PL_OK) return rc;
+    PL_REQUIRE(xq && uq && yq && Cout > 0 && Cout % 4 == 0, PL_EINVAL, "pl_conv2d_winograd43_q4_f32: bad argument");
+    PL_REQUIRE(act >= 0 && (act & 15) <= 2 && (act & ~31) == 0, PL_EINVAL, "pl_conv2d_winograd43_q4_f32: bad activation code");
+    if (N == 0) return PL_OK;
+    CtxGuard guard(ctx);
+    size_t vin = 0, vout = 0;
+    pl_wino43_elems(N, Cin, H, W, &vin);
+    pl_wino43_elems(N, Cout, H, W, &vout);
+    float *V = nullptr, *M = nullptr;
+    rc = pl_alloc(ctx, vin * sizeof(float), (void **)&V);
+    if (rc != PL_OK) return rc;
+    rc = pl_alloc(ctx, vout * sizeof(float), (void **)&M);
+    if (rc != PL_OK) {
+        pl_free(ctx, V);
+        return rc;
+    }
+    rc = wino43_input_launch(ctx, xq, V, N, Cin, H, W);
+    if (rc == PL_OK) rc = wino43_gemm_launch(ctx, V, uq, M, N, Cin, H, W, Cout);
+    if (rc == PL_OK) rc = wino43_output_launch(ctx, M, yq, nullptr, N, Cout, H, W, make_epilogue(bias, scale, shift, resq, act, alpha));
+    pl_free(ctx, M);
+    pl_free(ctx, V);
+    return rc;
 }
 
 int pl_conv2d_winograd_q4_filter_elems(int Cout, int Cin, size_t *elems) {

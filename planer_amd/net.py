@@ -39,7 +39,8 @@ W_LAYOUT_NAMES = {0: "igemm-nchw", 1: "tap-nchw", 2: "direct-q4 (conv_q4_kernel)
                   4: "wino2x2-q4 (transforms + grouped conv_q4_kernel)",
                   6: "rowpack-q4 (nchw_to_rowpack + conv_q4_kernel)",
                   7: "wino4x4-q4 (transforms + grouped conv_q4_kernel)", 8: "w1d4 F(4,3) (conv_w1d4_kernel)",
-                  9: "wf4 fused F(4x4,3x3) (conv_wf4_kernel)", 10: "stem + maxpool (conv_stem_pool_kernel)"}
+                  9: "wf4 fused F(4x4,3x3) (conv_wf4_kernel)", 10: "stem + maxpool (conv_stem_pool_kernel)",
+                  11: "wino43-q4 (mixed F(4,3) x F(3,3) tiles: transforms + 121 grouped conv_q4_kernel)"}
 
 
 def _as_list(v):
@@ -398,12 +399,12 @@ class Net:
                     val = obj(*args)
                 if profile:                                  # ONE marker per step boundary: step time = marker to marker
                     events.append((name, obj.name, hip.Event(self.ctx).record()))
-                if record is not None and obj.name in ("conv", "conv_fused", "conv_q4", "dense", "matmul", "wino4_gemm", "conv_q4_pair",
-                                                       "conv_pool_q4", "conv1x1_wino_in"):
+                if record is not None and obj.name in ("conv", "conv_fused", "conv_q4", "dense", "matmul", "wino4_gemm", "wino43_gemm",
+                                                       "conv_q4_pair", "conv_pool_q4", "conv1x1_wino_in"):
                     lay = obj.para().get("w_layout", 2 if obj.name in ("conv_q4_pair", "conv1x1_wino_in") else 0) if obj.name != "conv" else 0
                     lname = name
-                    if obj.name == "wino4_gemm":               # the GEMM stage of a staged F(4x4,3x3) conv
-                        lay, lname = 7, name[:-len("@gemm")]
+                    if obj.name in ("wino4_gemm", "wino43_gemm"):       # the GEMM stage of a staged Winograd conv
+                        lay, lname = (7 if obj.name == "wino4_gemm" else 11), name[:-len("@gemm")]
                     ctx_ = args[0].ctx if isinstance(args[0], DeviceArray) else self.ctx
                     xshape = (args[0].meta if args[0].meta is not None else
                               _q4.logical_shape(args[0]) if _q4.is_q4(args[0]) else args[0].shape)
@@ -485,15 +486,16 @@ class Net:
                 elif (use_wino and _q4.w1d_q4_eligible(K.shape, **para)
                         and shapes.get(srcs[0].split("@")[0]) is not None):
                     lay = self._pick_conv_algo(_q4.ConvQ4, K, srcs, entry[2], shapes, wmap, q4=True)
-                key = {2: "%s@q4g%d" % (srcs[1], group), 4: srcs[1] + "@winoq4",
-                       6: srcs[1] + "@rowpack", 7: srcs[1] + "@wino4q4", 8: srcs[1] + "@w1d4q4", 9: srcs[1] + "@wf4q4"}[lay]
+                key = {2: "%s@q4g%d" % (srcs[1], group), 4: srcs[1] + "@winoq4", 6: srcs[1] + "@rowpack", 7: srcs[1] + "@wino4q4",
+                       8: srcs[1] + "@w1d4q4", 9: srcs[1] + "@wf4q4", 11: srcs[1] + "@wino43q4"}[lay]
                 if key not in self._extra:
                     self._extra[key] = {2: lambda: _q4.prepare_q4_weights(K, group),
                                         4: lambda: _q4.prepare_winograd_q4_weights(K),
                                         6: lambda: _q4.prepare_rowpack_weights(K),
                                         7: lambda: _q4.prepare_winograd4_q4_weights(K),
                                         8: lambda: _q4.prepare_w1d4_q4_weights(K),
-                                        9: lambda: _q4.prepare_wf4_q4_weights(K)}[lay]()
+                                        9: lambda: _q4.prepare_wf4_q4_weights(K),
+                                        11: lambda: _q4.prepare_winograd43_q4_weights(K)}[lay]()
                 srcs[1] = key
                 out_body[name] = [name, "conv_q4", dict(entry[2], w_layout=lay)]
             elif entry[1] in ("conv", "conv_fused") and len(srcs) >= 2 and srcs[1] in wmap:
@@ -615,6 +617,9 @@ class Net:
                     cands.append((7, _q4.prepare_winograd4_q4_weights))      # F(4x4,3x3), staged
                 if os.environ.get("PLANER_HIP_WF4", "1") != "0":
                     cands.append((9, _q4.prepare_wf4_q4_weights))            # F(4x4,3x3), one fused kernel
+                if os.environ.get("PLANER_HIP_WINOGRAD43", "1") != "0" and _q4.winograd43_eligible(xs, K.shape, 64, **{
+                        k: v for k, v in para.items() if k in ("group", "strides", "dilations", "pads")}):
+                    cands.append((11, _q4.prepare_winograd43_q4_weights))    # mixed F(4,3) x F(3,3) tiles, staged
         if self.force_algo is not None:
             if self.force_algo not in [c[0] for c in cands]:
                 raise ValueError("force_algo=%r does not apply to conv %s k%s" % (self.force_algo, xs, tuple(K.shape)))

@@ -281,10 +281,13 @@ def assign_layouts(body, flow, init_names, shapes, force=False):
 # when nothing else reads y it is never written at all.  `chain_winograd` makes the stages explicit plan
 # steps and merges the out / in pairs.  Kinds that only read their inputs (no in-place update): a
 # Winograd input transform may be hoisted over them.
-_PURE_READERS = ("conv_q4", "wino4_in", "wino4_gemm", "wino4_out", "wino4_chain", "add_q4", "maxpool_q4",
+_PURE_READERS = ("conv_q4", "wino4_in", "wino4_gemm", "wino4_out", "wino4_chain", "wino43_in", "wino43_gemm", "wino43_out",
+                 "wino43_chain", "conv1x1_wino_in", "conv_q4_pair", "add_q4", "maxpool_q4",
                  "averagepool_q4", "gap_q4", "upsample_q4", "concat_q4", "upconcat_q4", "batchnorm_q4",
                  "leakyrelu_q4", "sigmoid_q4", "from_q4")
 WINO4_LAYOUT = 7
+# w_layout -> stage-kind prefix: staged F(4x4,3x3), and the mixed-tile form for maps of 7 / 14 / 21 a side (q4.Wino43*)
+STAGED_LAYOUTS = {7: "wino4", 11: "wino43"}
 
 
 def chain_winograd(body, flow, supported=lambda key: True, chain=True):
@@ -297,12 +300,13 @@ def chain_winograd(body, flow, supported=lambda key: True, chain=True):
         name = names[0] if isinstance(names, (list, tuple)) else names
         srcs = list(src) if isinstance(src, (list, tuple)) else [src]
         _, kind, para = kinds[name]
-        if kind == "conv_q4" and para.get("w_layout") == WINO4_LAYOUT and isinstance(dst, str):
+        if kind == "conv_q4" and para.get("w_layout") in STAGED_LAYOUTS and isinstance(dst, str):
             full = srcs + ["None"] * (6 - len(srcs))
             tail = {k: para[k] for k in ("act", "alpha") if k in para}
-            steps.append([[full[0]], name + "@in", "wino4_in", {}, name + "@V"])
-            steps.append([[name + "@V", full[1]], name + "@gemm", "wino4_gemm", {}, name + "@M"])
-            steps.append([[name + "@M"] + full[2:6], name + "@out", "wino4_out", tail, dst])
+            pre = STAGED_LAYOUTS[para["w_layout"]]
+            steps.append([[full[0]], name + "@in", pre + "_in", {}, name + "@V"])
+            steps.append([[name + "@V", full[1]], name + "@gemm", pre + "_gemm", {}, name + "@M"])
+            steps.append([[name + "@M"] + full[2:6], name + "@out", pre + "_out", tail, dst])
         else:
             steps.append([srcs, name, kind, para, dst])
     nchained = 0
@@ -311,18 +315,19 @@ def chain_winograd(body, flow, supported=lambda key: True, chain=True):
         i = 0
         while i < len(steps):
             srcs, name, kind, para, dst = steps[i]
-            if kind == "wino4_out" and supported(dst):
+            if kind in ("wino4_out", "wino43_out") and (kind == "wino43_out" or supported(dst)):
+                pre = kind[:-len("_out")]
                 readers = [j for j in range(i + 1, len(steps)) if dst in steps[j][0]]
                 # overwritten later under the same key?  then only readers before that point count
                 rewrite = [j for j in range(i + 1, len(steps)) if dst in _as_list(steps[j][4])]
                 stop = rewrite[0] if rewrite else len(steps)
                 readers = [j for j in readers if j <= stop]
-                j = next((j for j in readers if steps[j][2] == "wino4_in" and steps[j][0] == [dst]), None)
+                j = next((j for j in readers if steps[j][2] == pre + "_in" and steps[j][0] == [dst]), None)
                 if j is not None and all(steps[k][2] in _PURE_READERS for k in readers if k < j):
                     vkey = steps[j][4]
                     keep = len(readers) > 1 or dst in last_dsts
                     base = name[:-len("@out")]
-                    steps[i] = [srcs, base + "@chain", "wino4_chain", dict(para, keep_y=keep), [dst, vkey] if keep else vkey]
+                    steps[i] = [srcs, base + "@chain", pre + "_chain", dict(para, keep_y=keep), [dst, vkey] if keep else vkey]
                     del steps[j]
                     nchained += 1
             i += 1

@@ -111,6 +111,30 @@ def prepare_winograd4_q4_weights(K):
     return out
 
 
+def winograd43_eligible(x_shape, k_shape, min_columns=0, **para):
+    """Mixed-tile Winograd (csrc/wino43_kernels.h): a 3x3 / stride 1 / pad 1 / group 1 conv on a map whose sides are 7, 14 or 21.
+    `min_columns`: the plan compiler only offers it where each of the 121 per-frequency GEMMs has that many tile columns
+    (N * (H / 7) * (W / 7)): its filters are 3.4x those of F(4x4,3x3), and with few columns per filter the GEMM lives on filter
+    bandwidth -- ResNet-18's layer4 at batch 32 (32 columns, 127 MB of filters per conv) wins 4 us per conv in isolation and
+    loses 2 % of the pipelined rate, layer3 (128 columns) wins both ways."""
+    return (len(x_shape) == 4 and x_shape[2] in (7, 14, 21) and x_shape[3] in (7, 14, 21) and winograd_q4_eligible(k_shape, **para)
+            and x_shape[0] * (x_shape[2] // 7) * (x_shape[3] // 7) >= min_columns)
+
+
+def prepare_winograd43_q4_weights(K):
+    """OIHW 3x3 filters -> mixed-tile Winograd filters [121][k-quad][Cout][4] (ConvQ4 w_layout=11)."""
+    _f32(K)
+    cout, cin, kh, kw = K.shape
+    if (kh, kw) != (3, 3) or cin % 4 or cout % 4:
+        raise ValueError("winograd Q4 filters need 3x3 kernels, Cin % 4 == 0 and Cout % 4 == 0")
+    n = ctypes.c_size_t()
+    _lib.call("pl_conv2d_winograd43_q4_filter_elems", cout, cin, ctypes.byref(n))
+    out = empty((n.value,), ctx=K.ctx)
+    _lib.call("pl_conv2d_prepare_winograd43_q4_f32", K.ctx.handle, K.ptr, cout, cin, out.ptr)
+    out.shape = K.shape
+    return out
+
+
 def prepare_wf4_q4_weights(K):
     """OIHW 3x3 filters -> fully fused F(4x4,3x3) filters [Cout/64][Cin/4][36][4][4][16] (ConvQ4 w_layout=9)."""
     _f32(K)
@@ -229,12 +253,15 @@ def ConvQ4(xq, Kq, B=None, scale=None, shift=None, resq=None, group=1, strides=(
         _lib.call("pl_conv2d_w1d4_q4_f32", xq.ctx.handle, xq.ptr, n, cin, h, w, Kq.ptr, cout, _ptr(B), y.ptr,
                   _ptr(scale), _ptr(shift), _ptr(resq), int(act), float(alpha))
         return y
-    if w_layout in (4, 7, 9):
+    if w_layout == 11 and (h not in (7, 14, 21) or w not in (7, 14, 21)):
+        raise ValueError("mixed-tile winograd filters serve maps whose sides are 7, 14 or 21")
+    if w_layout in (4, 7, 9, 11):
         if not winograd_q4_eligible(Kq.shape, group, strides, dilations, pads):
             raise ValueError("winograd Q4 filters serve 3x3 / stride 1 / pad 1 / group 1 convs only")
         if w_layout == 9 and any(a is not None and a.ptr % 16 for a in (B, scale, shift)):
             raise ValueError("the fused F(4x4,3x3) kernel reads bias / scale / shift as 16-byte quads: misaligned parameter")
-        _lib.call({4: "pl_conv2d_winograd_q4_f32", 7: "pl_conv2d_winograd4_q4_f32", 9: "pl_conv2d_wf4_q4_f32"}[w_layout], xq.ctx.handle, xq.ptr, n, cin, h, w, Kq.ptr, cout, _ptr(B), y.ptr,
+        _lib.call({4: "pl_conv2d_winograd_q4_f32", 7: "pl_conv2d_winograd4_q4_f32", 9: "pl_conv2d_wf4_q4_f32",
+                   11: "pl_conv2d_winograd43_q4_f32"}[w_layout], xq.ctx.handle, xq.ptr, n, cin, h, w, Kq.ptr, cout, _ptr(B), y.ptr,
                   _ptr(scale), _ptr(shift), _ptr(resq), int(act), float(alpha))
         return y
     _lib.call("pl_conv2d_q4_f32", xq.ctx.handle, xq.ptr, n, cin, h, w, Kq.ptr, cout, kh, kw,
@@ -376,6 +403,54 @@ def Wino4Chain(m, B=None, scale=None, shift=None, resq=None, act=ACT_NONE, alpha
     y = _new_q4(n, c, h, w, m.ctx) if keep_y else None
     v = _wino_tensor(n, c, h, w, m.ctx)
     _lib.call("pl_wino4_chain_q4_f32", m.ctx.handle, m.ptr, n, c, h, w, _ptr(B), _ptr(scale), _ptr(shift), _ptr(resq),
+              int(act), float(alpha), _ptr(y), v.ptr)
+    return (y, v) if keep_y else v
+
+
+# ---- mixed-tile Winograd (maps of 7 / 14 / 21 a side) stage by stage: the same four stages, other kernels ----
+def _wino43_tensor(n, c, h, w, ctx):
+    e = ctypes.c_size_t()
+    _lib.call("pl_wino43_elems", n, c, h, w, ctypes.byref(e))
+    t = empty((max(e.value, 1),), ctx=ctx)
+    t.meta = (n, c, h, w)
+    return t
+
+
+def Wino43In(xq):
+    _f32(xq)
+    if not is_q4(xq):
+        raise TypeError("Wino43In needs a Q4 activation")
+    n, c, h, w = logical_shape(xq)
+    v = _wino43_tensor(n, c, h, w, xq.ctx)
+    _lib.call("pl_wino43_input_q4_f32", xq.ctx.handle, xq.ptr, n, c, h, w, v.ptr)
+    return v
+
+
+def Wino43Gemm(v, Kq, **_):
+    n, cin, h, w = v.meta
+    cout, cin_k, kh, kw = Kq.shape
+    if cin_k != cin or (kh, kw) != (3, 3):
+        raise ValueError("conv: weight %s does not match input %s" % (Kq.shape, (n, cin, h, w)))
+    m = _wino43_tensor(n, cout, h, w, v.ctx)
+    _lib.call("pl_wino43_gemm_q4_f32", v.ctx.handle, v.ptr, n, cin, h, w, Kq.ptr, cout, m.ptr)
+    return m
+
+
+def Wino43Out(m, B=None, scale=None, shift=None, resq=None, act=ACT_NONE, alpha=0.0, **_):
+    _f32(B, scale, shift, resq)
+    n, c, h, w = _wino_tail_check(m, resq)
+    y = _new_q4(n, c, h, w, m.ctx)
+    _lib.call("pl_wino43_output_q4_f32", m.ctx.handle, m.ptr, n, c, h, w, _ptr(B), _ptr(scale), _ptr(shift), _ptr(resq),
+              int(act), float(alpha), y.ptr)
+    return y
+
+
+def Wino43Chain(m, B=None, scale=None, shift=None, resq=None, act=ACT_NONE, alpha=0.0, keep_y=True, **_):
+    _f32(B, scale, shift, resq)
+    n, c, h, w = _wino_tail_check(m, resq)
+    y = _new_q4(n, c, h, w, m.ctx) if keep_y else None
+    v = _wino43_tensor(n, c, h, w, m.ctx)
+    _lib.call("pl_wino43_chain_q4_f32", m.ctx.handle, m.ptr, n, c, h, w, _ptr(B), _ptr(scale), _ptr(shift), _ptr(resq),
               int(act), float(alpha), _ptr(y), v.ptr)
     return (y, v) if keep_y else v
 
@@ -543,5 +618,6 @@ def register(layer_map):
     """Plan-internal kinds (never present in a user's IR)."""
     layer_map.update({"to_q4": to_q4, "from_q4": from_q4, "conv_q4": ConvQ4, "upconcat_q4": UpConcatQ4,
                       "wino4_in": Wino4In, "wino4_gemm": Wino4Gemm, "wino4_out": Wino4Out, "wino4_chain": Wino4Chain,
-                      "conv_q4_pair": ConvQ4Pair, "conv_pool_q4": ConvPoolQ4, "conv1x1_wino_in": Conv1x1WinoIn})
+                      "conv_q4_pair": ConvQ4Pair, "conv_pool_q4": ConvPoolQ4, "conv1x1_wino_in": Conv1x1WinoIn,
+                      "wino43_in": Wino43In, "wino43_gemm": Wino43Gemm, "wino43_out": Wino43Out, "wino43_chain": Wino43Chain})
     layer_map.update({k + "_q4": f for k, f in Q4_LAYERS.items()})
