@@ -1614,13 +1614,13 @@ int pl_conv2d_rowpacked_pool_q4_f32(pl_ctx *ctx, const float *xp, int N, int Cin
     PL_REQUIRE(blocks < (1ll << 31), PL_EUNSUPPORTED, "conv + maxpool (row-packed stem): grid too large");
     void (*kern)(const StemPoolArgs) = nullptr;
     switch (nb) {
-    case 1: kern = conv_stem_pool_kernel<1>; break;
-    case 2: kern = conv_stem_pool_kernel<2>; break;
-    case 3: kern = conv_stem_pool_kernel<3>; break;
-    case 4: kern = conv_stem_pool_kernel<4>; break;
-    case 5: kern = conv_stem_pool_kernel<5>; break;
-    case 6: kern = conv_stem_pool_kernel<6>; break;
-    default: kern = conv_stem_pool_kernel<7>; break;
+    case 1: kern = conv_stem_pool_kernel<1, false>; break;
+    case 2: kern = conv_stem_pool_kernel<2, false>; break;
+    case 3: kern = conv_stem_pool_kernel<3, false>; break;
+    case 4: kern = conv_stem_pool_kernel<4, false>; break;
+    case 5: kern = conv_stem_pool_kernel<5, false>; break;
+    case 6: kern = conv_stem_pool_kernel<6, false>; break;
+    default: kern = conv_stem_pool_kernel<7, false>; break;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), 0, ctx->stream, a);
     PL_LAUNCH_CHECK();
@@ -1628,6 +1628,84 @@ int pl_conv2d_rowpacked_pool_q4_f32(pl_ctx *ctx, const float *xp, int N, int Cin
     snprintf(buf, sizeof buf, "stem+maxpool 64co x 2 rows x %dpx, strips=%d chunks=%d blocks=%lld", 16 * nb, a.strips, a.chunks, blocks);
     ctx->last_plan = buf;
     // executed MFMA work: 16 conv rows per strip, 16 nb columns per chunk, K = 176
+    ctx->last_gemm[0] = 1; ctx->last_gemm[1] = (long long)a.cout_blocks * 64;
+    ctx->last_gemm[2] = (long long)N * a.strips * a.chunks * 16 * 16 * nb; ctx->last_gemm[3] = 16 * SP_GROUPS;
+    return PL_OK;
+}
+
+// The same kernel reading the NCHW input itself (conv_stem_pool_kernel<NB, true>): no row-packed copy of the batch.  Needs whole
+// 16-byte cells per input row: W % 4 == 0 and a 16-byte aligned tensor.
+int pl_conv2d_stem_pool_nchw_supported(int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw, int pt, int pl, int *ok) {
+    PL_REQUIRE(ok, PL_EINVAL, "pl_conv2d_stem_pool_nchw_supported: null argument");
+    *ok = (stem_pool_shape_ok(Cin, H, W, Cout, kh, kw, sh, sw, pt, pl) && W % 4 == 0) ? 1 : 0;
+    return PL_OK;
+}
+
+int pl_conv2d_stem_nchw_filter_elems(int Cout, size_t *elems) {
+    PL_REQUIRE(elems && Cout > 0, PL_EINVAL, "pl_conv2d_stem_nchw_filter_elems: bad argument");
+    *elems = (size_t)((4 * SP_GROUPS + 7) / 8 * 8) * Cout * 4;
+    return PL_OK;
+}
+
+int pl_conv2d_prepare_stem_nchw_f32(pl_ctx *ctx, const float *w, int Cout, float *out) {
+    PL_REQUIRE(ctx && w && out, PL_EINVAL, "pl_conv2d_prepare_stem_nchw_f32: null pointer");
+    PL_REQUIRE(Cout > 0, PL_EINVAL, "pl_conv2d_prepare_stem_nchw_f32: bad shape");
+    PL_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15u) == 0, PL_EINVAL, "pl_conv2d_prepare_stem_nchw_f32: unaligned output");
+    const int q_pad = (4 * SP_GROUPS + 7) / 8 * 8;
+    const size_t total = (size_t)q_pad * Cout;
+    PL_REQUIRE(total * 16 < (1ull << 29), PL_EUNSUPPORTED, "filter too large");
+    CtxGuard g(ctx);
+    pack_filter_stem_nchw_kernel<<<(unsigned)((total + 255) / 256), 256, 0, ctx->stream>>>(w, reinterpret_cast<float4 *>(out), (unsigned)total, Cout);
+    PL_LAUNCH_CHECK();
+    return PL_OK;
+}
+
+int pl_conv2d_stem_pool_nchw_q4_f32(pl_ctx *ctx, const float *x, int N, int H, int W, const float *wq, int Cout, const float *bias,
+                                    float *yq, const float *scale, const float *shift, int act, double alpha) {
+    const int Cin = 3, kh = SP_KH, kw = 7, sh = 2, sw = 2, pt = 3, pl = 3;
+    int rc = rowpack_check(ctx, x, N, Cin, H, W, wq, Cout, kh, kw, yq, sh, sw, pt, pl, nullptr);
+    if (rc != PL_OK) return rc;
+    PL_REQUIRE(stem_pool_shape_ok(Cin, H, W, Cout, kh, kw, sh, sw, pt, pl) && W % 4 == 0, PL_EUNSUPPORTED,
+               "conv + maxpool (NCHW stem): 3 channels, 7x7 / stride 2 / pad 3, W %% 4 == 0, Cout %% 4 == 0");
+    PL_REQUIRE(act >= 0 && act <= 2, PL_EINVAL, "pl_conv2d_stem_pool_nchw_q4_f32: bad activation code");
+    PL_REQUIRE(((reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift) |
+                 reinterpret_cast<uintptr_t>(x)) & 15u) == 0,
+               PL_EINVAL, "pl_conv2d_stem_pool_nchw_q4_f32: x / bias / scale / shift are read as 16-byte quads");
+    if (N == 0) return PL_OK;
+    CtxGuard guard(ctx);
+    StemPoolArgs a;
+    memset(&a, 0, sizeof a);
+    a.xp = x; a.wq = wq; a.y = yq;
+    a.N = N; a.H = H; a.W = W;
+    a.Ho = (H + 2 * pt - kh + sh) / sh; a.Wo = (W + 2 * pl - kw + sw) / sw;
+    a.Hq = (a.Ho + 1) / 2; a.Wq = (a.Wo + 1) / 2;            // (Ho + 2 - 3 + 2) // 2, util.py:84-85
+    a.Cout = Cout; a.Coq = Cout / 4;
+    a.strips = (a.Hq + SP_PROWS - 1) / SP_PROWS;
+    a.cout_blocks = (Cout + 63) / 64;
+    const int q_pad = (4 * SP_GROUPS + 7) / 8 * 8;
+    const size_t xb = (size_t)N * Cin * H * W * 4, yb = (size_t)N * a.Coq * a.Hq * a.Wq * 16;
+    int nb = 0;
+    stem_pool_chunks(a.Wo, a.chunks, a.pq, nb);
+    PL_REQUIRE(a.chunks > 0 && xb < (1ull << 31) && yb < (1ull << 31), PL_EUNSUPPORTED, "conv + maxpool (NCHW stem): tensor too large");
+    a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)((size_t)q_pad * Cout * 16); a.y_bytes = (unsigned)yb;
+    a.ep = make_epilogue(bias, scale, shift, nullptr, act, alpha);
+    const long long blocks = (long long)N * a.strips * a.chunks * a.cout_blocks;
+    PL_REQUIRE(blocks < (1ll << 31), PL_EUNSUPPORTED, "conv + maxpool (NCHW stem): grid too large");
+    void (*kern)(const StemPoolArgs) = nullptr;
+    switch (nb) {
+    case 1: kern = conv_stem_pool_kernel<1, true>; break;
+    case 2: kern = conv_stem_pool_kernel<2, true>; break;
+    case 3: kern = conv_stem_pool_kernel<3, true>; break;
+    case 4: kern = conv_stem_pool_kernel<4, true>; break;
+    case 5: kern = conv_stem_pool_kernel<5, true>; break;
+    case 6: kern = conv_stem_pool_kernel<6, true>; break;
+    default: kern = conv_stem_pool_kernel<7, true>; break;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), 0, ctx->stream, a);
+    PL_LAUNCH_CHECK();
+    char buf[112];
+    snprintf(buf, sizeof buf, "stem+maxpool(nchw) 64co x 2 rows x %dpx, strips=%d chunks=%d blocks=%lld", 16 * nb, a.strips, a.chunks, blocks);
+    ctx->last_plan = buf;
     ctx->last_gemm[0] = 1; ctx->last_gemm[1] = (long long)a.cout_blocks * 64;
     ctx->last_gemm[2] = (long long)N * a.strips * a.chunks * 16 * 16 * nb; ctx->last_gemm[3] = 16 * SP_GROUPS;
     return PL_OK;

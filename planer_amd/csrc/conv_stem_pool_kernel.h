@@ -30,11 +30,23 @@
 // window early (conv column 2 c pq - 2, an even column, so window centres stay on even lanes) and not storing that first
 // window -- two recomputed conv columns per chunk border.  Columns past the map's edge count as zero padding (masked before
 // the horizontal maximum).  ResNet's 224-pixel stem is NB = 7, one chunk.
+//
+// NCHW = true: the workgroup reads the reference's NCHW tensor itself -- no row-packed copy of the input exists (that copy was a
+// kernel of its own: 40 MB moved to re-lay a 19 MB batch).  The row buffer then holds one row per (input row, channel):
+// [4 zeros | the row's pixels from column 2 x0 - 4 on], whole 16-byte cells of the NCHW row landing by LDS-DMA where the
+// packed rows did (W % 4 == 0 keeps every cell inside or outside its row; cells outside arrive as zeros through the range
+// check: they are the conv's padding).  K is ordered for it: a k-quad = four consecutive taps kw = 4 half - 1 .. 4 half + 2
+// of one (filter row, channel) -- tap -1 is a zero filter value, so the seven taps of a row take two quads that start on
+// 16-byte cells; conv column l reads its quad at float 2 l + 4 half of the LDS row (8-byte aligned pairs, as before).  The 42
+// real quads + 2 zero quads are grouped so that the two quads a half-wave reads together (lanes 0-31: kk = 0, 1) sit two LDS
+// rows apart: a row is 32 NB + 16 floats, two rows = 32 banks (mod 64) -- conflict-free like the packed layout.  Filter packed
+// by pl_conv2d_prepare_stem_nchw_f32 in that order; everything behind the fragment reads is the same code.
 struct StemPoolArgs {
-    const float *xp;       // row-packed image [N][Hp][rowf] (zero border included)
+    const float *xp;       // row-packed image [N][Hp][rowf] (zero border included); NCHW: the input tensor [N][3][H][W]
     const float *wq;       // [Qpad][Cout][4] row-packed filter
     float *y;              // pooled Q4 tensor [N][Coq][Hq][Wq][4]
     int N, Hp, rowf;       // packed rows per image, floats per packed row
+    int H, W;              // NCHW: the input's height and width
     int Ho, Wo, Hq, Wq, Cout, Coq;
     int strips;            // strips of 7 pooled rows per image
     int cout_blocks;
@@ -50,15 +62,21 @@ constexpr int SP_XROWS = 9;                      // input rows under a conv-row 
 constexpr int SP_W_FLOATS = 4 * SP_GROUPS * 64 * 4;             // 44 quads x 64 channels x 4
 constexpr int SP_PROWS = 7;                      // pooled rows per strip
 constexpr int sp_xrow(int nb) { return 96 * nb + 32; }          // floats per staged input row: 6 per conv column + the last window's quads
+constexpr int sp_xrow_nchw(int nb) { return 32 * nb + 16; }     // NCHW: floats per staged (input row, channel): 2 per conv column + 4 left + the last window's quad
+// NCHW k order: group u reads (filter row, channel) pairs rho = 3 fr + c two apart -- kk = 0 / 2: rho_a (taps half 0 / 1), kk = 1 / 3:
+// rho_b = rho_a + 2; group 10 pairs rho 20 with a zero-filter quad that reads row 18
+__host__ __device__ constexpr int sp_nchw_rho(int u, int kk) { return u < 10 ? 4 * (u >> 1) + (u & 1) + 2 * (kk & 1) : ((kk & 1) ? 18 : 20); }
+__host__ __device__ constexpr bool sp_nchw_real(int u, int kk) { return u < 10 || !(kk & 1); }
 
 typedef float sp_f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float4 sp_max4(float4 a, float4 b) {
     return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
 }
-template <int SP_NB>
+template <int SP_NB, bool NCHW>
 __global__ void __launch_bounds__(512) conv_stem_pool_kernel(const StemPoolArgs p) {
-    constexpr int SP_XROW = sp_xrow(SP_NB), SP_X_FLOATS = SP_XROWS * SP_XROW;
+    constexpr int SP_XROW = NCHW ? sp_xrow_nchw(SP_NB) : sp_xrow(SP_NB), SP_X_FLOATS = (NCHW ? 3 : 1) * SP_XROWS * SP_XROW;
+    constexpr int SP_PXF = NCHW ? 32 : 96;           // floats of a staged row per 16-column pixel block
     constexpr int SP_PC = 8 * SP_NB;                 // pooled columns a workgroup's conv columns hold
     constexpr int SP_HP_CELLS = 16 * SP_PC;          // one horizontally pooled conv row: 16 channel quads x SP_PC columns
     // separate LDS objects: an LDS-DMA into one row buffer must not hold up the fragment reads of the other (the compiler
@@ -101,14 +119,28 @@ __global__ void __launch_bounds__(512) conv_stem_pool_kernel(const StemPoolArgs 
     auto load_rows = [&](int t, auto parity) {
         float *Xb = decltype(parity)::value ? X1 : X0;
         const int hr0 = 2 * (c0 + 2 * t);
-        constexpr int CELLS = SP_XROWS * (SP_XROW / 4);                    // 1584
-        for (int pc = wave; pc * 64 < CELLS; pc += 8) {
-            const int idx = pc * 64 + lane;
-            const int r = idx / (SP_XROW / 4), c = idx - r * (SP_XROW / 4);
-            const int hr = hr0 + r;
-            const bool ok = idx < CELLS && (unsigned)hr < (unsigned)p.Hp && 6 * x0 + c * 4 < p.rowf + 3;
-            const int off = ok ? (int)((((unsigned)n * (unsigned)p.Hp + (unsigned)hr) * (unsigned)p.rowf + (unsigned)(6 * x0) + 4u * (unsigned)c) << 2) : OOB;
-            if (idx < CELLS) __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_float *)(Xb + pc * 256), 16, off, 0, 0, 0);
+        if constexpr (NCHW) {
+            // 27 rows (input row r, channel c) of SP_XROW / 4 cells; cell j = input columns 2 x0 - 4 + 4 j .. + 3 of row hr0 - 3 + r
+            constexpr int CPR = SP_XROW / 4, CELLS = 3 * SP_XROWS * CPR;
+            for (int pc = wave; pc * 64 < CELLS; pc += 8) {
+                const int idx = pc * 64 + lane;
+                const int rr = idx / CPR, j = idx - rr * CPR;
+                const int r = rr / 3, c = rr - 3 * r;
+                const int h = hr0 - 3 + r, xin = 2 * x0 - 4 + 4 * j;
+                const bool ok = idx < CELLS && (unsigned)h < (unsigned)p.H && xin >= 0 && xin + 3 < p.W;
+                const int off = ok ? (int)(((((unsigned)n * 3u + (unsigned)c) * (unsigned)p.H + (unsigned)h) * (unsigned)p.W + (unsigned)xin) << 2) : OOB;
+                if (idx < CELLS) __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_float *)(Xb + pc * 256), 16, off, 0, 0, 0);
+            }
+        } else {
+            constexpr int CELLS = SP_XROWS * (SP_XROW / 4);                    // 1584
+            for (int pc = wave; pc * 64 < CELLS; pc += 8) {
+                const int idx = pc * 64 + lane;
+                const int r = idx / (SP_XROW / 4), c = idx - r * (SP_XROW / 4);
+                const int hr = hr0 + r;
+                const bool ok = idx < CELLS && (unsigned)hr < (unsigned)p.Hp && 6 * x0 + c * 4 < p.rowf + 3;
+                const int off = ok ? (int)((((unsigned)n * (unsigned)p.Hp + (unsigned)hr) * (unsigned)p.rowf + (unsigned)(6 * x0) + 4u * (unsigned)c) << 2) : OOB;
+                if (idx < CELLS) __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_float *)(Xb + pc * 256), 16, off, 0, 0, 0);
+            }
         }
     };
     load_rows(0, std::false_type{});
@@ -118,10 +150,15 @@ __global__ void __launch_bounds__(512) conv_stem_pool_kernel(const StemPoolArgs 
     int boff[SP_GROUPS];
 #pragma unroll
     for (int u = 0; u < SP_GROUPS; ++u) {
-        int q = 4 * u + kk;
-        if (q >= SP_KH * SP_RQ) q -= SP_KH * SP_RQ;
-        const int fr = q / SP_RQ, jq = q - fr * SP_RQ;
-        boff[u] = (2 * rsel + fr) * SP_XROW + 6 * li + 4 * jq;          // + 96 nb per pixel block
+        if constexpr (NCHW) {
+            const int rho = (kk & 1) ? sp_nchw_rho(u, 1) : sp_nchw_rho(u, 0);
+            boff[u] = (6 * rsel + rho) * SP_XROW + 4 * (kk >> 1) + 2 * li;       // + 32 nb per pixel block
+        } else {
+            int q = 4 * u + kk;
+            if (q >= SP_KH * SP_RQ) q -= SP_KH * SP_RQ;
+            const int fr = q / SP_RQ, jq = q - fr * SP_RQ;
+            boff[u] = (2 * rsel + fr) * SP_XROW + 6 * li + 4 * jq;          // + 96 nb per pixel block
+        }
     }
     const int aoff = (kk * 64 + mb * 16 + li) * 4;                          // + 1024 u: quad 4 u + kk, channel 16 mb + li
 
@@ -221,7 +258,7 @@ __global__ void __launch_bounds__(512) conv_stem_pool_kernel(const StemPoolArgs 
             fa[set] = *reinterpret_cast<const float4 *>(Wf + aoff + 1024 * u);
 #pragma unroll
             for (int nb = 0; nb < SP_NB; ++nb) {
-                const float *src = Xb + boff[u] + 96 * nb;
+                const float *src = Xb + boff[u] + SP_PXF * nb;
                 fb0[set][nb] = *reinterpret_cast<const float2 *>(src);
                 fb1[set][nb] = *reinterpret_cast<const float2 *>(src + 2);
             }
@@ -266,4 +303,24 @@ __global__ void __launch_bounds__(512) conv_stem_pool_kernel(const StemPoolArgs 
         pool_half(6, 0);
         pool_half(6, 1);
     }
+}
+
+// OIHW stem filter [Cout][3][7][7] -> [k-quad q][Cout][4] in the NCHW kernel's k order: quad q = 4 u + kk holds taps
+// kw = 4 (kk >> 1) - 1 .. + 3 of (filter row, channel) rho = sp_nchw_rho(u, kk); tap -1, the padding quad of group 10 and
+// quads 44 .. 47 are zeros.
+__global__ void __launch_bounds__(256) pack_filter_stem_nchw_kernel(const float *w, float4 *out, unsigned total, int Cout) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= total) return;
+    const int q = (int)(i / (unsigned)Cout), co = (int)(i - (unsigned)q * (unsigned)Cout);
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    const int u = q >> 2, kk = q & 3;
+    if (u < SP_GROUPS && sp_nchw_real(u, kk)) {
+        const int rho = sp_nchw_rho(u, kk), fr = rho / 3, c = rho - 3 * fr, half = kk >> 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int kw = 4 * half + j - 1;
+            if (kw >= 0 && kw < 7) v[j] = w[((co * 3 + c) * SP_KH + fr) * 7 + kw];
+        }
+    }
+    out[i] = make_float4(v[0], v[1], v[2], v[3]);
 }

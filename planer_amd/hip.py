@@ -242,7 +242,7 @@ class DeviceArray:
     context pool when it is garbage collected, which is what implements the
     reference's liveness-based freeing of intermediates (net.py:51-53)."""
 
-    __slots__ = ("shape", "dtype", "_p", "ctx", "base", "host", "chan", "meta", "packed", "_owned", "__weakref__")
+    __slots__ = ("shape", "dtype", "_p", "ctx", "base", "host", "chan", "meta", "packed", "prefed", "_owned", "__weakref__")
 
     def __init__(self, shape, dtype=numpy.float32, ctx=None, ptr=None, base=None, host=None):
         self.shape = tuple(int(s) for s in shape)
@@ -252,6 +252,7 @@ class DeviceArray:
         self.chan = None      # channel-quad (Q4) tensors: logical channel count (planer_amd/q4.py)
         self.meta = None      # Winograd-domain tensors: the (N, C, H, W) of the activation they stand for
         self.packed = None    # static plan inputs: ((kw, sw, pt, pl), row-packed image) kept beside the NCHW tensor (q4.pack_rows)
+        self.prefed = None    # static plan inputs: (feed(src_ptr, ctx), pooled tensor) -- the stem + max-pool kernel runs when the plan is fed
         if ptr is None:
             self._p = None
             if host is None or base is not None:

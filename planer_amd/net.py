@@ -40,7 +40,8 @@ W_LAYOUT_NAMES = {0: "igemm-nchw", 1: "tap-nchw", 2: "direct-q4 (conv_q4_kernel)
                   6: "rowpack-q4 (nchw_to_rowpack + conv_q4_kernel)",
                   7: "wino4x4-q4 (transforms + grouped conv_q4_kernel)", 8: "w1d4 F(4,3) (conv_w1d4_kernel)",
                   9: "wf4 fused F(4x4,3x3) (conv_wf4_kernel)", 10: "stem + maxpool (conv_stem_pool_kernel)",
-                  11: "wino43-q4 (mixed F(4,3) x F(3,3) tiles: transforms + 121 grouped conv_q4_kernel)"}
+                  11: "wino43-q4 (mixed F(4,3) x F(3,3) tiles: transforms + 121 grouped conv_q4_kernel)",
+                  12: "stem + maxpool (conv_stem_pool_kernel)"}         # (the kernel reads the NCHW batch itself)
 
 
 def _as_list(v):
@@ -86,8 +87,15 @@ def graph_tag_of(layers, flow, init_shapes):
 def _feed_static(ctx, dst, a, always=False):
     """A new batch `a` (a device tensor) into a captured plan's static input `dst`, on `ctx`'s stream.  Where the plan's
     only reader of that input is the row-packed stem conv (Net._capture, `dst.packed`), the batch is re-laid straight
-    into the packed image the graph reads -- that pass replaces the copy -- and the NCHW tensor is left alone."""
-    if dst.packed is not None:
+    into the packed image the graph reads -- that pass replaces the copy -- and the NCHW tensor is left alone.  Where that
+    reader is the stem + max-pool kernel that takes NCHW itself (`dst.prefed`), the kernel runs HERE, from the caller's batch
+    into the pooled tensor the captured pass starts from: no copy and no re-layout at all."""
+    if dst.prefed is not None:
+        if a.ptr % 16:                                   # (a view that starts off a 16-byte boundary: through the static tensor)
+            _lib.call("pl_d2d", ctx.handle, dst.ptr, a.ptr, dst.nbytes)
+            a = dst
+        dst.prefed[0](a.ptr, ctx)
+    elif dst.packed is not None:
         _q4.pack_rows(dst, src_ptr=a.ptr, ctx=ctx)
     elif always or a is not dst:
         _lib.call("pl_d2d", ctx.handle, dst.ptr, a.ptr, dst.nbytes)
@@ -590,8 +598,16 @@ class Net:
                         and [int(v) for v in pe[2].get("strides", (2, 2))] == [2, 2]
                         and [int(v) for v in pe[2].get("pads", (0, 0, 0, 0))] == [1, 1, 1, 1]
                         and int(entry[2].get("act", 0)) in (0, 1, 2) and _q4.stem_pool_eligible(tuple(xs), tuple(ks), **para)):
-                    body[names[0]] = [entry[0], "conv_pool_q4", dict(entry[2], w_layout=10)]
-                    out.append([src[:5], names, pdst])
+                    lay, fsrc = 10, list(src[:5])
+                    if (os.environ.get("PLANER_HIP_STEM_NCHW", "1") != "0" and src[1].endswith("@rowpack")
+                            and _q4.stem_pool_nchw_eligible(tuple(xs), tuple(ks), **para)):
+                        # W % 4 == 0: the kernel reads the NCHW batch itself (no row-packed copy), filter in its own k order
+                        lay, key = 12, src[1][:-len("@rowpack")] + "@stemnchw"
+                        if key not in self._extra:
+                            self._extra[key] = _q4.prepare_stem_nchw_weights(dict(zip(self.inits, self.weights))[src[1][:-len("@rowpack")]])
+                        fsrc[1] = key
+                    body[names[0]] = [entry[0], "conv_pool_q4", dict(entry[2], w_layout=lay)]
+                    out.append([fsrc, names, pdst])
                     drop.add(j)
                     continue
             if i not in drop:
@@ -1019,6 +1035,19 @@ class Net:
             src, names = readers[0]
             obj = prog.objs[_as_list(names)[0]]
             para = obj.para()
+            if (obj.name == "conv_pool_q4" and para.get("w_layout") == 12 and _as_list(src)[0] == k and _as_list(src).count(k) == 1
+                    and s_.prefed is None and s_.ptr % 16 == 0 and os.environ.get("PLANER_HIP_FEED_STEM", "1") != "0"):
+                # the stem + max-pool kernel reads NCHW itself: it leaves the graph and runs when the plan is fed, straight
+                # from the caller's batch; the captured pass starts from its (persistent) pooled tensor
+                env = {"None": None}
+                env.update(zip(self.inits, self.weights))
+                env.update(self._extra)
+                args = [env.get(a) for a in (_as_list(src)[1:5] + ["None"] * 4)[:4]]
+                fpara = {a: b for a, b in para.items() if a != "w_layout"}
+                pooled = _q4.ConvPoolQ4(s_, *args, w_layout=12, **fpara)
+                s_.prefed = (_q4.stem_pool_feeder(s_.shape, args[0], args[1], args[2], args[3], fpara.get("act", 0),
+                                                  fpara.get("alpha", 0.0), pooled), pooled)
+                continue
             if (obj.name not in ("conv_q4", "conv_pool_q4") or para.get("w_layout") not in (6, 10) or _as_list(src)[0] != k
                     or _as_list(src).count(k) != 1):
                 continue

@@ -169,6 +169,21 @@ def prepare_rowpack_weights(K):
     return out
 
 
+def prepare_stem_nchw_weights(K):
+    """OIHW stem filters [Cout][3][7][7] -> [48][Cout][4] in the k order of the stem + max-pool kernel that reads the NCHW
+    input itself (ConvPoolQ4 w_layout=12, csrc/conv_stem_pool_kernel.h)."""
+    _f32(K)
+    cout, cin, kh, kw = K.shape
+    if (cin, kh, kw) != (3, 7, 7):
+        raise ValueError("the NCHW stem kernel takes [Cout][3][7][7] filters")
+    n = ctypes.c_size_t()
+    _lib.call("pl_conv2d_stem_nchw_filter_elems", cout, ctypes.byref(n))
+    out = empty((n.value,), ctx=K.ctx)
+    _lib.call("pl_conv2d_prepare_stem_nchw_f32", K.ctx.handle, K.ptr, cout, out.ptr)
+    out.shape = K.shape
+    return out
+
+
 def prepare_w1d4_q4_weights(K):
     """OIHW 3x3 filters -> fused 1-D Winograd F(4,3) filters [6][row*Cin/4 + cin/4][Cout][4] (w_layout=8)."""
     _f32(K)
@@ -282,12 +297,28 @@ def stem_pool_eligible(x_shape, k_shape, group=1, strides=(1, 1), dilations=(1, 
     return bool(ok.value) and x_shape[1] == cin
 
 
+def stem_pool_nchw_eligible(x_shape, k_shape, group=1, strides=(1, 1), dilations=(1, 1), pads=(0, 0, 0, 0), **_):
+    """Whether the stem + max-pool kernel can read this NCHW input itself (W % 4 == 0 on top of stem_pool_eligible)."""
+    if not stem_pool_eligible(x_shape, k_shape, group, strides, dilations, pads):
+        return False
+    cout, cin, kh, kw = k_shape
+    ok = ctypes.c_int()
+    _lib.call("pl_conv2d_stem_pool_nchw_supported", int(cin), int(x_shape[2]), int(x_shape[3]), int(cout), int(kh), int(kw),
+              int(strides[0]), int(strides[1]), int(pads[0]), int(pads[1]), ctypes.byref(ok))
+    return bool(ok.value)
+
+
 def ConvPoolQ4(x, Kq, B=None, scale=None, shift=None, group=1, strides=(1, 1), dilations=(1, 1), pads=(0, 0, 0, 0),
-               act=ACT_NONE, alpha=0.0, **_):
+               act=ACT_NONE, alpha=0.0, w_layout=10, out=None, src_ptr=None, ctx=None, **_):
     """Row-packed stem conv (ConvQ4 w_layout 6: NCHW input, filter from prepare_rowpack_weights) with its fused tail, followed
     by layer.Maxpool(w=(3, 3), strides=(2, 2), pads=(1, 1, 1, 1)) (layer.py:71-72), in ONE kernel: only the pooled Q4 tensor is
-    written.  Emitted by the plan compiler (Net._fuse_stem_pool) where the max-pool is the conv's only reader."""
+    written.  Emitted by the plan compiler (Net._fuse_stem_pool) where the max-pool is the conv's only reader.
+    w_layout 12: the kernel reads the NCHW tensor itself (filter from prepare_stem_nchw_weights; W % 4 == 0) -- no row-packed
+    copy.  A plan's static input then carries `x.prefed = (feed, pooled)`: whoever feeds the plan runs this kernel from the
+    caller's batch straight into `pooled` (`out` / `src_ptr` / `ctx` below), and the captured pass starts behind it."""
     _f32(x, Kq, B, scale, shift)
+    if w_layout == 12 and out is None and getattr(x, "prefed", None) is not None:
+        return x.prefed[1]                         # a plan's static input: the feed has already run this step
     if is_q4(x) or not stem_pool_eligible(x.shape, Kq.shape, group, strides, dilations, pads):
         raise NotImplementedError("conv + maxpool in one kernel: NCHW 3-channel input, 7x7 / stride 2 / pad 3")
     if any(a is not None and a.ptr % 16 for a in (B, scale, shift)):
@@ -296,6 +327,15 @@ def ConvPoolQ4(x, Kq, B=None, scale=None, shift=None, group=1, strides=(1, 1), d
     cout, _, kh, kw = Kq.shape
     pads, strides = [int(p) for p in pads], [int(s) for s in strides]
     ho, wo = conv_out_hw(h, w, kh, kw, strides, [1, 1], pads)
+    cx = ctx or x.ctx
+    if w_layout == 12:
+        xptr = x.ptr if src_ptr is None else src_ptr
+        if w % 4 or xptr % 16:
+            raise NotImplementedError("the NCHW stem + max-pool kernel needs W % 4 == 0 and a 16-byte aligned input")
+        y = out if out is not None else _new_q4(n, cout, (ho + 1) // 2, (wo + 1) // 2, cx)
+        _lib.call("pl_conv2d_stem_pool_nchw_q4_f32", cx.handle, xptr, n, h, w, Kq.ptr, cout, _ptr(B), y.ptr, _ptr(scale),
+                  _ptr(shift), int(act), float(alpha))
+        return y
     geom = (kw, strides[1], pads[0], pads[1])
     if x.packed is not None and x.packed[0] == geom:
         img = x.packed[1]                          # a plan's static input: whoever feeds the plan keeps the image current
@@ -308,6 +348,18 @@ def ConvPoolQ4(x, Kq, B=None, scale=None, shift=None, group=1, strides=(1, 1), d
     _lib.call("pl_conv2d_rowpacked_pool_q4_f32", x.ctx.handle, img.ptr, n, cin, h, w, Kq.ptr, cout, kh, kw, _ptr(B), y.ptr,
               strides[0], strides[1], pads[0], pads[1], _ptr(scale), _ptr(shift), int(act), float(alpha))
     return y
+
+
+def stem_pool_feeder(x_shape, Kq, B, scale, shift, act, alpha, pooled):
+    """feed(src_ptr, ctx): the NCHW stem + max-pool kernel from the batch at `src_ptr` into the persistent tensor `pooled`, on
+    `ctx`'s stream -- what `DeviceArray.prefed` holds for a plan's static input (Net._pack_static_inputs)."""
+    n, _, h, w = (int(v) for v in x_shape)
+    cout = int(Kq.shape[0])
+
+    def feed(src_ptr, ctx):
+        _lib.call("pl_conv2d_stem_pool_nchw_q4_f32", ctx.handle, src_ptr, n, h, w, Kq.ptr, cout, _ptr(B), pooled.ptr, _ptr(scale),
+                  _ptr(shift), int(act), float(alpha))
+    return feed
 
 
 def ConvQ4Pair(xq, K1, B1, scale1, shift1, K2, B2, scale2, shift2, para1=None, para2=None, **_):

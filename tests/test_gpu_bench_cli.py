@@ -60,7 +60,7 @@ def test_bench_default_command_prints_one_contract_line():
     assert len(steps) >= 30 and all(len(s) == 2 for s in steps)
     if d["config"]["wino_chains"]:
         kinds = [k for _, k in steps]
-        assert kinds.count("wino4_chain") == d["config"]["wino_chains"]
+        assert kinds.count("wino4_chain") + kinds.count("wino43_chain") == d["config"]["wino_chains"]      # (F(4x4) and mixed-tile chains)
         assert any("transform" in h["layer"] for h in d["roofline_hbm"])
     # round 4: the in-process (HIP-event) utilisation of the dominant family against the one recomputed from the committed
     # rocprofv3 kernel trace of this build (profiles/<tag>_per_layer.csv) -- when that table describes this run's kernels

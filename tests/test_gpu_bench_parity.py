@@ -58,7 +58,7 @@ def test_throughput_plan_batch32_full_size(pa, r18, streams):
     assert plan.streams == streams and len(plan.replicas) == R
     # what ran is on record: one entry per conv / dense step with its kernel family and tile plan
     # (wino4_gemm: a staged F(4x4,3x3) conv; conv_q4_pair: two sibling convs in one launch; conv_pool_q4: stem conv + max-pool)
-    convs = [a for a in plan.algos if a["kind"] in ("conv_q4", "wino4_gemm", "conv_q4_pair", "conv_pool_q4")]
+    convs = [a for a in plan.algos if a["kind"] in ("conv_q4", "wino4_gemm", "wino43_gemm", "conv_q4_pair", "conv_pool_q4")]
     assert sum(2 if a["kind"] == "conv_q4_pair" else 1 for a in convs) == 20 and all(a["plan"] for a in convs), plan.algos
     for rnd in range(2):
         held = []
@@ -119,7 +119,7 @@ def test_whole_net_with_one_forced_algorithm_batch32(pa, r18, lay):
     y = net(d).get()
     used = []
     for a in net.compile(d).algos:
-        if a["kind"] in ("conv_q4", "wino4_gemm", "conv_q4_pair"):
+        if a["kind"] in ("conv_q4", "wino4_gemm", "wino43_gemm", "conv_q4_pair"):
             used += [a["w_layout"]] * (2 if a["kind"] == "conv_q4_pair" else 1)
     # 13 stride-1 3x3 convs; the 3 stride-2 3x3 and the 3 1x1 convs are always direct (w_layout 2)
     assert used.count(lay) == (13 if lay != 2 else 19), used

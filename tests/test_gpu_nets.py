@@ -129,20 +129,26 @@ def test_call_on_a_pipelined_plan_sees_each_new_input(pa, streams, monkeypatch):
 
 @pytest.mark.parametrize("streams", ["1x1", "pipe2"])
 def test_feeding_a_plan_relays_the_batch_into_the_stem_image(pa, streams, monkeypatch):
-    """Where the row-packed stem conv is the only reader of a graph input, the plan keeps the packed image beside the
-    static input and `feed` re-lays each new batch straight into it (no copy + in-graph re-layout).  Same results as the
-    plan that re-lays inside the graph (PLANER_HIP_FEED_PACK=0) for batches fed one after another; re-feeding a batch
-    reproduces its result bit for bit."""
+    """Where the stem conv is the only reader of a graph input, feeding the plan IS the stem's first pass over the batch:
+    (round 5) the stem + max-pool kernel reads the caller's NCHW batch itself and runs at feed time, in front of the captured
+    pass (`static.prefed`; W % 4 == 0); with PLANER_HIP_STEM_NCHW=0 the plan keeps a row-packed image beside the static
+    input and `feed` re-lays each new batch straight into it (`static.packed`).  Same results as the plan that does everything
+    inside the graph (PLANER_HIP_FEED_PACK=0) for batches fed one after another; re-feeding a batch reproduces its result bit
+    for bit; batches the caller drops right after feeding are read before their memory is reused."""
     g, b = resnet18.build()
     xs = [pa.asarray(resnet18.make_input(2, seed=70 + s, size=64)) for s in range(4)]
     outs = {}
-    for flag in ("1", "0"):
+    for flag, nchw in (("1", "1"), ("1", "0"), ("0", "1")):
         monkeypatch.setenv("PLANER_HIP_FEED_PACK", flag)
+        monkeypatch.setenv("PLANER_HIP_STEM_NCHW", nchw)
         net = pa.from_graph(g, b)
         net.streams = streams
         plan = net.compile(xs[0], mode="throughput")
         statics = (plan.replicas[0] if hasattr(plan, "replicas") else plan).inputs
-        assert (statics[0].packed is not None) == (flag == "1")
+        assert (statics[0].prefed is not None) == (flag == "1" and nchw == "1")
+        assert (statics[0].packed is not None) == (flag == "1" and nchw == "0")
+        assert any(a["kind"] == "conv_pool_q4" and a["plan"].startswith("stem+maxpool(nchw)" if nchw == "1" else "stem+maxpool ")
+                   for a in plan.algos), plan.algos
         got = []
         for x in xs + xs[:2]:
             plan.feed([x])
@@ -151,13 +157,19 @@ def test_feeding_a_plan_relays_the_batch_into_the_stem_image(pa, streams, monkey
             plan.join()
             net.ctx.synchronize()
             got.append((held[0] if isinstance(held, tuple) else held).get())
-        outs[flag] = got
+        outs[flag + nchw] = got
         y = net(xs[3])                                   # the latency path feeds the same way
         np.testing.assert_array_equal((y[0] if isinstance(y, tuple) else y).get(), got[3])
-    for a, c in zip(outs["1"], outs["0"]):               # (two nets: each times its own launch plans for these small shapes,
-        assert_close(a, c, 1e-5, "fed vs in-graph")      #  so split-K / algorithm picks -- the summation order -- may differ)
-    np.testing.assert_array_equal(outs["1"][0], outs["1"][4])
-    assert not np.array_equal(outs["1"][0], outs["1"][1])
+        # asynchronous submits of host batches: the temporaries are dropped at once, the feed kernel must have read them
+        pend = [net.submit(resnet18.make_input(2, seed=70 + s, size=64)) for s in range(4)]
+        for s, pd in enumerate(pend):
+            r = pd.get()
+            np.testing.assert_array_equal(r[0] if isinstance(r, tuple) else r, got[s])
+    for key in ("10", "01"):
+        for a, c in zip(outs["11"], outs[key]):          # (other nets: each times its own launch plans for these small shapes,
+            assert_close(a, c, 1e-5, "fed vs " + key)    #  so split-K / algorithm picks -- the summation order -- may differ)
+    np.testing.assert_array_equal(outs["11"][0], outs["11"][4])
+    assert not np.array_equal(outs["11"][0], outs["11"][1])
 
 
 @pytest.mark.parametrize("streams", ["pipe2", "pipe3", "auto"])

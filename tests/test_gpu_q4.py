@@ -207,7 +207,8 @@ def test_stem_conv_maxpool_marching_kernel_matches_oracle(pa):
                                       (2, 30, 8, 0, "none", 224), (1, 226, 132, 2, "bn", 224), (32, 224, 64, 1, "bn", 224),
                                       (2, 160, 64, 1, "bn", 160), (2, 256, 64, 1, "bn", 256), (1, 416, 64, 2, "bn", 416),
                                       (2, 64, 64, 0, "bias", 64), (1, 50, 36, 1, "bn", 37), (1, 90, 64, 0, "none", 231),
-                                      (1, 70, 64, 1, "bn", 450), (1, 33, 12, 2, "bn", 1000), (2, 20, 64, 1, "bn", 12)]:
+                                      (1, 70, 64, 1, "bn", 450), (1, 33, 12, 2, "bn", 1000), (2, 20, 64, 1, "bn", 12),
+                                      (1, 40, 64, 1, "bn", 452), (2, 21, 20, 0, "bias", 8), (1, 47, 64, 2, "bn", 1000)]:
         x = rng.standard_normal((n, 3, h, wd)).astype(np.float32)
         K = (rng.standard_normal((cout, 3, 7, 7)) * 0.1).astype(np.float32)
         B = rng.standard_normal(cout).astype(np.float32) if tail == "bias" else None
@@ -229,6 +230,19 @@ def test_stem_conv_maxpool_marching_kernel_matches_oracle(pa):
         assert_close(got, want, RTOL, "stem + maxpool %s" % ((n, h, cout, act, tail, wd),))
         assert_close(one.get(), two.get(), 1e-5, "one kernel vs conv kernel + pool kernel")
         np.testing.assert_array_equal(one.get(), q4_host(got))                 # padding lanes of the last quad stay zero
+        # the same kernel reading the NCHW tensor itself (w_layout 12: no row-packed copy, its own k order) where W % 4 == 0
+        assert q4.stem_pool_nchw_eligible(x.shape, K.shape, **para) == (wd % 4 == 0)
+        if wd % 4 == 0:
+            Kn = q4.prepare_stem_nchw_weights(pa.asarray(K))
+            direct = q4.ConvPoolQ4(dx, Kn, dB, dsc, dsh, act=act, alpha=0.1, w_layout=12, **para)
+            assert "maxpool(nchw)" in pa.hip.context().last_conv_plan(), pa.hip.context().last_conv_plan()
+            assert direct.shape == one.shape and direct.chan == one.chan
+            gotn = q4.from_q4(direct).get()
+            assert_close(gotn, want, RTOL, "stem + maxpool, NCHW input %s" % ((n, h, cout, act, tail, wd),))
+            assert_close(direct.get(), one.get(), 1e-5, "NCHW-reading kernel vs row-packed kernel")
+            np.testing.assert_array_equal(direct.get(), q4_host(gotn))
+    with pytest.raises(NotImplementedError):
+        q4.ConvPoolQ4(pa.asarray(np.zeros((1, 3, 64, 30), np.float32)), q4.prepare_stem_nchw_weights(pa.asarray(K[:8])), w_layout=12, **para)
     assert q4.stem_pool_eligible((1, 3, 224, 200), (64, 3, 7, 7), **para)
     assert not q4.stem_pool_eligible((1, 3, 224, 224), (64, 3, 3, 3), **dict(para, pads=[1, 1, 1, 1]))
     assert not q4.stem_pool_eligible((1, 3, 224, 224), (64, 3, 7, 7), **dict(para, strides=[1, 1]))

@@ -102,9 +102,11 @@ def expected_kernels(a):
         return ["dense_small_kernel"]
     if plan.startswith("pair["):
         return ["conv_q4_pair_kernel"]
-    plan = re.sub(r"^wino\d\[(.*)\]$", r"\1", plan) if algo == "direct" else plan
+    plan = re.sub(r"^wino\d+\[(.*)\]$", r"\1", plan) if algo == "direct" else plan
     if plan.startswith("as128"):
         return ["wino4_gemm_as_kernel"]      # filter-stationary GEMM stage of a 128-channel F(4x4,3x3) conv
+    if plan.startswith("stem+maxpool(nchw)"):
+        return ["conv_stem_pool_kernel"]     # reads the NCHW batch itself; runs when the plan is fed, in front of the graph
     if plan.startswith("stem+maxpool"):
         return ["nchw_to_rowpack_kernel", "conv_stem_pool_kernel"]      # the re-layout runs when the plan is fed
     if plan.startswith("smallcin3x3valu"):
@@ -118,6 +120,8 @@ def expected_kernels(a):
         return ["nchw_to_rowpack_kernel"] + gemm
     if algo.startswith("w1d4"):
         return ["conv_w1d4_kernel"]
+    if algo.startswith("wino43"):
+        return ["wino43_"] + gemm + ["wino43_"]
     if algo.startswith("wino4x4"):
         return ["wino4_input_"] + gemm + ["wino4_output_"]          # ..._q4_kernel or the row-split ..._rows_q4_kernel
     if algo.startswith("wino2x2"):
@@ -132,7 +136,9 @@ def step_kernels(step, kind, algos):
         return expected_kernels(a) if a else None
     if kind in ("wino4_in", "wino4_out", "wino4_chain"):
         return ["wino4_"]                    # wino4_chain_kernel<..> (LDS) or wino4_input_ / wino4_output_ (register kernels)
-    if kind == "wino4_gemm":
+    if kind in ("wino43_in", "wino43_out", "wino43_chain"):
+        return ["wino43_"]                   # wino43_lds_kernel<..> or the register kernels wino43_input_ / wino43_output_
+    if kind in ("wino4_gemm", "wino43_gemm"):
         return expected_kernels(dict(a, algo="direct")) if a else None
     return {"maxpool_q4": ["pool"], "gap_q4": ["gap_q4_kernel"], "to_q4": ["nchw_to_q4"], "from_q4": ["q4_to_nchw"],
             "flatten": [], "return": [], "identity": []}.get(kind)

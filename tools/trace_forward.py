@@ -11,7 +11,7 @@ if not n:                                           # period = distance between 
     prev = max(i for i in range(last) if names[i] == first)
     n = last - prev
     # find a true period: smallest p >= n such that names[-p:] == names[-2p:-p]
-    p = n
+    p = max(n, 8)                                   # (several result copies in a row are not a period)
     while names[-p:] != names[-2 * p:-p]:
         p += 1
     n = p
