@@ -42,7 +42,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0
 PER_GPU_BATCH = 32                 # BASELINE.json configs[2] / configs[3]: 32 images per GPU
 PROF_REPEAT = 10                   # launches of a step between its two stream markers in the per-layer passes
-PROFILE_TAG = "r04"                # profiles/<tag>_* files this build's numbers are cross-checked against
+PROFILE_TAG = "r05"
 
 
 def cdiv(a, b):
@@ -697,7 +697,7 @@ def main():
     for r in tr:
         hbm.append(hbm_row(r["layer"], r["kind"], r["hbm_bytes"], r["ms"]))
     if tr:
-        hbm.append(dict(hbm_row("all F(4x4,3x3) transform steps of one forward", "wino4_in + wino4_out + wino4_chain",
+        hbm.append(dict(hbm_row("all Winograd transform steps of one forward", "wino4_* / wino43_* in + out + chain",
                                 sum(r["hbm_bytes"] for r in tr), sum(r["ms"] for r in tr)), steps=len(tr)))
 
     out = {"metric": "images/sec ResNet-18 fp32 forward", "value": round(value, 1), "unit": "images/sec",
