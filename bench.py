@@ -536,7 +536,7 @@ def main():
         ms = float(np.median(v))                 # median: one pool-growth hiccup must not skew a layer
         base, stage = split_step(name)
         c, rec = conv_of(convs, base), algos.get(base)
-        mfma_step = c is not None and stage in ("", "gemm", "gemmout")          # the step of a conv that runs its GEMM(s)
+        mfma_step = c is not None and stage in ("", "gemm")          # the step of a conv that runs its GEMM(s)
         alg = c["flops"] if mfma_step else 0.0
         exe = executed_flops(rec) if mfma_step else None
         cls = c["cls"] if c else kind

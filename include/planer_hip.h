@@ -264,11 +264,6 @@ int pl_wino4_gemm_q4_f32(pl_ctx *ctx, const float *V, int N, int Cin, int H, int
 int pl_wino4_output_q4_f32(pl_ctx *ctx, const float *M, int N, int C, int H, int W, const float *bias,
                            const float *scale, const float *shift, const float *resq, int act, double alpha,
                            float *yq);
-/* pl_wino4_gemm_q4_f32 and pl_wino4_output_q4_f32 in one kernel for maps of few tiles (batch-1 detection nets): a workgroup
- * owns 16 output channels x 16 tiles for all 36 frequencies, M never exists in memory (wino4_gemm_out_kernel.h). */
-int pl_wino4_gemm_out_q4_f32(pl_ctx *ctx, const float *V, int N, int Cin, int H, int W, const float *uq, int Cout,
-                             const float *bias, const float *scale, const float *shift, const float *resq,
-                             int act, double alpha, float *yq);
 int pl_wino4_chain_q4_f32(pl_ctx *ctx, const float *M, int N, int C, int H, int W, const float *bias,
                           const float *scale, const float *shift, const float *resq, int act, double alpha,
                           float *yq, float *Vnext);

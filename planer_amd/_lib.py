@@ -84,7 +84,6 @@ SIGNATURES = {
     "pl_wino4_input_q4_f32": [_P, _P, _I, _I, _I, _I, _P],
     "pl_wino4_gemm_q4_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _P],
     "pl_wino4_output_q4_f32": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, c_double, _P],
-    "pl_wino4_gemm_out_q4_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _I, c_double, _P],
     "pl_wino4_chain_q4_f32": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, c_double, _P, _P],
     "pl_wino43_supported": [_I, _I, POINTER(c_int)],
     "pl_wino43_elems": [_I, _I, _I, _I, POINTER(c_size_t)],

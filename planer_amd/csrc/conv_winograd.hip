@@ -649,7 +649,6 @@ __global__ void __launch_bounds__(256) wino4_output_rows_q4_kernel(const float4 
 }
 
 #include "wino4_chain_kernel.h"
-#include "wino4_gemm_out_kernel.h"
 #include "wino4_gemm_as_kernel.h"
 #include "conv1x1_wino_in_kernel.h"
 #include "wino43_kernels.h"
@@ -1212,40 +1211,6 @@ int pl_wino4_output_q4_f32(pl_ctx *ctx, const float *M, int N, int C, int H, int
     if (rc != PL_OK) return rc;
     p.ep = make_epilogue(bias, scale, shift, resq, act, alpha);
     return wino4_output_launch(ctx, M, yq, p, 1);
-}
-
-int pl_wino4_gemm_out_q4_f32(pl_ctx *ctx, const float *V, int N, int Cin, int H, int W, const float *uq, int Cout, const float *bias,
-                             const float *scale, const float *shift, const float *resq, int act, double alpha, float *yq) {
-    int rc = wino4_stage_check("pl_wino4_gemm_out_q4_f32", ctx, N, Cin, H, W, V, uq, yq, resq);
-    if (rc != PL_OK) return rc;
-    PL_REQUIRE(V && uq && yq && Cout > 0 && Cout % 4 == 0, PL_EINVAL, "pl_wino4_gemm_out_q4_f32: bad argument");
-    PL_REQUIRE(act >= 0 && (act & 15) <= 2 && (act & ~31) == 0, PL_EINVAL, "pl_wino4_gemm_out_q4_f32: bad activation code");
-    PL_REQUIRE(((reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift)) & 3u) == 0, PL_EINVAL,
-               "pl_wino4_gemm_out_q4_f32: misaligned parameter");
-    if (N == 0) return PL_OK;
-    CtxGuard guard(ctx);
-    WinoArgs p;
-    rc = wino4_geometry(p, N, Cin, H, W, Cout);
-    if (rc != PL_OK) return rc;
-    W4GOArgs a;
-    memset(&a, 0, sizeof a);
-    a.V = V; a.U = uq; a.y = (float4 *)yq;
-    a.N = N; a.Cq = Cin / 4; a.Qpad = (Cin / 4 + 7) / 8 * 8; a.Cout = Cout; a.Coq = Cout / 4; a.T = p.T; a.H = H; a.W = W; a.th = p.th; a.tw = p.tw;
-    a.mtiles = (Cout + 15) / 16;
-    a.steps = (a.Cq + 3) / 4;
-    const size_t vb = (size_t)36 * Cin * p.T * 4, ub = (size_t)36 * a.Qpad * Cout * 16, yb = (size_t)N * Cout * H * W * 4;
-    PL_REQUIRE(vb < (1ull << 31) && ub < (1ull << 31) && yb < (1ull << 31), PL_EUNSUPPORTED, "pl_wino4_gemm_out_q4_f32: tensor too large");
-    a.v_bytes = (unsigned)vb; a.u_bytes = (unsigned)ub; a.y_bytes = (unsigned)yb;
-    a.divMt = FastDiv((unsigned)a.mtiles); a.divTw = FastDiv((unsigned)p.tw); a.divTh = FastDiv((unsigned)p.th);
-    a.ep = make_epilogue(bias, scale, shift, resq, act, alpha);
-    const long long blocks = (long long)a.mtiles * ((p.T + 15) / 16);
-    PL_REQUIRE(blocks < (1ll << 31), PL_EUNSUPPORTED, "pl_wino4_gemm_out_q4_f32: grid too large");
-    hipLaunchKernelGGL(wino4_gemm_out_kernel, dim3((unsigned)blocks), dim3(W4GO_WAVES * 64), 0, ctx->stream, a);
-    PL_LAUNCH_CHECK();
-    ctx->last_plan = "wino4[gemm+out 16co x 16 tiles x 36f, blocks=" + std::to_string(blocks) + "]";
-    ctx->last_gemm[0] = 36; ctx->last_gemm[1] = (long long)a.mtiles * 16; ctx->last_gemm[2] = (long long)((p.T + 15) / 16) * 16;
-    ctx->last_gemm[3] = (long long)((a.steps + 2) / 3) * 3 * 16;
-    return PL_OK;
 }
 
 int pl_wino4_chain_q4_f32(pl_ctx *ctx, const float *M, int N, int C, int H, int W, const float *bias, const float *scale,

@@ -28,7 +28,7 @@ from . import hip
 from .hip import DeviceArray
 from . import q4 as _q4
 from .layer import layer_map, wrap
-from .plan import assign_layouts, chain_winograd, fuse_conv1x1_wino_in, fuse_flow, fuse_wino_gemm_out, pair_sibling_convs
+from .plan import assign_layouts, chain_winograd, fuse_conv1x1_wino_in, fuse_flow, pair_sibling_convs
 
 _q4.register(layer_map)
 
@@ -303,7 +303,6 @@ class Net:
         self._extra = {}             # derived constant tensors (tap-major / Winograd filters)
         self._algo = {}              # conv shape signature -> chosen w_layout
         self.wino_chains = 0         # F(4x4,3x3) output / input transform pairs the last plan runs as one kernel
-        self.wino_gemm_out = 0       # F(4x4,3x3) convs whose GEMM and output transform the last plan runs as one kernel
         self.conv_pairs = 0          # sibling conv pairs the last plan runs as one launch
         self.conv_wino_fused = 0     # 1x1 convs the last plan runs inside the next conv's Winograd input transform
         # force_algo: w_layout (int) every eligible 3x3/s1/p1 conv must use, or None = pick by timing
@@ -409,13 +408,11 @@ class Net:
                 if profile:                                  # ONE marker per step boundary: step time = marker to marker
                     events.append((name, obj.name, hip.Event(self.ctx).record()))
                 if record is not None and obj.name in ("conv", "conv_fused", "conv_q4", "dense", "matmul", "wino4_gemm", "wino43_gemm",
-                                                       "wino4_gemm_out", "conv_q4_pair", "conv_pool_q4", "conv1x1_wino_in"):
+                                                       "conv_q4_pair", "conv_pool_q4", "conv1x1_wino_in"):
                     lay = obj.para().get("w_layout", 2 if obj.name in ("conv_q4_pair", "conv1x1_wino_in") else 0) if obj.name != "conv" else 0
                     lname = name
                     if obj.name in ("wino4_gemm", "wino43_gemm"):       # the GEMM stage of a staged Winograd conv
                         lay, lname = (7 if obj.name == "wino4_gemm" else 11), name[:-len("@gemm")]
-                    elif obj.name == "wino4_gemm_out":                 # GEMM stage + output transform in one kernel
-                        lay, lname = 7, name[:-len("@gemmout")]
                     ctx_ = args[0].ctx if isinstance(args[0], DeviceArray) else self.ctx
                     xshape = (args[0].meta if args[0].meta is not None else
                               _q4.logical_shape(args[0]) if _q4.is_q4(args[0]) else args[0].shape)
@@ -552,14 +549,6 @@ class Net:
                     shp = shapes.get(key.split("@")[0])
                     return shp is not None and len(shp) == 4 and shp[0] * (-(-shp[2] // 4)) * (-(-shp[3] // 4)) <= int(lim)
                 out_list, out_flow, self.conv_wino_fused = fuse_conv1x1_wino_in(out_list, out_flow, self._shape_of_init, small)
-            # an unchained F(4x4,3x3) conv on a map of few tiles: GEMM stage + output transform in one kernel, M stays on chip
-            # (csrc/wino4_gemm_out_kernel.h); PLANER_HIP_WINO_GEMM_OUT=0 turns it off, =<tiles> moves the size limit
-            glim = os.environ.get("PLANER_HIP_WINO_GEMM_OUT", "0")
-            if glim != "0":
-                def few_tiles(key):
-                    shp = shapes.get(key.split("@")[0])
-                    return shp is not None and len(shp) == 4 and shp[0] * (-(-shp[2] // 4)) * (-(-shp[3] // 4)) <= int(glim)
-                out_list, out_flow, self.wino_gemm_out = fuse_wino_gemm_out(out_list, out_flow, few_tiles)
         return out_list, out_flow
 
     @staticmethod

@@ -281,7 +281,7 @@ def assign_layouts(body, flow, init_names, shapes, force=False):
 # when nothing else reads y it is never written at all.  `chain_winograd` makes the stages explicit plan
 # steps and merges the out / in pairs.  Kinds that only read their inputs (no in-place update): a
 # Winograd input transform may be hoisted over them.
-_PURE_READERS = ("conv_q4", "wino4_in", "wino4_gemm", "wino4_out", "wino4_chain", "wino4_gemm_out", "wino43_in", "wino43_gemm", "wino43_out",
+_PURE_READERS = ("conv_q4", "wino4_in", "wino4_gemm", "wino4_out", "wino4_chain", "wino43_in", "wino43_gemm", "wino43_out",
                  "wino43_chain", "conv1x1_wino_in", "conv_q4_pair", "add_q4", "maxpool_q4",
                  "averagepool_q4", "gap_q4", "upsample_q4", "concat_q4", "upconcat_q4", "batchnorm_q4",
                  "leakyrelu_q4", "sigmoid_q4", "from_q4")
@@ -386,42 +386,6 @@ def fuse_conv1x1_wino_in(body, flow, kshape=lambda key: None, small=lambda key: 
             out.append(repl[i])
         else:
             out.append((srcs, name, kinds[name][1], kinds[name][2], dst))
-    out_body, seen = [], set()
-    for srcs, name, kind, para, dst in out:
-        if name not in seen:
-            seen.add(name)
-            out_body.append([name, kind, para])
-    return out_body, [[srcs, [name], dst] for srcs, name, kind, para, dst in out], nfused
-
-
-# ---- staged Winograd conv on a small map: GEMM stage + output stage -> one step ---------------------------------
-def fuse_wino_gemm_out(body, flow, small=lambda key: True):
-    """-> (body', flow', number fused).  A `wino4_gemm` step whose M is read ONLY by the `wino4_out` step right behind it (an
-    unchained F(4x4,3x3) conv) becomes one `wino4_gemm_out` step (q4.Wino4GemmOut: csrc/wino4_gemm_out_kernel.h -- 36 frequencies
-    of a 16-channel x 16-tile block per workgroup, M stays on chip) where `small(y)` says the output map has few enough tiles
-    for a launch and the M round trip to outweigh the lost operand reuse (batch-1 detection nets)."""
-    kinds = {b[0]: b for b in body}
-    steps = [[list(src) if isinstance(src, (list, tuple)) else [src], names[0] if isinstance(names, (list, tuple)) else names, dst]
-             for src, names, dst in flow]
-    readers = {}
-    for i, (srcs, name, dst) in enumerate(steps):
-        for k in set(srcs):
-            readers.setdefault(k, []).append(i)
-    out, skip, nfused = [], set(), 0
-    for i, (srcs, name, dst) in enumerate(steps):
-        if i in skip:
-            continue
-        kind, para = kinds[name][1], kinds[name][2]
-        if (kind == "wino4_gemm" and isinstance(dst, str) and i + 1 < len(steps) and readers.get(dst, []) == [i + 1]
-                and kinds[steps[i + 1][1]][1] == "wino4_out" and steps[i + 1][0][0] == dst and isinstance(steps[i + 1][2], str)
-                and small(steps[i + 1][2])):
-            osrcs, oname, odst = steps[i + 1]
-            base = name[:-len("@gemm")] if name.endswith("@gemm") else name
-            out.append((list(srcs) + list(osrcs[1:]), base + "@gemmout", "wino4_gemm_out", dict(kinds[oname][2]), odst))
-            skip.add(i + 1)
-            nfused += 1
-        else:
-            out.append((srcs, name, kind, para, dst))
     out_body, seen = [], set()
     for srcs, name, kind, para, dst in out:
         if name not in seen:

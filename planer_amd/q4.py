@@ -447,22 +447,6 @@ def Wino4Out(m, B=None, scale=None, shift=None, resq=None, act=ACT_NONE, alpha=0
     return y
 
 
-def Wino4GemmOut(v, Kq, B=None, scale=None, shift=None, resq=None, act=ACT_NONE, alpha=0.0, **_):
-    """Wino4Gemm and Wino4Out in one kernel (csrc/wino4_gemm_out_kernel.h): V x Winograd-domain filters -> A^T m A + the
-    conv's fused tail -> y (Q4); M stays on chip.  For maps of few tiles (plan.fuse_wino_gemm_out)."""
-    _f32(B, scale, shift, resq)
-    n, cin, h, w = v.meta
-    cout, cin_k, kh, kw = Kq.shape
-    if cin_k != cin or (kh, kw) != (3, 3):
-        raise ValueError("conv: weight %s does not match input %s" % (Kq.shape, (n, cin, h, w)))
-    if resq is not None and (not is_q4(resq) or logical_shape(resq) != (n, cout, h, w)):
-        raise ValueError("fused residual %s != conv output %s" % (getattr(resq, "shape", None), (n, cout, h, w)))
-    y = _new_q4(n, cout, h, w, v.ctx)
-    _lib.call("pl_wino4_gemm_out_q4_f32", v.ctx.handle, v.ptr, n, cin, h, w, Kq.ptr, cout, _ptr(B), _ptr(scale), _ptr(shift),
-              _ptr(resq), int(act), float(alpha), y.ptr)
-    return y
-
-
 def Wino4Chain(m, B=None, scale=None, shift=None, resq=None, act=ACT_NONE, alpha=0.0, keep_y=True, **_):
     """Wino4Out and the Wino4In of the next 3x3 conv in one kernel: -> (y, V) or, with keep_y=False
     (nothing else reads y), V alone -- y then never exists in memory."""
@@ -686,7 +670,6 @@ def register(layer_map):
     """Plan-internal kinds (never present in a user's IR)."""
     layer_map.update({"to_q4": to_q4, "from_q4": from_q4, "conv_q4": ConvQ4, "upconcat_q4": UpConcatQ4,
                       "wino4_in": Wino4In, "wino4_gemm": Wino4Gemm, "wino4_out": Wino4Out, "wino4_chain": Wino4Chain,
-                      "wino4_gemm_out": Wino4GemmOut,
                       "conv_q4_pair": ConvQ4Pair, "conv_pool_q4": ConvPoolQ4, "conv1x1_wino_in": Conv1x1WinoIn,
                       "wino43_in": Wino43In, "wino43_gemm": Wino43Gemm, "wino43_out": Wino43Out, "wino43_chain": Wino43Chain})
     layer_map.update({k + "_q4": f for k, f in Q4_LAYERS.items()})

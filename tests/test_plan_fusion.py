@@ -313,32 +313,6 @@ def test_chain_winograd_merges_output_and_input_transforms():
         have |= set(dst if isinstance(dst, list) else [dst])
 
 
-def test_fuse_wino_gemm_out_merges_an_unchained_gemm_with_its_output_transform():
-    """plan.fuse_wino_gemm_out: `wino4_gemm` whose M only the next step's `wino4_out` reads -> one `wino4_gemm_out` step that
-    carries the GEMM's operands, then the tail's; chained convs and maps that are not small stay as they are."""
-    from planer_amd.plan import chain_winograd, fuse_wino_gemm_out
-    body, flow = _wino_prog()
-    b, f, _ = chain_winograd(body, flow)                       # c1..c3 chained, c4 ends in a lone output transform
-    b2, f2, n = fuse_wino_gemm_out(b, f)
-    kinds = {e[0]: e for e in b2}
-    seq = [(names[0], kinds[names[0]][1]) for _, names, _ in f2]
-    assert n == 1 and seq[-3:] == [("c4@gemmout", "wino4_gemm_out"), ("pool", "maxpool_q4"), ("out", "from_q4")]
-    assert ("c4@gemm", "wino4_gemm") not in seq and ("c4@out", "wino4_out") not in seq
-    step = [fl for fl in f2 if fl[1] == ["c4@gemmout"]][0]
-    assert step[0] == ["c4@V", "U4", "None", "s4", "t4", "y2"] and step[2] == "y4" and kinds["c4@gemmout"][2]["act"] == 1
-    assert seq.count(("c1@gemm", "wino4_gemm")) == 1           # a GEMM that feeds a chain step is left alone
-    # all four unchained: four fused steps; none when the maps are not small
-    b, f, _ = chain_winograd(body, flow, chain=False)
-    b3, f3, n3 = fuse_wino_gemm_out(b, f)
-    assert n3 == 4 and [e[1] for e in b3].count("wino4_gemm_out") == 4 and [e[1] for e in b3].count("wino4_in") == 4
-    b4, f4, n4 = fuse_wino_gemm_out(b, f, small=lambda key: key == "y3")
-    assert n4 == 1 and [e[0] for e in b4 if e[1] == "wino4_gemm_out"] == ["c3@gemmout"]
-    have = {"x", "None"} | {"U%d" % i for i in range(1, 5)} | {"s%d" % i for i in range(1, 5)} | {"t%d" % i for i in range(1, 5)}
-    for src, _, dst in f3:
-        assert all(k in have for k in src), (src, sorted(have))
-        have |= set(dst if isinstance(dst, list) else [dst])
-
-
 def test_chain_winograd_stages_only_and_unsupported_maps():
     from planer_amd.plan import chain_winograd
     body, flow = _wino_prog()
