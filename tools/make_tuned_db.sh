@@ -21,6 +21,7 @@ python tools/latency_bench.py > $out/fill_latency.log 2>&1
 : > $out/fill_more.jsonl
 for b in 1 8 16 64 256; do python tools/tune_fill.py resnet18 $b 2>>$out/fill_more.err | tail -1 >> $out/fill_more.jsonl; done
 for sz in 320 608; do python tools/tune_fill.py yolov3 1 $sz 2>>$out/fill_more.err | tail -1 >> $out/fill_more.jsonl; done
+python tools/tune_fill.py customnet 1 2>>$out/fill_more.err | tail -1 >> $out/fill_more.jsonl      # BASELINE config 1 (bench.py's extra.customnet_b1)
 cat $out/fill_more.jsonl
 # a second pass must find everything: its tune_source may not mention "autotuned"
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-e2e > $out/check_resnet18.json 2> $out/check_resnet18.err

@@ -1,15 +1,15 @@
 """GPU: fill the tuning caches (PLANER_HIP_TUNE_CACHE: launch plans + conv algorithms + stream plans) for one workload shape:
 the latency plan (net(x)) and the throughput plan, as tools/make_tuned_db.sh needs them for shapes bench.py does not run.
-    python tools/tune_fill.py resnet18|yolov3 <batch> [size]        -> one JSON line: compile seconds, misses, rates"""
+    python tools/tune_fill.py resnet18|yolov3|customnet <batch> [size]        -> one JSON line: compile seconds, misses, rates"""
 import json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import planer_amd
-from planer_amd.irgen import resnet18, yolov3
+from planer_amd.irgen import customnet, resnet18, yolov3
 which, batch = sys.argv[1], int(sys.argv[2])
-size = int(sys.argv[3]) if len(sys.argv) > 3 else (416 if which == "yolov3" else 224)
+size = int(sys.argv[3]) if len(sys.argv) > 3 else {"yolov3": 416, "customnet": 64}.get(which, 224)
 ctx = planer_amd.hip.context()
-g, b = (yolov3 if which == "yolov3" else resnet18).build()
+g, b = {"yolov3": yolov3, "customnet": customnet}.get(which, resnet18).build()
 xs = [planer_amd.asarray(np.random.default_rng(1 + i).standard_normal((batch, 3, size, size)).astype(np.float32), ctx=ctx) for i in range(2)]
 net = planer_amd.from_graph(g, b)
 t0 = time.perf_counter()
