@@ -621,7 +621,7 @@ def main():
     # ... and the same table gives the family's utilisation from the rocprofv3 kernel trace: executed FLOPs of its convs / the
     # summed average durations of ALL its kernels (roofline.frac_rocprof; the HIP-event figure above is the in-process estimate
     # of the same quantity and must agree with it)
-    frac_rocprof, rocprof_us = None, None
+    frac_rocprof, rocprof_us, gemm_us_rocprof = None, None, 0.0
     tpath = os.path.join(ROOT, "profiles", PROFILE_TAG + "_per_layer.csv")
     # (only for a run whose kernels ARE the profiled ones: every launch plan, algorithm and stream plan from the shipped database)
     if os.path.exists(tpath) and tune_src == "shipped":
@@ -634,6 +634,8 @@ def main():
                 if fam_of.get(base) != dom_name:
                     continue
                 us_sum += float(r["us_rocprof_avg"])
+                if split_step(r["layer"])[1] == "gemm":
+                    gemm_us_rocprof += float(r["us_rocprof_avg"])
                 if r.get("layer_executed_flops") not in (None, "", "None"):
                     exe_by_layer[base] = float(r["layer_executed_flops"])
                 if r.get("hbm_read_bytes") not in (None, ""):
@@ -662,6 +664,11 @@ def main():
         "achieved": round(tf(dom["executed"], dom["ms"]), 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
         "frac": round(tf(dom["executed"], dom["ms"]) / PEAK_FP32_MFMA_TFLOPS, 4),
         "frac_rocprof": frac_rocprof,
+        # the family's GEMM steps alone (20-30 us, compute-bound kernels: neither the tool's per-dispatch overhead on short kernels nor
+        # warm caches under the ten-fold repetition move them): HIP events against the committed trace
+        "gemm_steps": None if not gemm_us_rocprof else {
+            "us_hip_events": round(sum(r["ms"] for r in rows if r["kernel"] == dom_name and r["stage"] == "gemm") * 1e3, 2),
+            "us_rocprof": round(gemm_us_rocprof, 2)},
         "frac_rocprof_source": None if frac_rocprof is None else
         "profiles/%s_per_layer.csv: executed FLOPs of the family's convs / %.1f us = the summed average durations of all its "
         "kernels in the one-stream rocprofv3 kernel trace of this build (shipped tuning database)" % (PROFILE_TAG, rocprof_us),
