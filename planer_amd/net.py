@@ -1086,6 +1086,8 @@ class Net:
             if isinstance(plan, _MultiPlan) or not isinstance(a, DeviceArray):
                 if a is not s:
                     s.copy_from(a)
+                if s.prefed is not None or s.packed is not None:        # (a host array: through the static tensor, then the feed pass)
+                    _feed_static(self.ctx, s, s)
             else:
                 _feed_static(self.ctx, s, a)
 
