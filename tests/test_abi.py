@@ -98,3 +98,21 @@ def test_plan_dispatch_table_is_current():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_plan_dispatch.py"), "--check"])
     assert r.returncode == 0, "run tools/gen_plan_dispatch.py and rebuild"
+
+
+def test_stem_pool_shape_predicates_need_no_device():
+    """The plan compiler asks the library which stem shapes the one-kernel stem + max-pool paths take (host functions, no GPU):
+    3 channels, 7x7 / stride 2 / pad 3, Cout % 4 == 0 at any width; the form that reads the NCHW batch itself needs W % 4 == 0."""
+    from planer_amd import q4
+    para = dict(group=1, strides=[2, 2], dilations=[1, 1], pads=[3, 3, 3, 3])
+    for w, packed, nchw in ((224, True, True), (160, True, True), (1000, True, True), (37, True, False), (231, True, False), (8, True, True)):
+        assert q4.stem_pool_eligible((2, 3, 64, w), (64, 3, 7, 7), **para) is packed, w
+        assert q4.stem_pool_nchw_eligible((2, 3, 64, w), (64, 3, 7, 7), **para) is nchw, w
+    assert not q4.stem_pool_nchw_eligible((2, 3, 64, 64), (62, 3, 7, 7), **para)                     # Cout % 4
+    assert not q4.stem_pool_nchw_eligible((2, 3, 64, 64), (64, 3, 7, 7), **dict(para, strides=[1, 1]))
+    assert not q4.stem_pool_nchw_eligible((2, 4, 64, 64), (64, 4, 7, 7), **para)                     # 3 input channels only
+    assert not q4.stem_pool_nchw_eligible((2, 3, 64, 64), (64, 3, 3, 3), **dict(para, pads=[1, 1, 1, 1]))
+    n = __import__("ctypes").c_size_t()
+    from planer_amd import _lib
+    _lib.call("pl_conv2d_stem_nchw_filter_elems", 64, __import__("ctypes").byref(n))
+    assert n.value == 48 * 64 * 4                                                                    # [48 k-quads][Cout][4]
