@@ -510,7 +510,8 @@ def main():
     shapes[g["input"][0]] = xs[0].shape
     net._interpret(net._program, [xs[0].copy()], shapes=shapes)
     convs = conv_table(g, shapes)
-    prog, _ = net._fuse(shapes)
+    with net.picking("throughput"):           # the TIMED plan's program: throughput plans take the pipeline-judged algorithm picks
+        prog, _ = net._fuse(shapes)
     tbytes = transform_bytes(prog, convs)
     per_layer = {}
     prof_steps = min(max(args.steps, 5), 20)

@@ -128,14 +128,16 @@ def _place(events, pinned):
     return offsets, top
 
 
-def export_plan(net, *xs, path=None):
-    """-> bytes of the plan file for `net` on inputs shaped like `xs` (host arrays or DeviceArrays)."""
+def export_plan(net, *xs, path=None, mode="latency"):
+    """-> bytes of the plan file for `net` on inputs shaped like `xs` (host arrays or DeviceArrays).  `mode="throughput"`: the conv
+    algorithms a pipelined host (several plan instances on several streams) should run -- the pipeline-judged picks first."""
     ctx = net.ctx
     xs = [hip.asarray(numpy.asarray(a) if not isinstance(a, DeviceArray) else a, ctx=ctx) for a in xs]
     shapes = {k: a.shape for k, a in zip(net.input, xs)}
     shapes.update({k: w.shape for k, w in zip(net.inits, net.weights)})
     net._interpret(net._program, [a.copy() for a in xs], shapes=shapes)          # validates the graph, records every shape
-    prog, _ = net._fuse(shapes, net.use_fusion)
+    with net.picking(mode):
+        prog, _ = net._fuse(shapes, net.use_fusion)
     net._interpret(prog, [a.copy() for a in xs])                                 # warm: tuning, lazy uploads, pool sizes
     ctx.synchronize()
     kinds = {name: obj.name for name, obj in prog.objs.items()}

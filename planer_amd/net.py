@@ -302,6 +302,8 @@ class Net:
         self._plans = {}
         self._extra = {}             # derived constant tensors (tap-major / Winograd filters)
         self._algo = {}              # conv shape signature -> chosen w_layout
+        self._algo_tp = {}           # the same for THROUGHPUT plans where the pipeline's judge differs from the isolated one
+        self._pick_mode = None       # "throughput" while a throughput plan's program is being fused (Net.picking)
         self.wino_chains = 0         # F(4x4,3x3) output / input transform pairs the last plan runs as one kernel
         self.conv_pairs = 0          # sibling conv pairs the last plan runs as one launch
         self.conv_wino_fused = 0     # 1x1 convs the last plan runs inside the next conv's Winograd input transform
@@ -641,6 +643,12 @@ class Net:
                 raise ValueError("force_algo=%r does not apply to conv %s k%s" % (self.force_algo, xs, tuple(K.shape)))
             return self.force_algo
         self._load_algo_cache()
+        # Throughput plans first ask the table of picks made UNDER the pipeline (tools/pipeline_search.py): a kernel that holds
+        # a fraction of the CUs for longer loses an isolated timing and can win there -- the other replicas' kernels take the rest
+        # of the chip (ResNet-18 layer2 at batch 32: the fused F(4x4,3x3) kernel on 128 workgroups, 63 us against 43 us staged, and
+        # +1.9 % on seven replicas).  Latency plans (net(x) one call at a time) keep the isolated picks.
+        if self._pick_mode == "throughput" and self._algo_tp.get(sig) in [c[0] for c in cands]:
+            return self._algo_tp[sig]
         if sig in self._algo and self._algo[sig] in [c[0] for c in cands]:      # (a stored pick this run's switches exclude is ignored)
             return self._algo[sig]
         self.algo_misses += 1
@@ -715,11 +723,12 @@ class Net:
                 stored = {"device": None, "algo": stored, "streams": {}}
             if stored.get("device") not in (None, self._device_tag()):
                 continue
-            for k, v in stored.get("algo", {}).items():
-                try:
-                    self._algo[ast.literal_eval(k)] = int(v)
-                except (ValueError, SyntaxError):
-                    pass
+            for table, dst in (("algo", self._algo), ("algo_throughput", self._algo_tp)):
+                for k, v in stored.get(table, {}).items():
+                    try:
+                        dst[ast.literal_eval(k)] = int(v)
+                    except (ValueError, SyntaxError):
+                        pass
             self._streams_pick.update({str(k): str(v) for k, v in stored.get("streams", {}).items()})
 
     def save_algo_cache(self, path=None):
@@ -731,6 +740,7 @@ class Net:
         import json
         data = {"device": self._device_tag(),
                 "algo": {self._sig_key(k): v for k, v in sorted(self._algo.items(), key=repr)},
+                "algo_throughput": {self._sig_key(k): v for k, v in sorted(self._algo_tp.items(), key=repr)},
                 "streams": dict(sorted(self._streams_pick.items()))}
         tmp = "%s.%d.tmp" % (path, os.getpid())
         with open(tmp, "w") as f:
@@ -758,7 +768,25 @@ class Net:
         what = "autotuned: %d launch plans, %d conv algorithms, %d stream plans" % (plan_misses, self.algo_misses, self.stream_misses)
         return "%s; %s" % (base, what) if base else what
 
+    def picking(self, mode):
+        """Context: programs fused inside take the conv algorithms of `mode` ("throughput": the pipeline-judged table first)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            prev, self._pick_mode = self._pick_mode, mode
+            try:
+                yield self
+            finally:
+                self._pick_mode = prev
+        return cm()
+
     def compile(self, *xs, mode="latency"):
+        """(see _compile: the plan's program is fused under this mode's conv algorithm tables)"""
+        with self.picking(mode):
+            return self._compile(*xs, mode=mode)
+
+    def _compile(self, *xs, mode="latency"):
         """Build (or fetch) the captured plan for these device inputs.  `mode` only affects how
         the number of sub-batch streams is chosen: "latency" measures fork/join passes (what
         __call__ does), "throughput" measures free-running back-to-back passes."""

@@ -65,15 +65,17 @@ def test_bench_default_command_prints_one_contract_line():
     # round 4: the in-process (HIP-event) utilisation of the dominant family against the one recomputed from the committed
     # rocprofv3 kernel trace of this build (profiles/<tag>_per_layer.csv) -- when that table describes this run's kernels
     # (shipped tuning database), the two may differ by the run-to-run spread of short kernels, not by a definition
-    # (round 5: the two readings of the whole family differ by a systematic 4.3 % -- 11.7 us of 250: the tool adds 0.5-1.5 us to
-    #  each 5-14 us transform kernel, and the in-process pass launches every step ten times between two markers, so a transform finds its
-    #  12.8 MB input in the Infinity Cache (l20b@in: 10.4 against 13.7 us) -- and the in-process figure moves +-1.2 % run to run
-    #  (0.320-0.3275 over 17 runs against 0.3116): asserted at 6.5 %.  The family's GEMM steps, which neither effect touches, must
-    #  agree within 3 %.)
+    # (round 5: for a family of STAGED convs the two readings differ by a systematic 4.3 % -- the tool adds 0.5-1.5 us to each 5-14 us
+    #  transform kernel, and the in-process pass launches every step ten times between two markers, so a transform finds its input in
+    #  the Infinity Cache -- on top of +-1.2 % from run to run: asserted at 6.5 %, with the family's GEMM steps, which neither effect
+    #  touches, within 3 %.  A family of one-kernel convs -- the fused F(4x4,3x3) kernel, dominant since layer2 joined it in throughput
+    #  plans -- has neither effect: 5 %.)
     if rf.get("frac_rocprof") and d["config"]["tune_source"] == "shipped":
-        assert abs(rf["frac"] - rf["frac_rocprof"]) <= 0.065 * rf["frac_rocprof"], (rf["frac"], rf["frac_rocprof"])
-        gs = rf["gemm_steps"]
-        assert gs and abs(gs["us_hip_events"] - gs["us_rocprof"]) <= 0.03 * gs["us_rocprof"], gs
+        gs = rf.get("gemm_steps")
+        tol = 0.065 if gs else 0.05
+        assert abs(rf["frac"] - rf["frac_rocprof"]) <= tol * rf["frac_rocprof"], (rf["frac"], rf["frac_rocprof"])
+        if gs:
+            assert abs(gs["us_hip_events"] - gs["us_rocprof"]) <= 0.03 * gs["us_rocprof"], gs
     # the reference-shaped entry points on resident batches: net(x) and the asynchronous net.submit(x)
     assert d["config"]["net_call_images_per_sec"] > 10000
     assert d["config"]["net_submit_images_per_sec"] >= 0.93 * d["value"]

@@ -77,6 +77,36 @@ def test_throughput_plan_batch32_full_size(pa, r18, streams):
             assert r <= 1.0
 
 
+def test_throughput_plans_take_the_pipeline_judged_picks(pa, r18):
+    """Round 5: throughput plans ask the database's `algo_throughput` table first (picks made under the seven-replica pipeline,
+    tools/pipeline_search.py) -- ResNet-18 layer2 at batch 32 runs the fused F(4x4,3x3) kernel there (128 workgroups for 63 us:
+    slower alone, +1.9 % pipelined) -- while the latency plan behind net(x) keeps the isolated picks (staged F(4x4,3x3)).  Both
+    match the oracle; a net without the table falls back to the isolated picks in both modes."""
+    g, b, ref = r18
+    x = resnet18.make_input(32, seed=77)
+    want = ref(x.copy())
+    d = pa.asarray(x)
+    net = pa.from_graph(g, b)
+    net._load_algo_cache()
+    if not net._algo_tp:
+        pytest.skip("no throughput table in the database of this device")
+    lay = lambda plan: {a["layer"].split("@")[0].rstrip("+"): a["w_layout"] for a in plan.algos}
+    tp = net.compile(d, mode="throughput")
+    lat = net.compile(d, mode="latency")
+    for name in ("l20b_conv", "l21a_conv", "l21b_conv"):
+        assert lay(tp)[name] == 9 and lay(lat)[name] == 7, (name, lay(tp)[name], lay(lat)[name])
+    assert {k: v for k, v in lay(tp).items() if not k.startswith("l2")} == {k: v for k, v in lay(lat).items() if not k.startswith("l2")}
+    tp.feed([d]); tp.launch(join=False); tp.join(); net.ctx.synchronize()
+    o = tp.outputs
+    assert_close((o[0] if isinstance(o, tuple) else o).get(), want, RTOL, "throughput plan")
+    y = net(d)
+    assert_close((y[0] if isinstance(y, tuple) else y).get(), want, RTOL, "latency plan")
+    bare = pa.from_graph(g, b)
+    bare._load_algo_cache()
+    bare._algo_tp.clear()
+    assert lay(bare.compile(d, mode="throughput")) == lay(lat)
+
+
 LAYER_SHAPES = [(64, 56), (128, 28), (256, 14), (512, 7)]       # ResNet-18 layer1..4 stride-1 3x3 convs
 ALGOS = [2, 8, 4, 7, 9]      # 9 = the fully fused F(4x4,3x3) kernel (conv_wf4_kernel), what layer1 runs
 

@@ -7,7 +7,8 @@ import numpy as np
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 B = int(os.environ.get("BATCH", "32"))
-path = "/tmp/resnet18_b%d.plplan" % B
+MODE = os.environ.get("MODE", "throughput")          # which conv algorithm table the exported pass takes (latency / throughput)
+path = "/tmp/resnet18_b%d_%s.plplan" % (B, MODE)
 x = np.random.default_rng(1).standard_normal((B, 3, 224, 224)).astype(np.float32)
 if not os.path.exists(path):
     import planer_amd
@@ -16,7 +17,7 @@ if not os.path.exists(path):
     g, b = resnet18.build()
     net = planer_amd.from_graph(g, b)
     t0 = time.perf_counter()
-    export_plan(net, x, path=path)
+    export_plan(net, x, path=path, mode=MODE)
     print("exported %s: %.1f MB in %.2f s" % (path, os.path.getsize(path) / 1e6, time.perf_counter() - t0))
     want = net(x)
 else:
