@@ -57,7 +57,7 @@ def test_bench_default_command_prints_one_contract_line():
     assert d["config"]["rccl_ranks"] == 1 and d["config"]["tune_source"]
     assert all(r["executed_flops"] for r in d["per_layer"] if r["algorithmic_flops"])
     steps = d["config"]["plan_steps"]
-    assert len(steps) >= 30 and all(len(s) == 2 for s in steps)
+    assert len(steps) >= 25 and all(len(s) == 2 for s in steps)      # (29 since layer2 runs the one-kernel convs in throughput plans)
     if d["config"]["wino_chains"]:
         kinds = [k for _, k in steps]
         assert kinds.count("wino4_chain") + kinds.count("wino43_chain") == d["config"]["wino_chains"]      # (F(4x4) and mixed-tile chains)
