@@ -997,6 +997,23 @@ int wf4_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const
     int BC = 1, BR = 1, lBC = 0, lBR = 0;
     while (BC < a.tw && BC < 16) BC *= 2, ++lBC;
     while (BR < a.th && BR * BC < 32) BR *= 2, ++lBR;
+    // Fewer tile rows per block and more images instead, where that needs fewer 32-tile blocks: 7 tile rows (a 28-pixel map) are
+    // two blocks of 4 rows per image (64 slots for 49 tiles) but seven blocks of 1 row x 4 images (56 slots per image quartet's
+    // 49 x 4 / 4) -- 112 instead of 128 workgroups for ResNet-18's layer2 at batch 32.  Ties keep the taller block (less halo in
+    // the patch).  PLANER_HIP_EXPERIMENT=wf4_br=<rows> forces.
+    {
+        auto blocks_of = [&](int br) { const int nb = 32 / (br * BC); return (long long)((N + nb - 1) / nb) * ((a.th + br - 1) / br); };
+        int best_br = BR, best_l = lBR;
+        for (int br = BR / 2, l = lBR - 1; br >= 1; br /= 2, --l)
+            if (blocks_of(br) < blocks_of(best_br) && (32 / (br * BC)) * (4 * br + 2) * 4 * (BC + 1) <= WF4_P_CELLS) best_br = br, best_l = l;
+        const int force = pl_experiment("wf4_br", 0);
+        if (force > 0 && force <= BR && (force & (force - 1)) == 0 && (32 / (force * BC)) * (4 * force + 2) * 4 * (BC + 1) <= WF4_P_CELLS) {
+            best_br = force;
+            best_l = 0;
+            while ((1 << best_l) < force) ++best_l;
+        }
+        BR = best_br; lBR = best_l;
+    }
     const int NB = 32 / (BR * BC);
     a.lBR = lBR; a.lBC = lBC;
     a.R = 4 * BR + 2; a.S = BC + 1;
