@@ -225,14 +225,16 @@ int pl_conv2d_rowpacked_pool_q4_f32(pl_ctx *ctx, const float *xp, int N, int Cin
                                     const float *shift, int act, double alpha);
 /* The same kernel reading the reference's NCHW input itself (no row-packed copy of the batch; util.conv_for util.py:17-44 gathers
  * from the padded NCHW tensor too): 3 channels, 7x7 / stride 2 / pad 3, W % 4 == 0, x 16-byte aligned.  wq = the filter in this
- * kernel's k order, [48][Cout][4] floats (_filter_elems) made by pl_conv2d_prepare_stem_nchw_f32 from OIHW [Cout][3][7][7]. */
+ * kernel's k order, [48][Cout][4] floats (_filter_elems) made by pl_conv2d_prepare_stem_nchw_f32 from OIHW [Cout][3][7][7].
+ * strip_rows: pooled rows per workgroup strip -- 0 or 7 (one workgroup per CU at batch 32 / 224 px), or 14: half the workgroups
+ * running 15 instead of 2 x 8 conv-row pairs, slower alone and cheaper for a pipelined host. */
 int pl_conv2d_stem_pool_nchw_supported(int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw, int pt,
                                        int pl, int *ok);
 int pl_conv2d_stem_nchw_filter_elems(int Cout, size_t *elems);
 int pl_conv2d_prepare_stem_nchw_f32(pl_ctx *ctx, const float *w, int Cout, float *out);
 int pl_conv2d_stem_pool_nchw_q4_f32(pl_ctx *ctx, const float *x, int N, int H, int W, const float *wq, int Cout,
                                     const float *bias, float *yq, const float *scale, const float *shift,
-                                    int act, double alpha);
+                                    int act, double alpha, int strip_rows);
 /* Winograd F(4x4,3x3) on Q4 tensors (same constraints as the F(2x2,3x3) entry points): 6x6 input
  * tiles, 36 grouped GEMMs, 4x fewer multiplies than the direct conv and less transform traffic
  * than F(2x2,3x3); larger transform constants, error a few 1e-6 of max|y| in fp32.

@@ -106,7 +106,7 @@ SIGNATURES = {
     "pl_conv2d_stem_pool_nchw_supported": [_I] * 10 + [POINTER(c_int)],
     "pl_conv2d_stem_nchw_filter_elems": [_I, POINTER(c_size_t)],
     "pl_conv2d_prepare_stem_nchw_f32": [_P, _P, _I, _P],
-    "pl_conv2d_stem_pool_nchw_q4_f32": [_P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _I, c_double],
+    "pl_conv2d_stem_pool_nchw_q4_f32": [_P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _I, c_double, _I],
     "pl_conv2d_w1d4_q4_filter_elems": [_I, _I, POINTER(c_size_t)],
     "pl_conv2d_prepare_w1d4_q4_f32": [_P, _P, _I, _I, _P],
     "pl_conv2d_w1d4_q4_f32": [_P, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, c_double],

@@ -1600,7 +1600,8 @@ int pl_conv2d_rowpacked_pool_q4_f32(pl_ctx *ctx, const float *xp, int N, int Cin
     a.Ho = (H + 2 * pt - kh + sh) / sh; a.Wo = (W + 2 * pl - kw + sw) / sw;
     a.Hq = (a.Ho + 1) / 2; a.Wq = (a.Wo + 1) / 2;            // (Ho + 2 - 3 + 2) // 2, util.py:84-85
     a.Cout = Cout; a.Coq = Cout / 4;
-    a.strips = (a.Hq + SP_PROWS - 1) / SP_PROWS;
+    a.prows = SP_PROWS; a.steps = a.prows + 1;
+    a.strips = (a.Hq + a.prows - 1) / a.prows;
     a.cout_blocks = (Cout + 63) / 64;
     const int q_pad = (kh * ((kw * Cin + 3) / 4) + 7) / 8 * 8;
     const size_t yb = (size_t)N * a.Coq * a.Hq * a.Wq * 16;
@@ -1629,7 +1630,7 @@ int pl_conv2d_rowpacked_pool_q4_f32(pl_ctx *ctx, const float *xp, int N, int Cin
     ctx->last_plan = buf;
     // executed MFMA work: 16 conv rows per strip, 16 nb columns per chunk, K = 176
     ctx->last_gemm[0] = 1; ctx->last_gemm[1] = (long long)a.cout_blocks * 64;
-    ctx->last_gemm[2] = (long long)N * a.strips * a.chunks * 16 * 16 * nb; ctx->last_gemm[3] = 16 * SP_GROUPS;
+    ctx->last_gemm[2] = (long long)N * a.strips * a.chunks * 2 * a.steps * 16 * nb; ctx->last_gemm[3] = 16 * SP_GROUPS;
     return PL_OK;
 }
 
@@ -1661,13 +1662,14 @@ int pl_conv2d_prepare_stem_nchw_f32(pl_ctx *ctx, const float *w, int Cout, float
 }
 
 int pl_conv2d_stem_pool_nchw_q4_f32(pl_ctx *ctx, const float *x, int N, int H, int W, const float *wq, int Cout, const float *bias,
-                                    float *yq, const float *scale, const float *shift, int act, double alpha) {
+                                    float *yq, const float *scale, const float *shift, int act, double alpha, int strip_rows) {
     const int Cin = 3, kh = SP_KH, kw = 7, sh = 2, sw = 2, pt = 3, pl = 3;
     int rc = rowpack_check(ctx, x, N, Cin, H, W, wq, Cout, kh, kw, yq, sh, sw, pt, pl, nullptr);
     if (rc != PL_OK) return rc;
     PL_REQUIRE(stem_pool_shape_ok(Cin, H, W, Cout, kh, kw, sh, sw, pt, pl) && W % 4 == 0, PL_EUNSUPPORTED,
                "conv + maxpool (NCHW stem): 3 channels, 7x7 / stride 2 / pad 3, W %% 4 == 0, Cout %% 4 == 0");
     PL_REQUIRE(act >= 0 && act <= 2, PL_EINVAL, "pl_conv2d_stem_pool_nchw_q4_f32: bad activation code");
+    PL_REQUIRE(strip_rows == 0 || strip_rows == 7 || strip_rows == 14, PL_EINVAL, "pl_conv2d_stem_pool_nchw_q4_f32: strip_rows is 0 (= 7), 7 or 14");
     PL_REQUIRE(((reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift) |
                  reinterpret_cast<uintptr_t>(x)) & 15u) == 0,
                PL_EINVAL, "pl_conv2d_stem_pool_nchw_q4_f32: x / bias / scale / shift are read as 16-byte quads");
@@ -1680,7 +1682,9 @@ int pl_conv2d_stem_pool_nchw_q4_f32(pl_ctx *ctx, const float *x, int N, int H, i
     a.Ho = (H + 2 * pt - kh + sh) / sh; a.Wo = (W + 2 * pl - kw + sw) / sw;
     a.Hq = (a.Ho + 1) / 2; a.Wq = (a.Wo + 1) / 2;            // (Ho + 2 - 3 + 2) // 2, util.py:84-85
     a.Cout = Cout; a.Coq = Cout / 4;
-    a.strips = (a.Hq + SP_PROWS - 1) / SP_PROWS;
+    a.prows = strip_rows == 14 ? 14 : SP_PROWS;      // (14: half the workgroups, 15 steps instead of 2 x 8)
+    a.steps = a.prows + 1;
+    a.strips = (a.Hq + a.prows - 1) / a.prows;
     a.cout_blocks = (Cout + 63) / 64;
     const int q_pad = (4 * SP_GROUPS + 7) / 8 * 8;
     const size_t xb = (size_t)N * Cin * H * W * 4, yb = (size_t)N * a.Coq * a.Hq * a.Wq * 16;
@@ -1704,10 +1708,10 @@ int pl_conv2d_stem_pool_nchw_q4_f32(pl_ctx *ctx, const float *x, int N, int H, i
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), 0, ctx->stream, a);
     PL_LAUNCH_CHECK();
     char buf[112];
-    snprintf(buf, sizeof buf, "stem+maxpool(nchw) 64co x 2 rows x %dpx, strips=%d chunks=%d blocks=%lld", 16 * nb, a.strips, a.chunks, blocks);
+    snprintf(buf, sizeof buf, "stem+maxpool(nchw) 64co x 2 rows x %dpx, strips=%d of %d rows, chunks=%d blocks=%lld", 16 * nb, a.strips, a.prows, a.chunks, blocks);
     ctx->last_plan = buf;
     ctx->last_gemm[0] = 1; ctx->last_gemm[1] = (long long)a.cout_blocks * 64;
-    ctx->last_gemm[2] = (long long)N * a.strips * a.chunks * 16 * 16 * nb; ctx->last_gemm[3] = 16 * SP_GROUPS;
+    ctx->last_gemm[2] = (long long)N * a.strips * a.chunks * 2 * a.steps * 16 * nb; ctx->last_gemm[3] = 16 * SP_GROUPS;
     return PL_OK;
 }
 

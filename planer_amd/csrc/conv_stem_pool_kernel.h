@@ -48,7 +48,8 @@ struct StemPoolArgs {
     int N, Hp, rowf;       // packed rows per image, floats per packed row
     int H, W;              // NCHW: the input's height and width
     int Ho, Wo, Hq, Wq, Cout, Coq;
-    int strips;            // strips of 7 pooled rows per image
+    int strips;            // strips of `prows` pooled rows per image
+    int prows, steps;      // pooled rows per strip (7; 14: half the workgroups, 15 steps instead of 2 x 8), conv-row pairs per strip = prows + 1
     int cout_blocks;
     int chunks, pq;        // column chunks per strip, pooled columns per chunk
     unsigned x_bytes, w_bytes, y_bytes;
@@ -101,7 +102,7 @@ __global__ void __launch_bounds__(512) conv_stem_pool_kernel(const StemPoolArgs 
     const int q0 = (int)chunk * p.pq;                       // first pooled column this workgroup stores
     const int x0 = chunk ? 2 * q0 - 2 : 0;                  // its first conv column; local pooled column l is global x0 / 2 + l
     const int lskip = chunk ? 1 : 0, qend = min(q0 + p.pq, p.Wq);
-    const int p0 = (int)strip * SP_PROWS;                   // first pooled row of the strip
+    const int p0 = (int)strip * p.prows;                    // first pooled row of the strip
     const int c0 = 2 * p0 - 1;                              // first conv row: the one above the first window's centre
     const int co0 = (int)cob * 64;
 
@@ -246,7 +247,7 @@ __global__ void __launch_bounds__(512) conv_stem_pool_kernel(const StemPoolArgs 
         const float *Xb = cur ? X1 : X0;
         sp_f32x4 (&acc)[SP_NB] = cur ? accB : accA;
         const sp_f32x4 (&old)[SP_NB] = cur ? accA : accB;
-        if (t + 1 < 8) load_rows(t + 1, std::integral_constant<bool, !cur>{});
+        if (t + 1 < p.steps) load_rows(t + 1, std::integral_constant<bool, !cur>{});
 #pragma unroll
         for (int nb = 0; nb < SP_NB; ++nb) acc[nb] = (sp_f32x4){0.f, 0.f, 0.f, 0.f};
         // fragments one group ahead, in two register sets that alternate (no copies: a copy is a v_mov, and fp32 VALU work
@@ -290,19 +291,20 @@ __global__ void __launch_bounds__(512) conv_stem_pool_kernel(const StemPoolArgs 
         // the next rows have landed (vmcnt), this step's row buffer and the ring rows read by the pooling are free again
         __syncthreads();
     };
-    for (int t = 0; t < 8; t += 2) {
+    for (int t = 0; t < p.steps; t += 2) {
         step(t, std::false_type{});
-        step(t + 1, std::true_type{});
+        if (t + 1 < p.steps) step(t + 1, std::true_type{});
     }
-    // drain: tail of step 7, pooled row 6
-    {
-        const sp_f32x4 (&old)[SP_NB] = accB;
+    // drain: tail of the last step (its accumulator set by parity), last pooled row
+    auto drain = [&](const sp_f32x4 (&old)[SP_NB]) {
 #pragma unroll
-        for (int nb = 0; nb < SP_NB; ++nb) tail_block(old, nb, 14 + rsel);
+        for (int nb = 0; nb < SP_NB; ++nb) tail_block(old, nb, 2 * (p.steps - 1) + rsel);
         lds_barrier();
-        pool_half(6, 0);
-        pool_half(6, 1);
-    }
+        pool_half(p.prows - 1, 0);
+        pool_half(p.prows - 1, 1);
+    };
+    if ((p.steps - 1) & 1) drain(accB);
+    else drain(accA);
 }
 
 // OIHW stem filter [Cout][3][7][7] -> [k-quad q][Cout][4] in the NCHW kernel's k order: quad q = 4 u + kk holds taps

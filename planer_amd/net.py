@@ -608,7 +608,15 @@ class Net:
                         if key not in self._extra:
                             self._extra[key] = _q4.prepare_stem_nchw_weights(dict(zip(self.inits, self.weights))[src[1][:-len("@rowpack")]])
                         fsrc[1] = key
-                    body[names[0]] = [entry[0], "conv_pool_q4", dict(entry[2], w_layout=lay)]
+                    extra = {}
+                    if lay == 12 and self._pick_mode == "throughput" and os.environ.get("PLANER_HIP_STEM_ROWS14", "1") != "0":
+                        # throughput plans: strips of 14 pooled rows where that still leaves half a chip of workgroups -- 15
+                        # conv-row pairs instead of 2 x 8, on half the CUs for longer (160 against 91 us alone; +0.8 ... +1.2 % on
+                        # seven replicas: the other replicas' kernels take the rest of the chip)
+                        hq = ((xs[2] + 6 - 7) // 2 + 1 + 1) // 2
+                        if xs[0] * (-(-hq // 14)) * (-(-ks[0] // 64)) * 2 >= self.ctx.cu_count:
+                            extra["strip_rows"] = 14
+                    body[names[0]] = [entry[0], "conv_pool_q4", dict(entry[2], w_layout=lay, **extra)]
                     out.append([fsrc, names, pdst])
                     drop.add(j)
                     continue
@@ -1074,7 +1082,7 @@ class Net:
                 fpara = {a: b for a, b in para.items() if a != "w_layout"}
                 pooled = _q4.ConvPoolQ4(s_, *args, w_layout=12, **fpara)
                 s_.prefed = (_q4.stem_pool_feeder(s_.shape, args[0], args[1], args[2], args[3], fpara.get("act", 0),
-                                                  fpara.get("alpha", 0.0), pooled), pooled)
+                                                  fpara.get("alpha", 0.0), pooled, fpara.get("strip_rows", 0)), pooled)
                 continue
             if (obj.name not in ("conv_q4", "conv_pool_q4") or para.get("w_layout") not in (6, 10) or _as_list(src)[0] != k
                     or _as_list(src).count(k) != 1):

@@ -309,7 +309,7 @@ def stem_pool_nchw_eligible(x_shape, k_shape, group=1, strides=(1, 1), dilations
 
 
 def ConvPoolQ4(x, Kq, B=None, scale=None, shift=None, group=1, strides=(1, 1), dilations=(1, 1), pads=(0, 0, 0, 0),
-               act=ACT_NONE, alpha=0.0, w_layout=10, out=None, src_ptr=None, ctx=None, **_):
+               act=ACT_NONE, alpha=0.0, w_layout=10, out=None, src_ptr=None, ctx=None, strip_rows=0, **_):
     """Row-packed stem conv (ConvQ4 w_layout 6: NCHW input, filter from prepare_rowpack_weights) with its fused tail, followed
     by layer.Maxpool(w=(3, 3), strides=(2, 2), pads=(1, 1, 1, 1)) (layer.py:71-72), in ONE kernel: only the pooled Q4 tensor is
     written.  Emitted by the plan compiler (Net._fuse_stem_pool) where the max-pool is the conv's only reader.
@@ -334,7 +334,7 @@ def ConvPoolQ4(x, Kq, B=None, scale=None, shift=None, group=1, strides=(1, 1), d
             raise NotImplementedError("the NCHW stem + max-pool kernel needs W % 4 == 0 and a 16-byte aligned input")
         y = out if out is not None else _new_q4(n, cout, (ho + 1) // 2, (wo + 1) // 2, cx)
         _lib.call("pl_conv2d_stem_pool_nchw_q4_f32", cx.handle, xptr, n, h, w, Kq.ptr, cout, _ptr(B), y.ptr, _ptr(scale),
-                  _ptr(shift), int(act), float(alpha))
+                  _ptr(shift), int(act), float(alpha), int(strip_rows))
         return y
     geom = (kw, strides[1], pads[0], pads[1])
     if x.packed is not None and x.packed[0] == geom:
@@ -350,7 +350,7 @@ def ConvPoolQ4(x, Kq, B=None, scale=None, shift=None, group=1, strides=(1, 1), d
     return y
 
 
-def stem_pool_feeder(x_shape, Kq, B, scale, shift, act, alpha, pooled):
+def stem_pool_feeder(x_shape, Kq, B, scale, shift, act, alpha, pooled, strip_rows=0):
     """feed(src_ptr, ctx): the NCHW stem + max-pool kernel from the batch at `src_ptr` into the persistent tensor `pooled`, on
     `ctx`'s stream -- what `DeviceArray.prefed` holds for a plan's static input (Net._pack_static_inputs)."""
     n, _, h, w = (int(v) for v in x_shape)
@@ -358,7 +358,7 @@ def stem_pool_feeder(x_shape, Kq, B, scale, shift, act, alpha, pooled):
 
     def feed(src_ptr, ctx):
         _lib.call("pl_conv2d_stem_pool_nchw_q4_f32", ctx.handle, src_ptr, n, h, w, Kq.ptr, cout, _ptr(B), pooled.ptr, _ptr(scale),
-                  _ptr(shift), int(act), float(alpha))
+                  _ptr(shift), int(act), float(alpha), int(strip_rows))
     return feed
 
 

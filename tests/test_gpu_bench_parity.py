@@ -96,6 +96,9 @@ def test_throughput_plans_take_the_pipeline_judged_picks(pa, r18):
     for name in ("l20b_conv", "l21a_conv", "l21b_conv"):
         assert lay(tp)[name] == 9 and lay(lat)[name] == 7, (name, lay(tp)[name], lay(lat)[name])
     assert {k: v for k, v in lay(tp).items() if not k.startswith("l2")} == {k: v for k, v in lay(lat).items() if not k.startswith("l2")}
+    # ... and the stem + max-pool kernel runs strips of 14 pooled rows on half the workgroups there (7 rows in the latency plan)
+    stem = lambda plan: [a["plan"] for a in plan.algos if a["kind"] == "conv_pool_q4"][0]
+    assert "of 14 rows" in stem(tp) and "of 7 rows" in stem(lat), (stem(tp), stem(lat))
     tp.feed([d]); tp.launch(join=False); tp.join(); net.ctx.synchronize()
     o = tp.outputs
     assert_close((o[0] if isinstance(o, tuple) else o).get(), want, RTOL, "throughput plan")

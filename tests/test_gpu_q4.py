@@ -241,6 +241,10 @@ def test_stem_conv_maxpool_marching_kernel_matches_oracle(pa):
             assert_close(gotn, want, RTOL, "stem + maxpool, NCHW input %s" % ((n, h, cout, act, tail, wd),))
             assert_close(direct.get(), one.get(), 1e-5, "NCHW-reading kernel vs row-packed kernel")
             np.testing.assert_array_equal(direct.get(), q4_host(gotn))
+            # strips of 14 pooled rows (what throughput plans take at batch 32): half the workgroups, the same arithmetic
+            tall = q4.ConvPoolQ4(dx, Kn, dB, dsc, dsh, act=act, alpha=0.1, w_layout=12, strip_rows=14, **para)
+            assert "of 14 rows" in pa.hip.context().last_conv_plan(), pa.hip.context().last_conv_plan()
+            np.testing.assert_array_equal(tall.get(), direct.get())
     with pytest.raises(NotImplementedError):
         q4.ConvPoolQ4(pa.asarray(np.zeros((1, 3, 64, 30), np.float32)), q4.prepare_stem_nchw_weights(pa.asarray(K[:8])), w_layout=12, **para)
     assert q4.stem_pool_eligible((1, 3, 224, 200), (64, 3, 7, 7), **para)
