@@ -25,9 +25,10 @@ python tools/tune_fill.py customnet 1 2>>$out/fill_more.err | tail -1 >> $out/fi
 cat $out/fill_more.jsonl
 # a second pass must find everything: its tune_source may not mention "autotuned"
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-e2e > $out/check_resnet18.json 2> $out/check_resnet18.err
+# picks judged under the seven-replica pipeline (table "algo_throughput": asked first by throughput plans);
+# the search reads and extends the cache this script has just filled
+STREAMS=pipe7 python tools/pipeline_search.py --cands 2,8,4,7,9,11 --write $out/$stem.plans.algo.json > $out/pipeline_search.log 2>&1; tail -2 $out/pipeline_search.log
 mv $out/$stem.plans.algo.json $out/$stem.algo.json
-# picks judged under the seven-replica pipeline (table "algo_throughput": asked first by throughput plans)
-PLANER_HIP_TUNE_CACHE=$out/$stem.plans.search STREAMS=pipe7 python tools/pipeline_search.py --cands 2,8,4,7,9,11 --write $out/$stem.algo.json > $out/pipeline_search.log 2>&1; tail -2 $out/pipeline_search.log
 python - <<PY
 import json
 d = json.load(open("$out/check_resnet18.json"))
