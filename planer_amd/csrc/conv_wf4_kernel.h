@@ -40,6 +40,10 @@ struct Wf4Args {
     int R, S;              // patch rows 4 BR + 2; 16-byte cells per x phase BC + 1
     int cells;             // NB * R * 4 * S cells of one patch
     int rblocks, cblocks, cout_blocks;
+    // PACK: the block's spare slot columns (BC - tw of them, one image per block, one column block) carry tiles of a DONOR image --
+    // of every G = tw / sc + 1 images the last one is cut into (th / BR) x (tw / sc) groups of BR x sc tiles, one per block of the
+    // other G - 1: no padding slots (a 56-pixel map: 196 real tiles in 7 blocks of 32 per image -> 49 blocks per 8 images instead of 56)
+    int pack_sc, pack_g, pack_gc;      // spare columns, images per group, donor groups per tile row (tw / sc); 0: off
     unsigned x_bytes, u_bytes, y_bytes;
     FastDiv divPlane, div4S, divS, divCoB, divCb, divRb;
     Epilogue ep;
@@ -275,12 +279,13 @@ __device__ __forceinline__ void wf4_output_row_coalesced(const Wf4Args &p, const
 // registers; PLANAR -- the patch is stored channel-planar (transform lanes = 16 tiles x 4 channels, tile fastest: conflict-free
 // patch reads AND 2-way instead of 4-way conflicts on the V writes) instead of as 16-byte cells (lanes channel fastest);
 // STAGGER -- waves 4-7 transform before their MFMAs and waves 0-3 after, so the two waves of a SIMD alternate on its matrix pipe.
-template <bool DMA_A, bool PLANAR, bool STAGGER, int LBC>
+template <bool DMA_A, bool PLANAR, bool STAGGER, int LBC, bool PACK = false>
 __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
     // the LDS-DMA requests of a step go out one per MFMA group (measured: 40.9 -> 39.8 us per layer1 conv against all seven
     // in a row at the head of the step)
     constexpr bool SPREAD = DMA_A && !PLANAR && STAGGER;
-    constexpr int S = (1 << LBC) + 1;               // 16-byte cells per x phase: compile time, so every patch read is base + immediate
+    constexpr int S = (1 << LBC) + 1 + (PACK ? 1 : 0);      // 16-byte cells per x phase: compile time, so every patch read is base + immediate
+    static_assert(!PACK || !PLANAR, "packed blocks: 16-byte-cell patch layout only");
     // six separate LDS objects (not one dynamic array): the compiler orders LDS-DMA against later LDS accesses object by
     // object, so a DMA into A1 / P0 does not hold up the reads of A0 / P1 / V0 and the writes of V1
     __shared__ __attribute__((aligned(16))) float As0[WF4_A_FLOATS], As1[WF4_A_FLOATS];      // [4 cb][4 k][16 i][36 f]
@@ -298,7 +303,18 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
     p.divCb.divmod(t1, t2, colblk);
     p.divRb.divmod(t2, ngrp, rowblk);
     const int BRm = (1 << p.lBR) - 1, BCm = (1 << LBC) - 1, lT = p.lBR + LBC;
-    const int n0 = (int)ngrp << (5 - lT), ty0 = (int)rowblk << p.lBR, tx0 = (int)colblk << LBC;
+    int n0 = (int)ngrp << (5 - lT);
+    const int ty0 = (int)rowblk << p.lBR, tx0 = (int)colblk << LBC;
+    // PACK: ngrp counts the RECEIVING images (G - 1 of every G); the donor's tile group of this block: (dgr, dgc)
+    int dn = 0, dgr = 0, dgc = 0;
+    if constexpr (PACK) {
+        const int grp = (int)ngrp / (p.pack_g - 1), i = (int)ngrp - grp * (p.pack_g - 1);
+        n0 = grp * p.pack_g + i;
+        dn = grp * p.pack_g + p.pack_g - 1;
+        const int id = i * p.rblocks + (int)rowblk;
+        dgr = id / p.pack_gc;
+        dgc = id - dgr * p.pack_gc;
+    }
     const int HW = p.H * p.W;
 
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, p.x_bytes, 0x00020000);
@@ -318,7 +334,18 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
             p.divPlane.divmod(ci, nb, rem);
             p.div4S.divmod(rem, r_, rem2);
             p.divS.divmod(rem2, m, s);
-            const int n = n0 + (int)nb, h = 4 * ty0 + (int)r_ - 1, w = 4 * tx0 + (int)(4 * s + m) - 1;
+            int n = n0 + (int)nb, h = 4 * ty0 + (int)r_ - 1, w = 4 * tx0 + (int)(4 * s + m) - 1;
+            if constexpr (PACK) {
+                // plane columns from 4 (tw + 1) on hold the donor group's patch (one cell right of where the spare slots would
+                // read by themselves: the main image's last tile column shares its two halo columns with nobody)
+                const int pc = (int)(4 * s + m) - 4 * (p.tw + 1);
+                if (pc >= 0) {
+                    n = dn;
+                    h = (4 * dgr << p.lBR) + (int)r_ - 1;
+                    w = 4 * p.pack_sc * dgc + pc - 1;
+                    if (pc > 4 * p.pack_sc + 1) n = p.N;           // (past the donor patch: nothing)
+                }
+            }
             if (n < p.N && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W)
                 pvoff[ps] = (int)(((unsigned)(n * p.Cq) * (unsigned)HW + (unsigned)(h * p.W + w)) << 4);
         }
@@ -413,7 +440,9 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
     int pb2 = 0, vb2 = 0;
     if constexpr (!PLANAR) {
         const int tj = lane >> 1, cp = lane & 1;
-        const int t_nb = tj >> lT, t_r = (tj >> LBC) & BRm, t_c = tj & BCm;
+        const int t_nb = tj >> lT, t_r = (tj >> LBC) & BRm;
+        int t_c = tj & BCm;
+        if (PACK && t_c >= p.tw) t_c += 1;                       // spare slots read the donor patch, one cell further right
         pb2 = 2 * cp + (((t_nb * p.R + 4 * t_r) * 4) * S + t_c) * 4;
         vb2 = ((((tj >> 4) * 4 + 2 * cp) * 16) + (tj & 15)) * 36;
     }
@@ -569,7 +598,14 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
     float4 *xb = reinterpret_cast<float4 *>(As0) + wave * (4 * 68);      // the K loop is over: A0 is free (8 x 4.25 KB)
     const int te = lane >> 2, be = lane & 3;
     const int oj2 = wn * 16 + te;
-    const int n2 = n0 + (oj2 >> lT), ty2 = ty0 + ((oj2 >> LBC) & BRm), tx2 = tx0 + (oj2 & BCm);
+    int n2 = n0 + (oj2 >> lT), ty2 = ty0 + ((oj2 >> LBC) & BRm), tx2 = tx0 + (oj2 & BCm);
+    if constexpr (PACK) {
+        if ((oj2 & BCm) >= p.tw) {                               // a spare slot: the donor image's tile
+            n2 = dn;
+            ty2 = (dgr << p.lBR) + ((oj2 >> LBC) & BRm);
+            tx2 = p.pack_sc * dgc + (oj2 & BCm) - p.tw;
+        }
+    }
     const int x2 = tx2 * 4 + be, cq0 = (int)coutblk * 16 + wm * 4;
     const bool ok2 = n2 < p.N && ty2 < p.th && tx2 < p.tw && x2 < p.W;
     auto row = [&](auto first, auto res, auto pl) {
@@ -598,9 +634,9 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
     }
 }
 
-template <bool DMA_A, bool PLANAR, bool STAGGER, int LBC>
+template <bool DMA_A, bool PLANAR, bool STAGGER, int LBC, bool PACK = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) conv_wf4_kernel(const Wf4Args p) {
-    conv_wf4_body<DMA_A, PLANAR, STAGGER, LBC>(p);
+    conv_wf4_body<DMA_A, PLANAR, STAGGER, LBC, PACK>(p);
 }
 
 // filter: OIHW 3x3 -> u[cout block][chunk][cb][kk][i][f] = (G g G^T)[f] of channel (64 blk + 16 cb + i, 4 chunk + kk); zero beyond Cout

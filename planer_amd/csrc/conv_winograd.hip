@@ -1017,9 +1017,20 @@ int wf4_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const
     const int NB = 32 / (BR * BC);
     a.lBR = lBR; a.lBC = lBC;
     a.R = 4 * BR + 2; a.S = BC + 1;
-    a.cells = NB * a.R * 4 * a.S;
     a.rblocks = (a.th + BR - 1) / BR; a.cblocks = (a.tw + BC - 1) / BC; a.cout_blocks = (Cout + 63) / 64;
-    const long long groups = (N + NB - 1) / NB;
+    // Packed blocks (conv_wf4_kernel<.., PACK>): one image per block, one column block, sc = BC - tw spare slot columns that divide
+    // tw, whole row blocks, batch a multiple of G = tw / sc + 1 -- the spare slots of G - 1 images' blocks carry the G-th image
+    // (ResNet-18's layer1 at batch 32: 196 instead of 224 workgroups).  PLANER_HIP_EXPERIMENT=wf4_pack=0 switches it off.
+    {
+        const int sc = BC - a.tw;
+        if (NB == 1 && a.cblocks == 1 && sc > 0 && a.tw % sc == 0 && a.th % BR == 0 && (lBC == 4 || lBC == 3) &&
+            N % (a.tw / sc + 1) == 0 && a.R * 4 * (BC + 2) <= WF4_P_CELLS && pl_experiment("wf4_pack", 1)) {
+            a.pack_sc = sc; a.pack_g = a.tw / sc + 1; a.pack_gc = a.tw / sc;
+            a.S = BC + 2;
+        }
+    }
+    a.cells = NB * a.R * 4 * a.S;
+    const long long groups = a.pack_g ? (long long)(N / a.pack_g) * (a.pack_g - 1) : (N + NB - 1) / NB;
     const long long blocks = groups * a.rblocks * a.cblocks * a.cout_blocks;
     const size_t xb = (size_t)N * Cin * H * W * 4, yb = (size_t)N * Cout * H * W * 4;
     const size_t ub = (size_t)a.cout_blocks * a.nchunks * WF4_A_FLOATS * 4;
@@ -1033,7 +1044,9 @@ int wf4_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const
     // against 51.4 us for register-staged operands with the waves in step, layer1 of ResNet-18 at batch 32); one instantiation
     // per block width, so that every patch read is base + immediate
     void (*kern)(const Wf4Args) = nullptr;
-    switch (lBC) {
+    switch (a.pack_g ? 10 + lBC : lBC) {
+    case 14: kern = conv_wf4_kernel<true, false, true, 4, true>; break;
+    case 13: kern = conv_wf4_kernel<true, false, true, 3, true>; break;
     case 4: kern = conv_wf4_kernel<true, false, true, 4>; break;
     case 3: kern = conv_wf4_kernel<true, false, true, 3>; break;
     case 2: kern = conv_wf4_kernel<true, false, true, 2>; break;
@@ -1043,7 +1056,7 @@ int wf4_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), 0, ctx->stream, a);      // LDS: static (WF4_LDS_BYTES)
     PL_LAUNCH_CHECK();
     char buf[96];
-    snprintf(buf, sizeof buf, "wf4 64co x 32tiles (%dx%dx%d) blocks=%lld", NB, BR, BC, blocks);
+    snprintf(buf, sizeof buf, "wf4 64co x 32tiles (%dx%dx%d%s) blocks=%lld", NB, BR, BC, a.pack_g ? " packed" : "", blocks);
     ctx->last_plan = buf;
     ctx->last_gemm[0] = 36; ctx->last_gemm[1] = (long long)a.cout_blocks * 64;
     ctx->last_gemm[2] = groups * a.rblocks * a.cblocks * 32; ctx->last_gemm[3] = Cin;

@@ -55,6 +55,34 @@ def test_fused_f4x4_conv_vs_oracle(pa, shape):
         assert_close(q4.from_q4(yq).get(), _oracle(host, tail), 3e-5, "%s %s [%s]" % (shape, tail, pa.hip.context().last_conv_plan()))
 
 
+PACKED = [(8, 64, 56, 56, 64), (16, 16, 56, 56, 24), (4, 8, 48, 48, 8), (8, 8, 54, 55, 12), (16, 4, 53, 56, 8), (5, 8, 20, 20, 8)]
+
+
+@pytest.mark.parametrize("shape", PACKED, ids=["x".join(map(str, s)) for s in PACKED])
+def test_packed_blocks_equal_plain_blocks_bit_for_bit(pa, shape, monkeypatch):
+    """Round 5: where a block has spare slot columns (14 tile columns in a 16-column block) and the batch is a multiple of G = tw / sc + 1,
+    the spare slots of G - 1 images' blocks carry the G-th image's tiles (ResNet-18 layer1 at batch 32: 196 instead of 224
+    workgroups).  Same arithmetic per tile: bit-identical to the plain blocks (PLANER_HIP_EXPERIMENT=wf4_pack=0) and within
+    the conv tolerance of the oracle, with every tail."""
+    from planer_amd import q4
+    n, cin, h, w, cout = shape
+    rng = np.random.default_rng(3 + sum(shape))
+    for tail in TAILS:
+        host, dev = _operands(pa, rng, n, cin, h, w, cout, tail)
+        u = q4.prepare_wf4_q4_weights(dev["k"])
+        kw = dict(pads=(1, 1, 1, 1), act=_act(tail), alpha=0.1, w_layout=9)
+        monkeypatch.delenv("PLANER_HIP_EXPERIMENT", raising=False)
+        packed = q4.ConvQ4(dev["xq"], u, dev["b"], dev["scale"], dev["shift"], dev["resq"], **kw)
+        plan = pa.hip.context().last_conv_plan()
+        monkeypatch.setenv("PLANER_HIP_EXPERIMENT", "wf4_pack=0")
+        plain = q4.ConvQ4(dev["xq"], u, dev["b"], dev["scale"], dev["shift"], dev["resq"], **kw)
+        assert "packed" not in pa.hip.context().last_conv_plan()
+        if shape != PACKED[-1]:
+            assert "packed" in plan, plan                       # (the last shape has no spare columns: 5 tile columns in 8 -> 3, 5 % 3)
+        np.testing.assert_array_equal(packed.get(), plain.get(), err_msg="%s %s [%s]" % (shape, tail, plan))
+        assert_close(q4.from_q4(packed).get(), _oracle(host, tail), 3e-5, "%s %s [%s]" % (shape, tail, plan))
+
+
 def test_fused_f4x4_is_linear_and_shard_independent(pa):
     """Size-independent properties at a real layer size (batch 32, 64 channels, 56x56): conv(a x1 + x2) = a conv(x1) + conv(x2),
     and row i of the batch equals the same image run alone."""
