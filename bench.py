@@ -455,6 +455,13 @@ def main():
     # `repeats` timed regions of exactly K steps each (barrier + device sync on both sides, MAX over ranks);
     # the line reports the MEDIAN repeat, with the spread next to it (median and best)
     spans, own = dist.timed_repeats(comm, step, sync, args.steps, args.warmup, args.repeats)
+    # A disturbed invocation (seen once in ~20 on the gpurun boxes: a first region at half rate, recovering over the next four while the
+    # shader clock comes back) is measured longer, not reported: when the regions spread by more than 5 %, as many regions again are
+    # timed and the median is taken over all of them (every rank sees the same MAX-over-ranks spans, so all ranks decide alike)
+    extended = False
+    if args.repeats > 1 and max(spans) > 1.05 * min(spans):
+        s2, o2 = dist.timed_repeats(comm, step, sync, args.steps, 0, args.repeats)
+        spans, own, extended = spans + s2, own + o2, True
     order = sorted(range(len(spans)), key=lambda i: spans[i])
     mid = order[len(order) // 2]
     elapsed = spans[mid]
@@ -462,7 +469,7 @@ def main():
     value = global_batch * args.steps / elapsed
     repeat_values = {"repeats": len(spans), "min": round(global_batch * args.steps / max(spans), 1),
                      "median": round(value, 1), "max": round(global_batch * args.steps / min(spans), 1),
-                     "all": [round(global_batch * args.steps / t, 1) for t in spans]}
+                     "all": [round(global_batch * args.steps / t, 1) for t in spans], "extended": extended}
     # every rank's own rate over the median repeat (no barrier wait inside): min / max over ranks
     my_rate = (hi - lo) * args.steps / own[mid]
     rank_rates = {"min": round(comm.min_over_ranks(my_rate), 1), "max": round(comm.max_over_ranks(my_rate), 1)}

@@ -53,7 +53,7 @@ def test_bench_default_command_prints_one_contract_line():
         assert h["unit"] == "GB/s" and h["peak"] == 8000.0 and 0 < h["frac"] < 1
     # round 3: spread of the repeated timed region, where the kernel choices came from, executed FLOPs from the library
     rv = d["config"]["repeat_values"]
-    assert rv["repeats"] == 5 and rv["min"] <= rv["median"] <= rv["max"] and abs(rv["median"] - d["value"]) <= 0.01 * d["value"]
+    assert rv["repeats"] == (10 if rv["extended"] else 5) and rv["min"] <= rv["median"] <= rv["max"] and abs(rv["median"] - d["value"]) <= 0.01 * d["value"]
     assert d["config"]["rccl_ranks"] == 1 and d["config"]["tune_source"]
     assert all(r["executed_flops"] for r in d["per_layer"] if r["algorithmic_flops"])
     steps = d["config"]["plan_steps"]
