@@ -303,19 +303,18 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
     p.divCb.divmod(t1, t2, colblk);
     p.divRb.divmod(t2, ngrp, rowblk);
     const int BRm = (1 << p.lBR) - 1, BCm = (1 << LBC) - 1, lT = p.lBR + LBC;
-    const int n0 = (int)ngrp << (5 - lT);
+    int n0 = (int)ngrp << (5 - lT);
     const int ty0 = (int)rowblk << p.lBR, tx0 = (int)colblk << LBC;
-    // PACK: the block's NB images are RECEIVING images (G - 1 of every G, counted through the batch); image slot nb of the block
-    // -> its image, the donor image and the donor's tile group (dgr, dgc) that rides in this block's spare slots of that image slot
-    auto pack_of = [&](int nb, int &n, int &dn, int &dgr, int &dgc) {
-        const int ri = ((int)ngrp << (5 - lT)) + nb;
-        const int grp = ri / (p.pack_g - 1), i = ri - grp * (p.pack_g - 1);
-        n = grp * p.pack_g + i;
+    // PACK: ngrp counts the RECEIVING images (G - 1 of every G); the donor's tile group of this block: (dgr, dgc)
+    int dn = 0, dgr = 0, dgc = 0;
+    if constexpr (PACK) {
+        const int grp = (int)ngrp / (p.pack_g - 1), i = (int)ngrp - grp * (p.pack_g - 1);
+        n0 = grp * p.pack_g + i;
         dn = grp * p.pack_g + p.pack_g - 1;
         const int id = i * p.rblocks + (int)rowblk;
         dgr = id / p.pack_gc;
         dgc = id - dgr * p.pack_gc;
-    };
+    }
     const int HW = p.H * p.W;
 
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, p.x_bytes, 0x00020000);
@@ -339,8 +338,6 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
             if constexpr (PACK) {
                 // plane columns from 4 (tw + 1) on hold the donor group's patch (one cell right of where the spare slots would
                 // read by themselves: the main image's last tile column shares its two halo columns with nobody)
-                int dn, dgr, dgc;
-                pack_of((int)nb, n, dn, dgr, dgc);
                 const int pc = (int)(4 * s + m) - 4 * (p.tw + 1);
                 if (pc >= 0) {
                     n = dn;
@@ -603,8 +600,6 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
     const int oj2 = wn * 16 + te;
     int n2 = n0 + (oj2 >> lT), ty2 = ty0 + ((oj2 >> LBC) & BRm), tx2 = tx0 + (oj2 & BCm);
     if constexpr (PACK) {
-        int dn, dgr, dgc;
-        pack_of(oj2 >> lT, n2, dn, dgr, dgc);
         if ((oj2 & BCm) >= p.tw) {                               // a spare slot: the donor image's tile
             n2 = dn;
             ty2 = (dgr << p.lBR) + ((oj2 >> LBC) & BRm);

@@ -1018,19 +1018,19 @@ int wf4_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const
     a.lBR = lBR; a.lBC = lBC;
     a.R = 4 * BR + 2; a.S = BC + 1;
     a.rblocks = (a.th + BR - 1) / BR; a.cblocks = (a.tw + BC - 1) / BC; a.cout_blocks = (Cout + 63) / 64;
-    // Packed blocks (conv_wf4_kernel<.., PACK>): one column block, sc = BC - tw spare slot columns that divide tw, whole row blocks,
-    // batch a multiple of G = tw / sc + 1 (and the receiving images a multiple of the images per block) -- the spare slots of
-    // G - 1 images' blocks carry the G-th image (ResNet-18 at batch 32: layer1 196 instead of 224 workgroups, layer2 98 instead of 112).  PLANER_HIP_EXPERIMENT=wf4_pack=0 switches it off.
+    // Packed blocks (conv_wf4_kernel<.., PACK>): one image per block, one column block, sc = BC - tw spare slot columns that divide
+    // tw, whole row blocks, batch a multiple of G = tw / sc + 1 -- the spare slots of G - 1 images' blocks carry the G-th image
+    // (ResNet-18's layer1 at batch 32: 196 instead of 224 workgroups).  PLANER_HIP_EXPERIMENT=wf4_pack=0 switches it off.
     {
         const int sc = BC - a.tw;
-        if (a.cblocks == 1 && sc > 0 && a.tw % sc == 0 && a.th % BR == 0 && (lBC == 4 || lBC == 3) && N % (a.tw / sc + 1) == 0 &&
-            (N / (a.tw / sc + 1) * (a.tw / sc)) % NB == 0 && NB * a.R * 4 * (BC + 2) <= WF4_P_CELLS && pl_experiment("wf4_pack", 1)) {
+        if (NB == 1 && a.cblocks == 1 && sc > 0 && a.tw % sc == 0 && a.th % BR == 0 && (lBC == 4 || lBC == 3) &&
+            N % (a.tw / sc + 1) == 0 && a.R * 4 * (BC + 2) <= WF4_P_CELLS && pl_experiment("wf4_pack", 1)) {
             a.pack_sc = sc; a.pack_g = a.tw / sc + 1; a.pack_gc = a.tw / sc;
             a.S = BC + 2;
         }
     }
     a.cells = NB * a.R * 4 * a.S;
-    const long long groups = a.pack_g ? (long long)(N / a.pack_g) * (a.pack_g - 1) / NB : (N + NB - 1) / NB;
+    const long long groups = a.pack_g ? (long long)(N / a.pack_g) * (a.pack_g - 1) : (N + NB - 1) / NB;
     const long long blocks = groups * a.rblocks * a.cblocks * a.cout_blocks;
     const size_t xb = (size_t)N * Cin * H * W * 4, yb = (size_t)N * Cout * H * W * 4;
     const size_t ub = (size_t)a.cout_blocks * a.nchunks * WF4_A_FLOATS * 4;
