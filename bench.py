@@ -585,6 +585,35 @@ def main():
     call_rates = {}
     if rank == 0 and not args.no_e2e:
         net.streams = "auto"
+        # host ndarray in -> host ndarray out (the reference's call contract, net.py:94-101) through net.submit: pageable numpy
+        # batches staged into the pinned ring by the library's copy threads, DMA on the copy stream, logits back through pinned
+        # tickets; a window of six passes in flight (one fewer than the pipeline has replicas)
+        import collections
+        window, pend = 6, collections.deque()
+
+        def host_loop(k, batches):
+            got = None
+            for i in range(k):
+                pend.append(net.submit(batches[i & 1]))
+                if len(pend) > window:
+                    got = pend.popleft().get()
+            while pend:
+                got = pend.popleft().get()
+            return got
+        host_loop(20, xs_host)
+        t0 = time.perf_counter()
+        got = host_loop(100, xs_host)
+        call_rates["net_submit_host"] = round(n * 100 / (time.perf_counter() - t0), 1)
+        ref_host = net.submit(xs[1]).get()                   # (100 passes: the last one read batch 1; xs[1] is its device copy)
+        call_rates["net_submit_host_max_abs_diff_vs_device_submit"] = float(np.abs(got - ref_host).max())
+        px = [planer_amd.hip.pinned_empty(xs_host[0].shape), planer_amd.hip.pinned_empty(xs_host[0].shape)]
+        px[0][...] = xs_host[0]
+        px[1][...] = xs_host[1]
+        host_loop(20, px)
+        t0 = time.perf_counter()
+        host_loop(100, px)
+        call_rates["net_submit_pinned_host"] = round(n * 100 / (time.perf_counter() - t0), 1)
+        del px
         for label, fn in (("net_call", lambda a: net(a)), ("net_submit", lambda a: net.submit(a))):
             for i in range(20):
                 last = fn(xs[i & 1])
@@ -735,6 +764,11 @@ def main():
                       "pcie_inclusive_images_per_sec": None if e2e is None else round(e2e, 1),
                       "net_call_images_per_sec": call_rates.get("net_call"),
                       "net_submit_images_per_sec": call_rates.get("net_submit"),
+                      # host arrays in, host arrays out, six passes in flight: pageable numpy batches / batches built in
+                      # hip.pinned_empty memory; and the largest difference between a host-array pass and the pass over the device copy of its batch
+                      "net_submit_host_images_per_sec": call_rates.get("net_submit_host"),
+                      "net_submit_pinned_host_images_per_sec": call_rates.get("net_submit_pinned_host"),
+                      "net_submit_host_max_abs_diff_vs_device_submit": call_rates.get("net_submit_host_max_abs_diff_vs_device_submit"),
                       "device": ctx.arch, "cu_count": ctx.cu_count,
                       "tune_cache": os.environ.get("PLANER_HIP_TUNE_CACHE"), "settle_ms": args.settle_ms,
                       "sclk_mhz_under_load": sclk_mhz,

@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libplaner_hip.so")
-SOURCES = ["runtime.hip", "pointwise.hip", "head_ops.hip", "conv_direct.hip", "conv_winograd.hip", "plan_exec.hip"]
+SOURCES = ["runtime.hip", "host_stage.hip", "pointwise.hip", "head_ops.hip", "conv_direct.hip", "conv_winograd.hip", "plan_exec.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall",
          "-Wno-unused-function", "-ffp-contract=off"]
 

@@ -40,6 +40,12 @@ SIGNATURES = {
     "pl_h2d": [_P, _P, _P, _Z],
     "pl_d2h": [_P, _P, _P, _Z],
     "pl_d2d": [_P, _P, _P, _Z],
+    "pl_h2d_staged": [_P, _P, _P, _P, _Z],
+    "pl_d2h_begin": [_P, _P, _P, _Z, POINTER(c_int)],
+    "pl_d2h_finish": [_P, _I, _P],
+    "pl_host_alloc": [_Z, POINTER(_P)],
+    "pl_host_free": [_P],
+    "pl_copy_threads": [POINTER(c_int)],
     "pl_memset": [_P, _P, _I, _Z],
     "pl_event_create": [_P, POINTER(_P)],
     "pl_event_record": [_P, _P],

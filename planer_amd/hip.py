@@ -180,6 +180,13 @@ def set_side_stream_perm(device, want):
             cur[i], cur[j] = cur[j], cur[i]
 
 
+def side_stream_perm(device):
+    """Creation index of the stream each side context of `device` currently holds (identity until something permutes it)."""
+    pool = _side_pool.get(int(device), [])
+    cur = _side_perm.get(int(device), [])
+    return list(cur) + list(range(len(cur), len(pool)))
+
+
 def set_side_stream_shift(device, n, shift):
     """Side context i (i < n) of `device` takes the stream created as number (i + shift) % n.  The hardware queue of a stream
     follows its creation order, so a shift moves a pipeline's replicas onto other queues without re-capturing anything
@@ -381,6 +388,39 @@ class DeviceArray:
             self.host = host.copy()
         return self
 
+    def set_staged(self, host, consumer=None):
+        """Asynchronous `set` (pl_h2d_staged): the bytes travel through the library's pinned ring on a copy stream; `consumer`'s
+        stream (a Context; default: this array's) waits for them, the host does not.  `host` may be overwritten on return."""
+        host = numpy.require(host, dtype=self.dtype, requirements="C")
+        if host.shape != self.shape:
+            raise ValueError("shape mismatch %s vs %s" % (host.shape, self.shape))
+        if self._p is None:
+            self._allocate()
+        if host.nbytes:
+            _lib.call("pl_h2d_staged", self.ctx.handle, (consumer or self.ctx).handle, self._p, host.ctypes.data, host.nbytes)
+        self.host = None
+        return self
+
+    def get_begin(self, producer=None):
+        """First half of an asynchronous `.get()`: the device -> pinned-host copy is enqueued behind `producer`'s stream
+        (default: this array's context).  Returns a ticket for `get_finish` (None: no pinned buffer free -- `get()` then)."""
+        if self._p is None or not self.nbytes:
+            return None
+        t = c_int(-1)
+        _lib.call("pl_d2h_begin", self.ctx.handle, (producer or self.ctx).handle, self._p, self.nbytes, byref(t))
+        return t.value if t.value >= 0 else None
+
+    def get_finish(self, ticket):
+        if ticket is None:
+            return self.get()
+        out = numpy.empty(self.shape, self.dtype)
+        _lib.call("pl_d2h_finish", self.ctx.handle, int(ticket), out.ctypes.data)
+        return out
+
+    def get_cancel(self, ticket):
+        if ticket is not None and self.ctx.handle is not None:
+            _lib.load().pl_d2h_finish(self.ctx.handle, int(ticket), None)
+
     def copy_from(self, other):
         if other.nbytes != self.nbytes:
             raise ValueError("size mismatch")
@@ -417,12 +457,31 @@ def zeros(shape, dtype=numpy.float32, ctx=None):
     return a
 
 
-def asarray(a, dtype=None, ctx=None):
-    """Host ndarray -> DeviceArray (net.py:96-98); DeviceArrays pass through."""
+def pinned_empty(shape, dtype=numpy.float32):
+    """A numpy array in pinned host memory (pl_host_alloc): batches built in it go to the device by DMA straight out of it,
+    no staging copy (`net.submit`, `net(x)`, `DeviceArray.set`).  The memory is released with the array."""
+    import weakref
+    dtype = numpy.dtype(dtype)
+    shape = (shape,) if isinstance(shape, (int, numpy.integer)) else tuple(int(v) for v in shape)
+    n = dtype.itemsize
+    for v in shape:
+        n *= v
+    p = c_void_p()
+    _lib.call("pl_host_alloc", max(n, 1), byref(p))
+    buf = (ctypes.c_char * max(n, 1)).from_address(p.value)
+    a = numpy.frombuffer(buf, dtype=dtype, count=n // dtype.itemsize).reshape(shape)
+    weakref.finalize(buf, _lib.load().pl_host_free, c_void_p(p.value))      # (numpy keeps `buf` alive through .base)
+    return a
+
+
+def asarray(a, dtype=None, ctx=None, consumer=None):
+    """Host ndarray -> DeviceArray (net.py:96-98); DeviceArrays pass through.  `consumer`: a Context whose stream waits for
+    the upload instead of the host (pl_h2d_staged); the array is read before the call returns either way."""
     if isinstance(a, DeviceArray):
         return a
     host = numpy.require(a, dtype=dtype, requirements="C")
-    d = DeviceArray(host.shape, host.dtype, ctx).set(host)
+    d = DeviceArray(host.shape, host.dtype, ctx)
+    d = d.set_staged(host, consumer) if consumer is not None and host.nbytes >= (128 << 10) else d.set(host)
     if host.dtype != numpy.float32 and host.size <= 4096:
         d.host = host.copy()         # small integer / bool tensors (shapes, indices) stay readable on the host
     return d

@@ -246,8 +246,11 @@ class Pending:
     device arrays, private to this handle, ordered behind the pass (no host wait); `get()` returns host arrays.  Both
     unwrap like `Net.__call__` (net.py:101)."""
 
-    def __init__(self, net, outs, event, to_host, final=False):
+    def __init__(self, net, outs, event, to_host, final=False, tickets=None):
         self.net, self._outs, self._event, self._to_host, self._final = net, outs, event, to_host, final
+        # host-array submits: the device -> pinned-host copies of the outputs were enqueued at submit time (one ticket per
+        # output, None where no pinned buffer was free); get() only waits for them
+        self._tickets = tickets
 
     def done(self):
         """Host-side wait for this pass alone (not for passes submitted after it)."""
@@ -264,8 +267,25 @@ class Pending:
         if self._final:                               # Net.__call__ ran the pass (flows that cannot be captured): as it returned
             return rst
         if self._to_host:
-            rst = tuple(i.get() for i in rst) if isinstance(rst, tuple) else rst.get()
+            tk, self._tickets = self._tickets, None
+            if tk is not None:
+                seq = rst if isinstance(rst, tuple) else (rst,)
+                got = tuple(o.get_finish(t) if isinstance(o, DeviceArray) else o for o, t in zip(seq, tk))
+                rst = got if isinstance(rst, tuple) else got[0]
+            else:
+                rst = tuple(i.get() for i in rst) if isinstance(rst, tuple) else rst.get()
         return rst[0] if len(rst) == 1 else rst
+
+    def __del__(self):
+        try:
+            tk, self._tickets = self._tickets, None
+            if tk is not None:                        # dropped without get(): hand the pinned buffers back
+                seq = self._outs if isinstance(self._outs, tuple) else (self._outs,)
+                for o, t in zip(seq, tk):
+                    if isinstance(o, DeviceArray):
+                        o.get_cancel(t)
+        except Exception:
+            pass
 
     def get(self):
         if self._final:
@@ -801,6 +821,7 @@ class Net:
         key = (mode,) + tuple((a.shape, str(a.dtype)) for a in xs)
         plan = self._plans.get(key)
         if plan is not None:
+            self._ensure_streams(plan)
             return plan
         ctx = self.ctx
         shapes = {k: a.shape for k, a in zip(self.input, xs)}
@@ -922,6 +943,9 @@ class Net:
             self._algo_dirty = True
         self.timer = timer
         self._plans[key] = best
+        # every pipeline candidate's probe rotated the process-wide side-stream pool for ITS depth: what is left is the last
+        # candidate's assignment, not the winner's -- re-apply the one the winner was measured (and picked) under
+        self._ensure_streams(best)
         if getattr(self, "_algo_dirty", False):
             self.save_algo_cache()
             self._algo_dirty = False
@@ -967,6 +991,19 @@ class Net:
             pick = 0
         hip.set_side_stream_shift(dev, nside, pick)
         plan.stream_probe = {"shift": pick, "ms_per_pass": ms}
+
+    def _ensure_streams(self, plan):
+        """The side-stream assignment is process-wide state (hip.set_side_stream_perm): another candidate's probe, or another
+        Net's throughput plan compiled since, may have rotated it.  A pipeline plan carries the assignment it was measured
+        under (`stream_probe`: shift over nrep + 2 side streams) and puts it back before it runs -- a few stream syncs, and only
+        when something else changed it."""
+        sp = getattr(plan, "stream_probe", None)
+        if not isinstance(plan, _PipelinePlan) or not sp or "shift" not in sp:
+            return
+        n = len(plan.replicas) - 1 + 3
+        want = [(i + int(sp["shift"])) % n for i in range(n)]
+        if hip.side_stream_perm(self.ctx.device)[:n] != want:
+            hip.set_side_stream_shift(self.ctx.device, n, sp["shift"])
 
     def _side_context(self, i):
         """Extra stream (context) number i of this net's device; 0 is the net's own."""
@@ -1136,13 +1173,25 @@ class Net:
         if type(x[0]) is dict:
             x = [x[0][i] for i in self.input]
         host = [isinstance(i, numpy.ndarray) for i in x]
-        xs = [hip.asarray(i, ctx=self.ctx) if b else i for i, b in zip(x, host)]
         plan = None
-        if self.use_graph and not self.profile:
-            try:
-                plan = self.compile(*xs, mode="throughput")
-            except _lib.NotCapturable:
-                self.use_graph = False
+        if any(host) and self.use_graph and not self.profile:
+            # a pipeline compiled for this signature: host batches go through the pinned ring on the copy stream, and only the
+            # replica whose turn it is waits for them (no copy on a compute stream, no host wait; x may be overwritten at once)
+            hx = [numpy.require(i, requirements="C") if b else i for i, b in zip(x, host)]
+            plan = self._plans.get(("throughput",) + tuple((a.shape, str(a.dtype)) for a in hx))
+            if isinstance(plan, _PipelinePlan):
+                self._ensure_streams(plan)
+                cx = plan.replicas[plan.turn].ctx
+                xs = [hip.asarray(i, ctx=self.ctx, consumer=cx) if b else i for i, b in zip(hx, host)]
+            else:
+                plan = None
+        if plan is None:
+            xs = [hip.asarray(i, ctx=self.ctx) if b else i for i, b in zip(x, host)]
+            if self.use_graph and not self.profile:
+                try:
+                    plan = self.compile(*xs, mode="throughput")
+                except _lib.NotCapturable:
+                    self.use_graph = False
         if plan is None:                              # flows that need the host between kernels: run now, hand back a finished handle
             return Pending(self, self(*x), None, any(host), final=True)
         if isinstance(plan, _PipelinePlan):
@@ -1161,7 +1210,11 @@ class Net:
         outs = tuple(o.copy() if isinstance(o, DeviceArray) else o for o in out) if isinstance(out, tuple) else out.copy()
         ev = self._events.pop() if self._events else hip.Event(cx)      # a marker can be recorded on any stream of its device
         _lib.call("pl_event_record", cx.handle, ev.handle)
-        return Pending(self, outs, ev, any(host))
+        tickets = None
+        if any(host):                                 # host in -> host out: the copies back start now, behind this pass
+            seq = outs if isinstance(outs, tuple) else (outs,)
+            tickets = [o.get_begin(producer=cx) if isinstance(o, DeviceArray) else None for o in seq]
+        return Pending(self, outs, ev, any(host), tickets=tickets)
 
     def _eager_program(self, xs):
         """The fused program for THESE input shapes (conv algorithms, Winograd chaining, row packing and the fusions are
@@ -1186,7 +1239,7 @@ class Net:
         host = [isinstance(i, numpy.ndarray) for i in x]
         need = any(host)
         if need:
-            x = [hip.asarray(i, ctx=self.ctx) if b else i for i, b in zip(x, host)]
+            x = [hip.asarray(i, ctx=self.ctx, consumer=self.ctx) if b else i for i, b in zip(x, host)]
         graphable = (self.use_graph and not key.get("debug") and not self.profile
                      and all(isinstance(i, DeviceArray) for i in x))
         if graphable:
