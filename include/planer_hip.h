@@ -74,20 +74,24 @@ int pl_h2d(pl_ctx *ctx, void *dst, const void *src_host, size_t bytes);
 int pl_d2h(pl_ctx *ctx, void *dst_host, const void *src, size_t bytes); /* syncs */
 int pl_d2d(pl_ctx *ctx, void *dst, const void *src, size_t bytes);
 int pl_memset(pl_ctx *ctx, void *dst, int byte, size_t bytes);
-/* The same contract (host ndarray in, host ndarray out: net.py:94-101) without a copy on a compute stream.  pl_h2d / pl_d2h
- * of 128 KB or more already take this route and then wait; these entry points are its asynchronous halves.
- *   pl_h2d_staged  copies src_host with the library's copy threads into a ring of pinned buffers, chunk by chunk, each chunk
- *                  leaving by DMA on a dedicated copy stream while the next is staged; `consumer`'s stream (NULL: ctx's own)
- *                  waits for the last chunk, nothing else does.  Returns as soon as src_host has been read -- the caller may
- *                  overwrite it.  dst is a block of ctx's pool; the copy is ordered behind what ctx's stream held at the call.
- *                  A src_host inside pl_host_alloc memory is not staged (DMA straight out of it; the call waits for that DMA).
- *   pl_d2h_begin   enqueues device -> pinned buffer on a second copy stream behind everything `producer` (NULL: ctx) has
- *                  enqueued; *ticket identifies the buffer (-1: every buffer is in flight, use pl_d2h).  No host wait.
+/* The asynchronous halves of the same contract (host ndarray in, host ndarray out: net.py:94-101).
+ *   pl_h2d_staged  copies src_host into a ring of pinned buffers, chunk by chunk (library copy threads), and enqueues each
+ *                  chunk's DMA on `consumer`'s stream (NULL: ctx's own) while the next is staged.  Returns as soon as
+ *                  src_host has been read -- the caller may overwrite it -- and nothing waits for the bytes except what
+ *                  `consumer` enqueues afterwards.  dst is a block of ctx's pool; the copy is ordered behind what ctx's stream
+ *                  held at the call.  A src_host inside pl_host_alloc memory is NOT staged: the DMA reads it in place, later,
+ *                  so the caller keeps it unchanged until `consumer`'s stream has passed the copy (a pl_event tells).
+ *   pl_d2h_begin   enqueues device -> pinned buffer on `producer`'s stream (NULL: ctx's); *ticket identifies the buffer
+ *                  (-1: every buffer is in flight, use pl_d2h).  No host wait.
  *   pl_d2h_finish  waits for that copy, moves the bytes to dst_host (NULL: drops them), releases the buffer.  The device
  *                  block must stay allocated until then.
  *   pl_host_alloc / pl_host_free   pinned host memory for callers that build batches in place.
- *   pl_copy_threads                worker threads of the staging copies (PLANER_HIP_COPY_THREADS; the caller's thread works too). */
+ *   pl_copy_threads                worker threads of the staging copies (PLANER_HIP_COPY_THREADS; the caller's thread works too).
+ * PLANER_HIP_COPY_STREAMS=1 moves the DMAs onto two dedicated copy streams (measured slower on MI355X: DESIGN 4.8). */
 int pl_h2d_staged(pl_ctx *ctx, pl_ctx *consumer, void *dst, const void *src_host, size_t bytes);
+/* host -> device at once and on NO stream: the host waits for the DMA, no hardware queue does.  The caller guarantees that no
+ * work on the device still uses dst.  (What Net.submit feeds a pipeline's replicas with: DESIGN 4.8.) */
+int pl_h2d_direct(pl_ctx *ctx, void *dst, const void *src_host, size_t bytes);
 int pl_d2h_begin(pl_ctx *ctx, pl_ctx *producer, const void *src, size_t bytes, int *ticket);
 int pl_d2h_finish(pl_ctx *ctx, int ticket, void *dst_host);
 int pl_host_alloc(size_t bytes, void **out);

@@ -41,6 +41,7 @@ SIGNATURES = {
     "pl_d2h": [_P, _P, _P, _Z],
     "pl_d2d": [_P, _P, _P, _Z],
     "pl_h2d_staged": [_P, _P, _P, _P, _Z],
+    "pl_h2d_direct": [_P, _P, _P, _Z],
     "pl_d2h_begin": [_P, _P, _P, _Z, POINTER(c_int)],
     "pl_d2h_finish": [_P, _I, _P],
     "pl_host_alloc": [_Z, POINTER(_P)],

@@ -89,9 +89,6 @@ struct pl_ctx {
 };
 
 void pl_stager_destroy(pl_ctx *ctx);     // host_stage.hip
-// large copies of pl_h2d / pl_d2h through the pinned rings (host_stage.hip); *done = false: the caller copies the plain way
-int pl_h2d_large(pl_ctx *ctx, void *dst, const void *src_host, size_t bytes, bool *done);
-int pl_d2h_large(pl_ctx *ctx, void *dst_host, const void *src, size_t bytes, bool *done);
 
 struct pl_graph {
     pl_ctx *ctx = nullptr;

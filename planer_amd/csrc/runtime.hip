@@ -205,9 +205,6 @@ int pl_h2d(pl_ctx *ctx, void *dst, const void *src_host, size_t bytes) {
     if (!bytes) return PL_OK;
     CtxGuard g(ctx);
     PL_REQUIRE(!ctx->capturing, PL_EINVAL, "pl_h2d during capture");
-    bool done = false;
-    if (int r = pl_h2d_large(ctx, dst, src_host, bytes, &done)) return r;
-    if (done) return PL_OK;
     PL_HIP(hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
     PL_HIP(hipStreamSynchronize(ctx->stream));  // src may be pageable/reused
     return PL_OK;
@@ -218,9 +215,6 @@ int pl_d2h(pl_ctx *ctx, void *dst_host, const void *src, size_t bytes) {
     if (!bytes) return PL_OK;
     CtxGuard g(ctx);
     PL_REQUIRE(!ctx->capturing, PL_EINVAL, "pl_d2h during capture");
-    bool done = false;
-    if (int r = pl_d2h_large(ctx, dst_host, src, bytes, &done)) return r;
-    if (done) return PL_OK;
     PL_HIP(hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     PL_HIP(hipStreamSynchronize(ctx->stream));
     return PL_OK;

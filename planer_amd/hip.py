@@ -459,7 +459,9 @@ def zeros(shape, dtype=numpy.float32, ctx=None):
 
 def pinned_empty(shape, dtype=numpy.float32):
     """A numpy array in pinned host memory (pl_host_alloc): batches built in it go to the device by DMA straight out of it,
-    no staging copy (`net.submit`, `net(x)`, `DeviceArray.set`).  The memory is released with the array."""
+    no staging copy (`net.submit`, `net(x)`, `DeviceArray.set` / `set_staged`).  The asynchronous routes read it IN PLACE, when
+    the consumer's stream gets there: refill it only after the pass that took it is over (`Pending.done()` / `.get()`).
+    An ordinary numpy array has no such rule (it is staged before the call returns).  The memory is released with the array."""
     import weakref
     dtype = numpy.dtype(dtype)
     shape = (shape,) if isinstance(shape, (int, numpy.integer)) else tuple(int(v) for v in shape)

@@ -113,6 +113,7 @@ class _Plan:
         # for milliseconds, and tools that intercept dispatches (rocprofv3) crash with ~2000 of them outstanding.
         self.max_in_flight, self._ring = 8, []
         self._held = []              # per ring slot: what that launch's feed read (Net.submit), released with the slot
+        self.host_in, self.fed = None, None      # Net.submit with host batches: this replica's own upload buffers + "feed has read them"
 
     def feed(self, xs):
         """Copy new inputs into the plan's static input buffers (on the plan's stream)."""
@@ -1174,15 +1175,36 @@ class Net:
             x = [x[0][i] for i in self.input]
         host = [isinstance(i, numpy.ndarray) for i in x]
         plan = None
-        if any(host) and self.use_graph and not self.profile:
-            # a pipeline compiled for this signature: host batches go through the pinned ring on the copy stream, and only the
-            # replica whose turn it is waits for them (no copy on a compute stream, no host wait; x may be overwritten at once)
+        route = os.environ.get("PLANER_HIP_HOST_ROUTE", "direct")          # direct | staged | plain (A/B: tools/host_submit_probe.py)
+        direct = False
+        if any(host) and self.use_graph and not self.profile and route != "plain":
+            # a pipeline compiled for this signature: a host batch goes straight into an input buffer that belongs to the
+            # replica whose turn it is -- a synchronous DMA on NO stream (pl_h2d_direct: the host waits 0.35 ms for a 19 MB
+            # batch while the other replicas compute; a copy enqueued on a stream would hold that stream's hardware queue, and
+            # the replica that shares it, for as long).  The buffer is free once the replica's previous feed has read it.
             hx = [numpy.require(i, requirements="C") if b else i for i, b in zip(x, host)]
             plan = self._plans.get(("throughput",) + tuple((a.shape, str(a.dtype)) for a in hx))
-            if isinstance(plan, _PipelinePlan):
+            if isinstance(plan, _PipelinePlan) and route == "staged":       # pinned ring + DMA on the replica's stream (pl_h2d_staged)
                 self._ensure_streams(plan)
-                cx = plan.replicas[plan.turn].ctx
-                xs = [hip.asarray(i, ctx=self.ctx, consumer=cx) if b else i for i, b in zip(hx, host)]
+                xs = [hip.asarray(i, ctx=self.ctx, consumer=plan.replicas[plan.turn].ctx) if b else i for i, b in zip(hx, host)]
+            elif isinstance(plan, _PipelinePlan):
+                self._ensure_streams(plan)
+                rp, direct = plan.replicas[plan.turn], True
+                if rp.host_in is None:
+                    rp.host_in, rp.fed = [None] * len(hx), hip.Event(rp.ctx)
+                else:
+                    rp.fed.synchronize()              # (recorded R submits ago)
+                xs = []
+                for i, (a, b) in enumerate(zip(hx, host)):
+                    if b:
+                        d = rp.host_in[i]
+                        if d is None or d.shape != a.shape or d.dtype != a.dtype:
+                            d = rp.host_in[i] = DeviceArray(a.shape, a.dtype, rp.ctx)
+                            rp.ctx.synchronize()      # (a fresh pool block: its previous reader was enqueued on this stream)
+                        if a.nbytes:
+                            _lib.call("pl_h2d_direct", rp.ctx.handle, d.ptr, a.ctypes.data, a.nbytes)
+                        a = d
+                    xs.append(a)
             else:
                 plan = None
         if plan is None:
@@ -1196,9 +1218,14 @@ class Net:
             return Pending(self, self(*x), None, any(host), final=True)
         if isinstance(plan, _PipelinePlan):
             rp = plan.replicas[plan.turn]
-            rp.ctx.wait_for(self.ctx)                 # the caller produced xs on the net's own stream
+            if not (direct and all(host)):
+                rp.ctx.wait_for(self.ctx)             # the caller produced xs on the net's own stream
             plan.feed(xs)
-            plan.launch(join=False, hold=xs)          # xs stay referenced until the replica has read them
+            if direct:
+                rp.fed.record()                       # the replica's upload buffers are free again behind this point
+            # what the feed read stays referenced until the replica has read it (the replica's own upload buffers live on anyway)
+            keep = [a for a, b in zip(xs, host) if not (direct and b)]
+            plan.launch(join=False, hold=keep or None)
             cx, out = rp.ctx, rp.outputs
         else:
             # sub-batch plans ("QxP"): the copy runs on the net's own stream, the sub-streams fork behind it and join
@@ -1239,7 +1266,7 @@ class Net:
         host = [isinstance(i, numpy.ndarray) for i in x]
         need = any(host)
         if need:
-            x = [hip.asarray(i, ctx=self.ctx, consumer=self.ctx) if b else i for i, b in zip(x, host)]
+            x = [hip.asarray(i, ctx=self.ctx) if b else i for i, b in zip(x, host)]
         graphable = (self.use_graph and not key.get("debug") and not self.profile
                      and all(isinstance(i, DeviceArray) for i in x))
         if graphable:

@@ -70,7 +70,8 @@ def test_pinned_arrays_are_numpy_arrays_and_skip_the_staging_copy(pa):
     big[...] = np.random.default_rng(0).standard_normal(big.size).astype(np.float32)
     want = big.copy()
     d = pa.hip.empty(big.shape, np.float32)
-    d.set_staged(big)                                            # DMA straight out of the caller's memory; held until read
+    d.set_staged(big)                                            # DMA straight out of the caller's memory, in stream order:
+    d.ctx.synchronize()                                          # ours again once the consumer's stream has passed the copy
     big[...] = -1.0
     np.testing.assert_array_equal(d.get(), want)
     del a, big                                                   # (finalizers hand the memory back: nothing to assert but no crash)
@@ -82,8 +83,9 @@ def test_pinned_arrays_are_numpy_arrays_and_skip_the_staging_copy(pa):
 def test_submit_with_host_batches_overwritten_right_after_it_returns(pa):
     """The reference-shaped asynchronous path at full speed: pageable numpy batches into `net.submit`, the SAME two host
     buffers refilled as soon as submit returns (the staging copy has read them), results fetched later and out of step --
-    every pass must equal the pass over the device-resident batch it was given (same plan), bit for bit; then the same with batches built in pinned
-    memory, and with handles dropped without get() (their pinned tickets go back)."""
+    every pass must equal the pass over the device-resident batch it was given (same plan), bit for bit; then batches built in pinned memory
+    (read in place: refilled only after the pass that took them is done), and handles dropped without get() (their pinned
+    tickets go back)."""
     g, b = resnet18.build()
     net = pa.from_graph(g, b)
     n, size, rounds = 16, 96, 30
@@ -106,9 +108,10 @@ def test_submit_with_host_batches_overwritten_right_after_it_returns(pa):
     hs = []
     for i in range(rounds):
         buf = pins[i & 1]
-        buf[...] = xs[i % 5]
+        if i >= 2:
+            hs[i - 2].done()                                      # pinned batches are read in place by the DMA: the pass that
+        buf[...] = xs[i % 5]                                      # took this buffer two submits ago has to be over first
         hs.append(net.submit(buf))
-        buf[...] = -1e6
     for i in range(rounds):
         np.testing.assert_array_equal(hs[i].get(), want[i % 5], "pinned, pass %d" % i)
     for i in range(300):                                          # dropped handles: tickets must come back

@@ -1,19 +1,6 @@
-mkdir -p gpurun_out/r6a
-python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r6a/bench_base.json 2> gpurun_out/r6a/bench_base.err
-tail -c 600 gpurun_out/r6a/bench_base.err
-python - <<'PY'
-import json
-d=json.loads(open('gpurun_out/r6a/bench_base.json').read().strip().splitlines()[-1])
-print('BASE value', d['value'], d['ms_per_step'], d['config'].get('streams'), d['roofline']['frac'], d['config'].get('pcie_inclusive_images_per_sec'), d['config'].get('net_submit_images_per_sec'))
-PY
-PLANER_HIP_STREAMS=1x1 python bench.py --batch 256 --steps 6 --warmup 2 --repeats 1 --no-cpu-baseline --no-e2e --no-extra --no-sclk > gpurun_out/r6a/bench_b256_1s.json 2> gpurun_out/r6a/bench_b256_1s.err
-python - <<'PY'
-import json
-d=json.loads(open('gpurun_out/r6a/bench_b256_1s.json').read().strip().splitlines()[-1])
-print('B256 1-stream value', d['value'], d['ms_per_step'])
-tot=0
-for r in d['per_layer']:
-    print('  %-28s %8.1f us per 256 = %6.2f per 32  %s' % (r['layer'], r['us'], r['us']/8, r.get('kernel','')[:60])); tot+=r['us']
-print('sum per 32:', tot/8)
-PY
-bash tools/wf4_stalls.sh
+mkdir -p gpurun_out/r6c
+( python -m pytest tests/test_gpu_host_path.py -x -q 2>&1 | tail -3
+for spec in "direct_w6|" "direct_w12|WINDOW=12" "plain_w12|PLANER_HIP_HOST_ROUTE=plain WINDOW=12" "staged_w12|PLANER_HIP_HOST_ROUTE=staged WINDOW=12" "direct_w12_q8|WINDOW=12 GPU_MAX_HW_QUEUES=8" "direct_prof|PROFILE=1 WINDOW=12"; do
+  tag=${spec%%|*}; envs=${spec#*|}
+  env $envs TAG=$tag python tools/host_submit_probe.py 2>&1 | grep -v "^$" | tail -22
+done ) | tee gpurun_out/r6c/host_submit_probe4.txt

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Host -> device routes for one ResNet batch (32 x 3 x 224 x 224 floats = 19.3 MB), GB/s each: the runtime's own pageable
-hipMemcpyAsync (PLANER_HIP_STAGED=0 in a child process), the staged route (copy threads -> pinned ring -> DMA on the copy
-stream) per worker count / chunk size, and DMA straight out of pinned memory.  Run on the GPU box.
+hipMemcpyAsync (pl_h2d), the staged route (copy threads -> pinned ring -> DMA on the consumer's stream; PLANER_HIP_COPY_STREAMS=1:
+on a copy stream) per worker count / chunk size, and DMA straight out of pinned memory.  Run on the GPU box.
 
     python tools/h2d_probe.py [threads ...]
 """
@@ -36,27 +36,26 @@ def child():
         dt = (time.perf_counter() - t0) / 20
         print("%-34s %7.1f GB/s  %.3f ms (numpy copyto, one thread)" % (which, x.nbytes / dt / 1e9, dt * 1e3))
         return
-    for _ in range(5):
-        d.set(x)
-    ctx.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(30):
-        d.set(x)
-    ctx.synchronize()
-    dt = (time.perf_counter() - t0) / 30
     tag = "%s threads=%s chunk=%s" % (which, os.environ.get("PLANER_HIP_COPY_THREADS", "dflt"), os.environ.get("PLANER_HIP_COPY_CHUNK_KB", "4096"))
-    print("%-34s %7.1f GB/s  %.3f ms per batch (sync set)" % (tag, x.nbytes / dt / 1e9, dt * 1e3))
-    if which != "plain":
-        # asynchronous form: the host returns when the source has been read; four ring slots keep the DMA busy
+
+    def timed(label, fn, reps=30):
         for _ in range(5):
-            d.set_staged(x)
+            fn()
         ctx.synchronize()
         t0 = time.perf_counter()
-        for _ in range(30):
-            d.set_staged(x)
+        for _ in range(reps):
+            fn()
         ctx.synchronize()
-        dt = (time.perf_counter() - t0) / 30
-        print("%-34s %7.1f GB/s  %.3f ms per batch (set_staged, host not waiting)" % (tag, x.nbytes / dt / 1e9, dt * 1e3))
+        dt = (time.perf_counter() - t0) / reps
+        print("%-34s %7.1f GB/s  %.3f ms per batch (%s)" % (tag, x.nbytes / dt / 1e9, dt * 1e3, label))
+    if which in ("plain", "pinned"):
+        timed("pl_h2d: the runtime's own route, host and stream wait", lambda: d.set(x))
+    if which != "plain":
+        def one():
+            d.set_staged(x)
+            ctx.synchronize()
+        timed("pl_h2d_staged + sync each", one)
+        timed("pl_h2d_staged, host not waiting", lambda: d.set_staged(x))
 
 
 if __name__ == "__main__":
@@ -64,7 +63,7 @@ if __name__ == "__main__":
         child()
         sys.exit(0)
     threads = sys.argv[1:] or ["0", "3", "7", "15", "31"]
-    runs = [("plain", {"PLANER_HIP_STAGED": "0"}), ("memcpy", {}), ("pinned", {})]
+    runs = [("plain", {}), ("memcpy", {}), ("pinned", {})]
     runs += [("staged", {"PLANER_HIP_COPY_THREADS": t}) for t in threads]
     runs += [("staged", {"PLANER_HIP_COPY_THREADS": "7", "PLANER_HIP_COPY_CHUNK_KB": c}) for c in ("1024", "2048", "8192", "32768")]
     for which, env in runs:
