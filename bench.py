@@ -5,9 +5,10 @@ kernel and a parity check of exactly what was timed.
 
     python bench.py --gpus N --steps K --warmup W
 
-N>1 is launched by the driver as `python -m torch.distributed.run
---nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU); torchrun is
-only the process spawner -- ranks exchange the RCCL id through /tmp and the
+N>1 runs one rank per GPU: `python -m planer_amd.launch --nproc N bench.py --gpus N ...`
+(the product's own torch-free spawner) or, as the driver does, `python -m
+torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` -- either is
+only a process spawner: ranks exchange the RCCL id through a file and the
 weight blob through ONE RCCL broadcast over xGMI; the forward pass itself has
 no collective (batch shards are independent), so scaling is weak: 32 images
 per GPU.  A step = one captured forward pass over one resident batch.
@@ -386,7 +387,8 @@ def main():
     if world != args.gpus:
         if args.gpus != 1 and world == 1:
             sys.exit("bench.py --gpus %d must be launched with one process per GPU "
-                     "(python -m torch.distributed.run --nproc-per-node %d bench.py ...)" % (args.gpus, args.gpus))
+                     "(python -m planer_amd.launch --nproc %d bench.py --gpus %d ...; python -m torch.distributed.run "
+                     "--nproc-per-node %d works as well)" % (args.gpus, args.gpus, args.gpus, args.gpus))
     ctx = planer_amd.hip.context()
     # RCCL or nothing: the same-node file transport is only used when asked for by name, so a
     # fallback run can never be mistaken for the RCCL path

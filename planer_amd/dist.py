@@ -7,10 +7,13 @@ The only exchange is at load time: rank 0 reads the weight file and ONE RCCL
 broadcast of the uint8 blob (net.load_weights, net.py:83-88) fills every
 other rank's copy.  No collective runs in the forward pass.
 
-Launch model: `python -m torch.distributed.run --nproc-per-node N ...` (or any
-launcher that sets RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT); the launcher
-is only a process spawner -- this module does not import torch.  The 128-byte
-RCCL unique id travels through a file in /tmp (all ranks share one node).
+Launch model: `python -m planer_amd.launch --nproc N script.py ...` (the
+package's own spawner, planer_amd/launch.py: no torch anywhere) or any launcher
+that sets RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT (`python -m
+torch.distributed.run --nproc-per-node N ...` is what the bench driver uses);
+the launcher is only a process spawner -- this module does not import torch.
+The 128-byte RCCL unique id travels through a file (PLANER_RDZV_FILE, else a
+name under /tmp derived from the launcher's port and pid: all ranks share one node).
 """
 import os
 import time

@@ -152,6 +152,13 @@ def test_bench_two_gpus_under_the_launcher():
          gross=per_gpu < 0.8 * d1["value"])
     rr = d2["config"]["rank_images_per_sec"]
     assert rr["min"] <= rr["max"]
+    # the package's own spawner (no torch in any process) must produce the same kind of line
+    own = subprocess.run([sys.executable, "-m", "planer_amd.launch", "--nproc", "2", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-extra"],
+                         capture_output=True, text=True, env=env, timeout=1500, cwd=ROOT)
+    assert own.returncode == 0, own.stderr[-3000:]
+    d3 = json.loads([ln for ln in own.stdout.splitlines() if ln.startswith("{")][0])
+    assert d3["n_gpus"] == 2 and d3["config"]["rccl_ranks"] == 2 and d3["parity_rel_err"] <= 1e-4
     soft(rr["min"] >= 0.9 * per_gpu, "slowest rank >= 0.9 x mean", (rr, per_gpu), gross=rr["min"] < 0.7 * per_gpu)
 
 
