@@ -315,7 +315,7 @@ int pl_conv2d_winograd43_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, in
 
 /* A 1x1 / stride 1 / group 1 channel-quad convolution with its fused tail (bias, scale, shift, ReLU / LeakyReLU; no residual)
  * whose only reader is a staged Winograd 3x3 convolution: writes that conv's transformed input V straight away --
- * wino = 4: F(4x4,3x3), V as pl_wino4_input_q4_f32 makes it; wino = 2: F(2x2,3x3), [16][Cout/4][T][4] with 2x2 tiles.
+ * wino = 4: F(4x4,3x3), V as pl_wino4_input_q4_f32 makes it (wino = 2, the F(2x2,3x3) domain, is reserved: PL_EUNSUPPORTED).
  * wq from pl_conv2d_prepare_q4_f32 (group 1).  Replaces, for a Darknet block (1x1 then 3x3), layer.Conv2d + BatchNorm +
  * LeakyReLU (reference layer.py:22-26, 125-127, 48-51) and the first stage of the next conv; plan-internal. */
 int pl_conv1x1_wino_in_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const float *wq, int Cout,
@@ -470,10 +470,12 @@ int pl_reduce_f32(pl_ctx *ctx, const float *x, float *y, int rows, int cols, int
 /* Transpose (layer.py:194): y = x.transpose(perm), up to 6 axes */
 int pl_transpose_f32(pl_ctx *ctx, const float *x, float *y, int ndim, const int *shape, const int *perm);
 /* General strided map, up to 6 axes: output index o_d reads input index
- * t = o_d*step[d] + start[d] (wrap[d]: taken modulo extent[d]; div[d] > 1: only
+ * t = o_d*step[d] + start[d] (wrap[d] = 1: taken modulo extent[d], 2: clamped to the
+ * axis, 3 / 4: mirrored at its borders without / with the border sample -- np.pad's
+ * 'wrap', 'edge', 'reflect', 'symmetric'; div[d] > 1: only
  * where t %% div[d] == 0, then t / div[d]) at in_stride[d] elements per index,
  * and `fill` wherever an axis falls outside [0, extent[d]).  Serves layer.Slice
- * (layer.py:188-196), constant layer.Pad (:241-245), Tile (:57), Expand
+ * (layer.py:188-196), layer.Pad in those five modes (:241-245), Tile (:57), Expand
  * (:198-200), Split (:170-172) and the zero-stuffing + filter flip/transpose of
  * layer.ConvTranspose2d (:28-34). */
 int pl_strided_map_f32(pl_ctx *ctx, const float *x, float *y, int ndim, const int *out_shape,

@@ -361,19 +361,60 @@ def unsqueeze(x, axes=None):
     return np.expand_dims(x, tuple(np.array(axes).tolist()))
 
 
+def nearest_shift(k, trans_mode, round_mode):
+    """util.offset (util.py:155-170): where output index 0 comes from under the coordinate transform and the rounding
+    rule, probed on the integers -64 .. 63 -- the first one that maps to source index 0.  Unknown names apply nothing
+    (a transform of its own for every name but 'half_pixel' / 'asymmetric' does not exist; an unknown rounding name
+    leaves the int16 cast's truncation)."""
+    pos = np.arange(-64, 64)
+    if trans_mode == "half_pixel":
+        pos = (pos + 0.5) / k - 0.5
+    if trans_mode == "asymmetric":
+        pos = pos / k
+    if round_mode == "round_prefer_floor":
+        pos = np.round(pos - 1e-3)
+    if round_mode == "round_prefer_ceil":
+        pos = np.round(pos + 1e-3)
+    if round_mode == "ceil":
+        pos = np.ceil(pos)
+    if round_mode == "floor":
+        pos = np.floor(pos)
+    return int(np.argmax(pos.astype(np.int16) == 0)) - 64
+
+
+def shift_with_border(img, dr, dc):
+    """util.pix_offset (util.py:172-182) out of place: the map moved by (dr, dc); what moves in from outside is the border
+    row / column of the UNMOVED map (three slice assignments in a row there: the interior, then the vacated rows from row 0
+    or h-1 as it then stands, then the vacated columns likewise -- so a vacated row keeps its columns unmoved and a vacated
+    column its rows)."""
+    h, w = img.shape[-2:]
+    if dr == 0 and dc == 0:
+        return img
+    rows, cols = np.arange(h), np.arange(w)
+    r_in = (rows >= dr) if dr >= 0 else (rows < h + dr)
+    c_in = (cols >= dc) if dc >= 0 else (cols < w + dc)
+    r_edge, c_edge = (0 if dr >= 0 else h - 1), (0 if dc >= 0 else w - 1)
+    R = np.where(r_in[:, None], np.where(c_in[None, :], (rows - dr)[:, None], rows[:, None]), r_edge)
+    C = np.where(c_in[None, :], np.where(r_in[:, None], (cols - dc)[None, :], cols[None, :]), c_edge)
+    return img[..., R, C]
+
+
 def resize(x, roi, k, size=None, mode="nearest", coordinate_transformation_mode="half_pixel",
            nearest_mode="round_prefer_floor"):
-    """layer.Resize (layer.py:84-88).  Nearest: for the two mode pairs util.offset()
-    (util.py:155-170) maps to a zero shift this is plain replication like UpSample.  Linear: the two mode
-    arguments are not looked at (util.py:216-218)."""
+    """layer.Resize (layer.py:84-88) -> util.upsample (util.py:212-219).  Nearest: block replication by the TRUNCATED
+    factors (util.py:213), then the shift util.offset() derives from the two mode names (util.py:184-192).  Linear: the
+    two mode arguments are not looked at (util.py:216-218)."""
     if k.size == 0:
         k = size[-2:] / np.array(x.shape[-2:])
+    k = np.asarray(k)[-2:].tolist()
     if mode == "linear":
-        return _upsample_any(x, np.asarray(k)[-2:].tolist(), mode)
-    if mode != "nearest" or (coordinate_transformation_mode, nearest_mode) not in (
-            ("half_pixel", "round_prefer_floor"), ("asymmetric", "floor")):
-        raise NotImplementedError("oracle covers the zero-shift nearest modes only")
-    return upsample(x, np.asarray(k)[-2:], "nearest")
+        return _upsample_any(x, k, mode)
+    if mode != "nearest":
+        raise NotImplementedError("oracle covers nearest and linear")
+    kint = [int(k[0]), int(k[1])]
+    out = upsample(x, np.array(kint), "nearest")
+    return shift_with_border(out, nearest_shift(kint[0], coordinate_transformation_mode, nearest_mode),
+                             nearest_shift(kint[1], coordinate_transformation_mode, nearest_mode))
 
 
 def slice_(x, start, end, axis=None, step=None):

@@ -26,21 +26,34 @@ backend = hip
 
 
 def core(obj="hip", silent=False):
-    """Backend switch with the reference's signature (__init__.py:22-38).
+    """Backend switch with the reference's signature (__init__.py:22-38): returns the array module.
 
-    The reference rebinds the `np` of its modules to any numpy-like module.
-    This package has exactly one backend -- the HIP one -- so `core` accepts
-    'hip' / `planer_amd.hip` (and returns it, as the reference returns the
-    backend).  numpy is refused on purpose: the numpy path is the reference
-    itself, not something this package re-implements or falls back to.
+    The reference rebinds the `np` of its modules to any numpy-like module -- the module decides what KIND OF ARRAY the
+    package hands out and takes; the arithmetic follows from that.  Here the arithmetic is always the HIP library (this
+    package holds no CPU implementation of any operator and never falls back to one), so `core` chooses the array side only:
+
+      core('hip') / core(planer_amd.hip)   device arrays: `asarray` uploads, layers and nets return DeviceArrays
+      core(numpy)                          host arrays, the reference's import-time default (__init__.py:40): `asarray` /
+                                           `asnumpy` are numpy's, `net(x)` and every layer callable take ndarrays and return
+                                           ndarrays -- computed on the GPU (uploaded and fetched per call, net.py:96-100)
+
+    A script written against the reference that calls `planer.core(numpy)` (or never calls core) therefore runs unchanged.
+    Anything else (cupy, a numpy clone) is refused: use the reference package for those backends.
     """
+    global backend
     name = obj if isinstance(obj, str) else getattr(obj, "__name__", "")
-    if name not in ("hip", "planer_amd.hip"):
-        raise ValueError("planer_amd has a single backend, 'hip'; got %r. "
-                         "Use the reference planer package for numpy/cupy." % (name,))
+    if name in ("hip", "planer_amd.hip"):
+        backend = hip
+    elif name == "numpy":
+        import numpy
+        backend = numpy
+    else:
+        raise ValueError("planer_amd computes on HIP only; core() takes 'hip' (device arrays) or numpy (host arrays in and "
+                         "out, still computed on the GPU), got %r.  For cupy or another numpy-like backend use the reference "
+                         "planer package." % (name,))
     if not silent:
-        print("\nuser switch engine:", hip.__name__)
-    return hip
+        print("\nuser switch engine:", backend.__name__)
+    return backend
 
 
 def asnumpy(arr, **key):
@@ -49,5 +62,8 @@ def asnumpy(arr, **key):
 
 
 def asarray(arr, **key):
-    """__init__.py:44"""
-    return hip.asarray(arr, **key)
+    """__init__.py:44: the array type of the current backend -- a DeviceArray under core('hip'), an ndarray under core(numpy)"""
+    if backend is hip:
+        return hip.asarray(arr, **key)
+    import numpy
+    return arr.get() if isinstance(arr, DeviceArray) else numpy.asarray(arr, **{k: v for k, v in key.items() if k != "ctx"})

@@ -787,6 +787,7 @@ int wino4_gemm_launch(pl_ctx *ctx, const float *V, const float *Uq, float *M, co
         if (u) {
             int rc = conv_launch(ctx, V, 1, 121 * p.C, p.N * p.th / 4, p.tw, u, 121 * p.Cout, 1, 1, nullptr, M, 1, 1, 1, 1, 0, 0, 0, 0, 121,
                                  nullptr, nullptr, nullptr, PL_ACT_NONE, 0.0, 2);
+            ctx->xcd_cols_request = 0;
             ctx->last_plan = "wino4-mixed-probe[" + ctx->last_plan + "]";
             return rc;
         }
@@ -1265,6 +1266,9 @@ int pl_conv1x1_wino_in_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int 
     PL_REQUIRE(ctx && xq && wq && V, PL_EINVAL, "pl_conv1x1_wino_in_q4_f32: null pointer");
     PL_REQUIRE(N >= 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 4 == 0 && (wino == 4 || wino == 2), PL_EINVAL,
                "pl_conv1x1_wino_in_q4_f32: bad shape (Cout must be a multiple of 4, wino 2 or 4)");
+    // F(2x2,3x3): the kernel template has the branch, nothing in the package ever asked for it and no test pins it (round-5
+    // advisor) -- refused until a caller and a parity test exist, rather than shipped unverified
+    PL_REQUIRE(wino == 4, PL_EUNSUPPORTED, "pl_conv1x1_wino_in_q4_f32: only wino = 4 (the F(4x4,3x3) domain) is supported");
     PL_REQUIRE(act >= 0 && act <= 2, PL_EINVAL, "pl_conv1x1_wino_in_q4_f32: bad activation code");
     PL_REQUIRE(((reinterpret_cast<uintptr_t>(xq) | reinterpret_cast<uintptr_t>(wq) | reinterpret_cast<uintptr_t>(V)) & 15u) == 0, PL_EINVAL,
                "Q4 tensors must be 16-byte aligned");
@@ -1288,7 +1292,7 @@ int pl_conv1x1_wino_in_q4_f32(pl_ctx *ctx, const float *xq, int N, int Cin, int 
     a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
     a.divMt = FastDiv(a.mtiles); a.divRw = FastDiv(a.rw); a.divRh = FastDiv(a.rh);
     a.ep = make_epilogue(bias, scale, shift, nullptr, act, alpha);
-    auto kern = wino == 4 ? conv1x1_wino_in_kernel<4> : conv1x1_wino_in_kernel<2>;
+    auto kern = conv1x1_wino_in_kernel<4>;
     int rc = ensure_lds_attr((const void *)kern, C1W_LDS_FLOATS * 4);
     if (rc != PL_OK) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C1W_WAVES * 64), C1W_LDS_FLOATS * 4, ctx->stream, a);

@@ -63,10 +63,13 @@ namespace {
 struct Reader {
     const unsigned char *p, *end;
     bool ok = true;
+    // (every bound is checked against what is LEFT, never by adding a length from the file to a pointer: a length near 2^64
+    //  must not wrap past the end)
+    size_t left() const { return (size_t)(end - p); }
     template <class T>
     T get() {
         T v{};
-        if (p + sizeof(T) > end) {
+        if (!ok || sizeof(T) > left()) {
             ok = false;
             return v;
         }
@@ -74,14 +77,22 @@ struct Reader {
         p += sizeof(T);
         return v;
     }
-    const unsigned char *bytes(size_t n) {
-        if (p + n > end) {
+    const unsigned char *bytes(unsigned long long n) {
+        if (!ok || n > left()) {
             ok = false;
             return nullptr;
         }
         const unsigned char *r = p;
-        p += n;
+        p += (size_t)n;
         return r;
+    }
+    // n bytes stored padded to a multiple of `align`
+    const unsigned char *padded(unsigned long long n, unsigned align) {
+        if (!ok || n > left()) {                  // (before rounding up: the rounding itself could wrap)
+            ok = false;
+            return nullptr;
+        }
+        return bytes((n + align - 1) / align * align);
     }
 };
 
@@ -126,7 +137,7 @@ int pl_plan_build(pl_ctx *ctx, const void *program, size_t program_bytes, pl_pla
         pt.dtype = r.get<unsigned>();
         pt.ndim = r.get<unsigned>();
         for (int d = 0; d < 8; ++d) pt.dims[d] = r.get<unsigned>();
-        if (!r.ok || pt.ndim > 8 || pt.offset + pt.bytes > arena_bytes) {
+        if (!r.ok || pt.ndim > 8 || pt.bytes > arena_bytes || pt.offset > arena_bytes - pt.bytes) {
             pl_set_error("pl_plan_build: bad tensor record %u", t);
             return fail(PL_EINVAL);
         }
@@ -140,7 +151,7 @@ int pl_plan_build(pl_ctx *ctx, const void *program, size_t program_bytes, pl_pla
     pl->calls.reserve(n_calls);
     for (unsigned k = 0; k < n_calls; ++k) {
         const unsigned name_len = r.get<unsigned>();
-        const unsigned char *nm = r.bytes((name_len + 3) / 4 * 4);
+        const unsigned char *nm = r.padded(name_len, 4);
         const unsigned nargs = r.get<unsigned>();
         if (!r.ok || name_len > 96 || nargs > 40) {
             pl_set_error("pl_plan_build: bad call record %u", k);
@@ -173,7 +184,7 @@ int pl_plan_build(pl_ctx *ctx, const void *program, size_t program_bytes, pl_pla
                 v.p = (char *)(kind == 3 ? pl->arena : pl->consts) + off;
             } else if (kind == 5) {
                 const unsigned long long len = r.get<unsigned long long>();
-                const unsigned char *b = r.bytes((len + 7) / 8 * 8);
+                const unsigned char *b = r.padded(len, 8);
                 if (b) {
                     pl->host_blobs.emplace_back((const char *)b, (const char *)b + len);
                     v.p = pl->host_blobs.back().data();

@@ -624,7 +624,8 @@ __global__ void __launch_bounds__(TPB) transpose_kernel(const float *x, float *y
 }
 
 // General strided map of up to 6 axes: output index o_d reads input index
-//     t = o_d*step_d + start_d;  wrap_d: t mod extent_d;  div_d > 1: needs t % div_d == 0, t /= div_d
+//     t = o_d*step_d + start_d;  wrap_d = 1: t mod extent_d, 2: t clamped to the axis, 3 / 4: t mirrored at the borders without /
+//     with the border sample (np.pad's 'wrap', 'edge', 'reflect', 'symmetric');  div_d > 1: needs t % div_d == 0, t /= div_d
 // and takes `fill` whenever an axis lands outside [0, extent_d).  One kernel covers Slice (start /
 // step, negative steps), constant Pad (negative start), Tile (wrap), Expand (stride 0), Split, the
 // zero-stuffing of ConvTranspose2d (div = stride) and its filter flip + transpose (step -1,
@@ -647,9 +648,17 @@ __global__ void __launch_bounds__(TPB) strided_map_kernel(const float *x, float 
             const int o = (int)(rem - q * p.oshape[d]);
             rem = q;
             int t = o * p.step[d] + p.start[d];
-            if (p.wrap[d]) {
-                t %= p.extent[d];
-                if (t < 0) t += p.extent[d];
+            const int n = p.extent[d];
+            if (p.wrap[d] == 1) {                      // modulo (Tile, np.pad 'wrap')
+                t %= n;
+                if (t < 0) t += n;
+            } else if (p.wrap[d] == 2) {               // clamp (np.pad 'edge')
+                t = min(max(t, 0), n - 1);
+            } else if (p.wrap[d] >= 3) {               // mirror: 3 without the border sample ('reflect'), 4 with it ('symmetric')
+                const int period = p.wrap[d] == 3 ? max(2 * (n - 1), 1) : 2 * n;
+                t %= period;
+                if (t < 0) t += period;
+                if (t >= n) t = (p.wrap[d] == 3 ? period : period - 1) - t;
             }
             if (p.div[d] > 1) {
                 ok = ok && t % p.div[d] == 0;
@@ -761,6 +770,7 @@ int pl_strided_map_f32(pl_ctx *ctx, const float *x, float *y, int ndim, const in
     size_t total = 1;
     for (int d = 0; d < ndim; ++d) {
         PL_REQUIRE(out_shape[d] >= 0 && extent[d] >= 0 && div[d] >= 1, PL_EINVAL, "pl_strided_map_f32: bad axis %d", d);
+        PL_REQUIRE(wrap[d] >= 0 && wrap[d] <= 4, PL_EINVAL, "pl_strided_map_f32: boundary mode %d of axis %d (0 fill, 1 wrap, 2 edge, 3 reflect, 4 symmetric)", wrap[d], d);
         PL_REQUIRE(!wrap[d] || extent[d] > 0, PL_EINVAL, "pl_strided_map_f32: wrap on an empty axis");
         p.oshape[d] = (unsigned)out_shape[d];
         p.istride[d] = in_stride[d];

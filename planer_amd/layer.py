@@ -607,11 +607,56 @@ def Unsqueeze(x, axes=None):
     return x.reshape(shape)
 
 
+def _nearest_shift(k, trans_mode, round_mode):
+    """util.offset (util.py:155-170): the source index of output index 0 under the coordinate transform and the rounding
+    rule, found by probing the integers -64 .. 63 (host arithmetic on 128 numbers; names the reference does not know
+    apply nothing, the int16 cast truncates)."""
+    pos = numpy.arange(-64, 64)
+    if trans_mode == "half_pixel":
+        pos = (pos + 0.5) / k - 0.5
+    if trans_mode == "asymmetric":
+        pos = pos / k
+    if round_mode == "round_prefer_floor":
+        pos = numpy.round(pos - 1e-3)
+    if round_mode == "round_prefer_ceil":
+        pos = numpy.round(pos + 1e-3)
+    if round_mode == "ceil":
+        pos = numpy.ceil(pos)
+    if round_mode == "floor":
+        pos = numpy.floor(pos)
+    return int(numpy.argmax(pos.astype(numpy.int16) == 0)) - 64
+
+
+_NEAREST_MAPS = {}
+
+
+def _shifted_nearest_map(ctx, h, w, fh, fw, dr, dc):
+    """Gather map of util.upsample_nearest + util.pix_offset (util.py:172-192) for one plane: output pixel (r, c) of the
+    (h fh) x (w fw) map -> flat index of its source pixel in the h x w plane.  The replicated map moves by (dr, dc); the
+    vacated rows take row 0 / H-1 of the UNMOVED map and the vacated columns its column 0 / W-1 (the reference assigns the
+    interior, the rows and the columns one after the other), so a vacated row keeps its columns unmoved and a vacated column
+    its rows.  Built once per geometry on the host (an int32 per output pixel), kept on the device."""
+    key = (id(ctx), h, w, fh, fw, dr, dc)
+    m = _NEAREST_MAPS.get(key)
+    if m is None:
+        H, W = h * fh, w * fw
+        rows, cols = numpy.arange(H), numpy.arange(W)
+        r_in = (rows >= dr) if dr >= 0 else (rows < H + dr)
+        c_in = (cols >= dc) if dc >= 0 else (cols < W + dc)
+        r_edge, c_edge = (0 if dr >= 0 else H - 1), (0 if dc >= 0 else W - 1)
+        R = numpy.where(r_in[:, None], numpy.where(c_in[None, :], (rows - dr)[:, None], rows[:, None]), r_edge)
+        C = numpy.where(c_in[None, :], numpy.where(r_in[:, None], (cols - dc)[None, :], cols[None, :]), c_edge)
+        m = _NEAREST_MAPS[key] = asarray(((R // fh) * w + C // fw).astype(numpy.int32).reshape(-1), ctx=ctx)
+    return m
+
+
 def Resize(x, roi, k, size=None, mode="nearest", coordinate_transformation_mode="half_pixel",
            nearest_mode="round_prefer_floor"):
-    """layer.Resize (layer.py:84-88).  Nearest with integer scales: the two mode pairs that util.offset()
-    maps to plain replication; the shifting (asymmetric, ceil) variant is not on the HIP
-    path.  Linear: the reference ignores the two mode arguments (util.py:212-219), so does this."""
+    """layer.Resize (layer.py:84-88) -> util.upsample (util.py:212-219).  Nearest: replication by the truncated factors
+    (util.py:213) and the shift util.offset() derives from the two mode names -- zero for (half_pixel, round_prefer_*) and
+    (asymmetric, floor), where this is UpSample's kernel; any other pair goes through a gather map that reproduces
+    util.pix_offset's border rule (`_shifted_nearest_map`).  Linear: the reference ignores the two mode arguments
+    (util.py:216-218), so does this."""
     if mode not in ("nearest", "linear"):
         raise NotImplementedError("resize mode %r is not on the HIP path" % mode)
     kv = _host_values(k)
@@ -622,12 +667,20 @@ def Resize(x, roi, k, size=None, mode="nearest", coordinate_transformation_mode=
     if mode == "linear":
         _f32(x)
         return _upsample_linear(x, fh, fw)
-    if (coordinate_transformation_mode, nearest_mode) not in (("half_pixel", "round_prefer_floor"),
-                                                              ("asymmetric", "floor")):
-        raise NotImplementedError("resize %s/%s is not on the HIP path" % (coordinate_transformation_mode, nearest_mode))
-    if fh != int(fh) or fw != int(fw) or fh < 1 or fw < 1:
-        raise NotImplementedError("resize: only integer up-scaling is on the HIP path")
-    return UpSample(x, numpy.array([1, 1, fh, fw], numpy.float32))
+    fh, fw = int(fh), int(fw)                      # util.py:213
+    if fh < 1 or fw < 1:
+        raise NotImplementedError("resize: nearest down-scaling (the reference returns an empty map) is not on the HIP path")
+    dr = _nearest_shift(fh, coordinate_transformation_mode, nearest_mode)
+    dc = _nearest_shift(fw, coordinate_transformation_mode, nearest_mode)
+    if dr == 0 and dc == 0:
+        return UpSample(x, numpy.array([1, 1, fh, fw], numpy.float32))
+    _f32(x)
+    n, c, h, w = x.shape
+    y = empty((n, c, h * fh, w * fw), ctx=x.ctx)
+    if y.size:
+        m = _shifted_nearest_map(x.ctx, h, w, fh, fw, dr, dc)
+        _lib.call("pl_gather_f32", x.ctx.handle, x.ptr, m.ptr, y.ptr, n * c, h * w, 1, h * fh * w * fw)
+    return y
 
 
 # ---- structural operators on the strided-map kernel ------------------------------
@@ -678,16 +731,23 @@ def Slice(x, start, end, axis=None, step=None):
                         [r.start for r in rng], [r.step for r in rng], extent=list(x.shape))
 
 
+_PAD_MODES = {"constant": 0, "wrap": 1, "edge": 2, "reflect": 3, "symmetric": 4}
+
+
 def Pad(x, pads, constant_value=0, mode="constant"):
-    """layer.Pad (layer.py:241-245): np.pad(x, pads.reshape(2,-1).T, constant)."""
-    if mode != "constant":
+    """layer.Pad (layer.py:241-245): np.pad(x, pads.reshape(2,-1).T, mode) -- constant (with its value), edge, reflect,
+    symmetric and wrap are index maps of the strided-map kernel (the padding index folded back into the axis: clamped,
+    mirrored without / with the border sample, modulo); np.pad's statistical modes are not on the HIP path."""
+    if mode not in _PAD_MODES:
         raise NotImplementedError("pad mode %r is not on the HIP path" % mode)
     pv = _host_values(pads).reshape(2, -1).T.astype(int).tolist()
     if len(pv) != x.ndim or any(b < 0 or a < 0 for b, a in pv):
         raise ValueError("pad: need one non-negative (before, after) pair per axis")
+    if mode != "constant" and any(x.shape[d] == 0 and (pv[d][0] or pv[d][1]) for d in range(x.ndim)):
+        raise ValueError("can't extend empty axis using modes other than 'constant' or 'empty'")      # np.pad's refusal
     out = [x.shape[d] + pv[d][0] + pv[d][1] for d in range(x.ndim)]
     return _strided_map(x, out, _contig_strides(x.shape), [-pv[d][0] for d in range(x.ndim)], [1] * x.ndim,
-                        extent=list(x.shape), fill=float(constant_value))
+                        extent=list(x.shape), wrap=[_PAD_MODES[mode]] * x.ndim, fill=float(constant_value))
 
 
 def Tile(x, repeat):
@@ -1092,3 +1152,46 @@ for _k, _ref in (("add", lambda a, b: a + b), ("sub", lambda a, b: a - b), ("mul
             return x[tuple(sl)]
     layer_map[_k] = _with_shape_domain(layer_map[_k], _ref)
 layer_map.update({k: _missing(k) for k in NOT_ON_DEVICE})
+
+
+# ---- host arrays in, host arrays out -------------------------------------------------------------
+# The reference's layer callables take whatever array type its backend module produces; a script written against it with the
+# numpy backend (`planer.core(numpy)`, the import-time default: __init__.py:40) calls `Conv2d(x, K, B)` with ndarrays and
+# expects ndarrays back.  Every public operator therefore accepts an all-host call: the arrays are uploaded, the HIP
+# operator runs, the results come back as ndarrays -- what Net.__call__ does for a whole net (net.py:94-101).  An operator that
+# works in place (ReLU returns its input, layer.py:44-46) writes the result into the caller's array and returns that array.
+# Calls that carry a DeviceArray are untouched (ndarrays among them are parameters the operator reads on the host).
+def _host_io(f):
+    import functools
+
+    @functools.wraps(f)
+    def op(*xs, **key):
+        if not xs or any(isinstance(a, DeviceArray) for a in xs) or not any(isinstance(a, numpy.ndarray) for a in xs):
+            return f(*xs, **key)
+        dev = [asarray(a) if isinstance(a, numpy.ndarray) else a for a in xs]
+        out = f(*dev, **key)
+
+        def back(o):
+            if isinstance(o, DeviceArray):
+                for a, d in zip(xs, dev):
+                    if o is d and isinstance(a, numpy.ndarray) and a.shape == o.shape and a.dtype == o.dtype and a.flags.writeable:
+                        a[...] = o.get()
+                        return a
+                return o.get()
+            if isinstance(o, (tuple, list)):
+                return type(o)(back(i) for i in o)
+            return o
+        return back(out)
+    op.device_op = f
+    return op
+
+
+_public = {}
+for _k, _f in list(layer_map.items()):
+    _public[id(_f)] = layer_map[_k] = _host_io(_f)
+for _name, _f in list(globals().items()):
+    # the module-level names of the same operators (what `from planer_amd import *` exports): kinds whose table entry carries
+    # the shape-domain branch keep the plain operator under their name, as before -- wrapped on its own
+    if callable(_f) and _name[:1].isupper() and not isinstance(_f, type) and getattr(_f, "__module__", None) == __name__:
+        globals()[_name] = _public.get(id(_f)) or _host_io(_f)
+del _public

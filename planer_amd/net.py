@@ -114,17 +114,28 @@ class _Plan:
         self.max_in_flight, self._ring = 8, []
         self._held = []              # per ring slot: what that launch's feed read (Net.submit), released with the slot
         self.host_in, self.fed = None, None      # Net.submit with host batches: this replica's own upload buffers + "feed has read them"
+        self._fed = False            # a feed has run since the last launch (else launch() runs the feed-time part itself)
 
     def feed(self, xs):
         """Copy new inputs into the plan's static input buffers (on the plan's stream)."""
         for s, a in zip(self.inputs, xs):
             _feed_static(self.ctx, s, a)
+        self._fed = True
 
     def launch(self, join=True, hold=None):
         """`hold`: objects the feed of THIS launch read on this plan's stream (the caller's input arrays).  They stay
         referenced until the host has seen a marker behind this launch complete: a block the caller drops right after
         submitting must not go back to its pool -- and be overwritten through another stream -- before the asynchronous
-        feed has read it."""
+        feed has read it.
+        A launch that no `feed` preceded takes what the caller wrote into `plan.inputs[i]` itself: where part of the pass
+        runs at feed time (the stem + max-pool kernel in front of the captured graph, `DeviceArray.prefed`; the row-packed
+        copy, `.packed`) that part runs here from the static tensor -- the graph alone would read the previous batch's
+        pooled tensor (round-5 advisor)."""
+        if not self._fed:
+            for s in self.inputs:
+                if s.prefed is not None or s.packed is not None:
+                    _feed_static(self.ctx, s, s)
+        self._fed = False
         _lib.call("pl_graph_launch", self.graph)
         if self.max_in_flight:
             if len(self._ring) >= self.max_in_flight:
@@ -172,6 +183,7 @@ class _MultiPlan:
         for i, sp in enumerate(self.subs):
             for dst, a in zip(sp.inputs, xs):
                 _feed_static(sp.ctx, dst, a.rows(i * n, (i + 1) * n), always=True)
+            sp._fed = True
 
     def launch(self, join=True):
         """join=True: fork from / join into the net's own stream (what Net.__call__ needs: inputs
@@ -224,6 +236,7 @@ class _PipelinePlan:
         rp = self.replicas[self.turn]
         for dst, a in zip(rp.inputs, xs):
             _feed_static(rp.ctx, dst, a, always=True)                           # on the replica's stream
+        rp._fed = True
 
     def launch(self, join=True, hold=None):
         rp = self.replicas[self.turn]
@@ -1164,6 +1177,8 @@ class Net:
                     _feed_static(self.ctx, s, s)
             else:
                 _feed_static(self.ctx, s, a)
+        for sp in (plan.subs if isinstance(plan, _MultiPlan) else (plan,)):
+            sp._fed = True
 
     def submit(self, *x):
         """Asynchronous form of `net(x)` (net.py:94-101): enqueue one forward pass and return a `Pending` handle at once.

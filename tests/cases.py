@@ -98,6 +98,20 @@ def layer_cases():
     c.append(("resize_asym_floor", "resize", [_r(461, 1, 2, 4, 4), np.zeros(0, np.float32),
                                               np.array([1, 1, 3, 2], np.float32)],
               {"mode": "nearest", "coordinate_transformation_mode": "asymmetric", "nearest_mode": "floor"}))
+    # nearest with a non-zero shift (util.offset / util.pix_offset, util.py:155-192): every (transform, rounding) pair whose
+    # offset is not 0, both signs, one axis alone and both together (the vacated corner rule), truncated factors
+    rz = lambda name, seed, shp, kk, tm, rm: c.append((name, "resize", [_r(seed, *shp), np.zeros(0, np.float32),
+                                                        np.array([1, 1] + list(kk), np.float32)],
+                                                       {"mode": "nearest", "coordinate_transformation_mode": tm, "nearest_mode": rm}))
+    rz("resize_asym_ceil", 462, (2, 3, 4, 5), (3, 2), "asymmetric", "ceil")
+    rz("resize_asym_prefer_ceil", 463, (1, 2, 5, 4), (2, 4), "asymmetric", "round_prefer_ceil")
+    rz("resize_asym_prefer_floor", 464, (1, 2, 3, 6), (3, 5), "asymmetric", "round_prefer_floor")
+    rz("resize_half_floor", 465, (2, 2, 4, 3), (2, 4), "half_pixel", "floor")
+    rz("resize_half_ceil", 466, (1, 3, 5, 5), (3, 3), "half_pixel", "ceil")
+    rz("resize_half_floor_rows_only", 467, (1, 2, 4, 6), (3, 1), "half_pixel", "floor")
+    rz("resize_asym_ceil_cols_only", 468, (1, 2, 4, 6), (1, 3), "asymmetric", "ceil")
+    rz("resize_unknown_modes", 469, (1, 2, 3, 4), (2, 2), "align_corners", "ceil")
+    rz("resize_nearest_truncated", 459, (1, 2, 4, 5), (2.7, 3.2), "asymmetric", "ceil")
     # ---- general numpy broadcasting (layer.py:93-111) and linear up-sampling (util.py:121-153, 194-219) ----
     c.append(("add_bcast_rows", "add", [_r(470, 2, 3, 4, 5), _r(471, 4, 1)], {}))
     c.append(("sub_bcast_outer", "sub", [_r(472, 3, 1), _r(473, 1, 4)], {}))
@@ -126,6 +140,13 @@ def layer_cases():
     c.append(("slice_default_axes", "slice", [_r(502, 5, 7), i64(1, 2), i64(-1, 6)], {}))
     c.append(("pad_hw", "pad", [_r(510, 2, 3, 5, 6), i64(0, 0, 1, 2, 0, 0, 3, 0)], {}))
     c.append(("pad_value", "pad", [_r(511, 3, 4), i64(2, 1, 0, 3)], {"constant_value": -1.5}))
+    # np.pad's index-map modes (layer.py:241-245 hands `mode` through): borders wider than the axis fold back more than once
+    c.append(("pad_reflect_hw", "pad", [_r(512, 2, 3, 5, 6), i64(0, 0, 2, 1, 0, 0, 1, 3)], {"mode": "reflect"}))
+    c.append(("pad_edge_hw", "pad", [_r(513, 2, 3, 5, 6), i64(0, 1, 2, 1, 0, 0, 3, 2)], {"mode": "edge"}))
+    c.append(("pad_symmetric", "pad", [_r(514, 3, 4, 5), i64(1, 2, 0, 0, 3, 6)], {"mode": "symmetric"}))
+    c.append(("pad_wrap", "pad", [_r(515, 4, 5), i64(3, 7, 5, 2)], {"mode": "wrap"}))
+    c.append(("pad_reflect_wide", "pad", [_r(516, 3, 4), i64(7, 9, 8, 10)], {"mode": "reflect"}))
+    c.append(("pad_reflect_len1", "pad", [_r(517, 1, 4), i64(2, 1, 3, 0)], {"mode": "reflect"}))
     c.append(("tile_2d", "tile", [_r(520, 3, 5), i64(2, 3)], {}))
     c.append(("tile_more_reps", "tile", [_r(521, 2, 3), i64(2, 1, 2)], {}))
     c.append(("expand_channel", "expand", [_r(530, 1, 4, 1, 1), i64(2, 4, 3, 5)], {}))

@@ -53,13 +53,24 @@ def test_no_device_means_loud_failure():
         planer_amd.from_graph(g, b)
 
 
-def test_core_has_one_backend():
+def test_core_chooses_the_array_side_only(capsys):
+    """core() returns the array module like the reference's (__init__.py:22-38): 'hip' = device arrays, numpy = host arrays
+    in and out (the reference's import-time default, __init__.py:40) -- computed on HIP either way; anything else is refused."""
+    import types
     import numpy
     import planer_amd
-    assert planer_amd.core("hip", silent=True) is planer_amd.hip
-    assert planer_amd.core(planer_amd.hip, silent=True) is planer_amd.hip
-    with pytest.raises(ValueError):
-        planer_amd.core(numpy)
+    try:
+        assert planer_amd.core("hip", silent=True) is planer_amd.hip
+        assert planer_amd.core(planer_amd.hip, silent=True) is planer_amd.hip
+        assert planer_amd.core(numpy) is numpy and planer_amd.backend is numpy
+        assert "user switch engine: numpy" in capsys.readouterr().out          # the reference's message (__init__.py:37)
+        a = planer_amd.asarray([[1.0, 2.0]])                                   # no device involved: numpy's asarray
+        assert isinstance(a, numpy.ndarray) and planer_amd.asnumpy(a) is a
+        for bad in (types.ModuleType("cupy"), "numexpr", types.ModuleType("jax.numpy")):
+            with pytest.raises(ValueError, match="reference"):
+                planer_amd.core(bad)
+    finally:
+        planer_amd.core("hip", silent=True)
 
 
 def test_product_never_imports_oracle_or_torch():

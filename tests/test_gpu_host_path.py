@@ -142,3 +142,42 @@ def test_net_call_with_a_host_batch_and_a_multi_output_net(pa):
     for h in hs:
         for o, w in zip(h.get(), want):
             np.testing.assert_array_equal(o, w)
+
+
+def test_layer_callables_and_nets_under_core_numpy(pa):
+    """`planer.core(numpy)` is what the reference does at import (__init__.py:40) and what scripts written against it
+    assume: ndarrays into layers and nets, ndarrays out.  Here that selects the ARRAY side only -- the operators still run
+    on HIP: a conv, an in-place ReLU (the reference returns its mutated input, layer.py:44-46), a multi-output op and a
+    whole net, against the oracle."""
+    from oracle import planer_np as onp
+    from planer_amd.irgen import customnet
+    from tests.conftest import assert_close
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, 3, 9, 11)).astype(np.float32)
+    K = (rng.standard_normal((8, 3, 3, 3)) * 0.2).astype(np.float32)
+    B = rng.standard_normal(8).astype(np.float32)
+    try:
+        assert pa.core(np, silent=True) is np
+        y = pa.Conv2d(x, K, B, pads=(1, 1, 1, 1))
+        assert isinstance(y, np.ndarray)
+        assert_close(y, np.ascontiguousarray(onp.conv2d(x, K, B, pads=(1, 1, 1, 1))), 1e-5, "conv on host arrays")
+        r = x.copy()
+        out = pa.ReLU(r)
+        assert out is r                                             # the caller's array, mutated
+        np.testing.assert_array_equal(r, onp.relu(x.copy()))
+        assert np.signbit(r[x < 0]).all()                           # negatives become -0.0 as in the reference (x * (x > 0))
+        parts = pa.layer_map["split"](x, split=[1, 2], axis=1)      # a multi-output operator: a list of ndarrays
+        assert all(isinstance(p, np.ndarray) for p in parts) and [p.shape[1] for p in parts] == [1, 2]
+        g, b = customnet.build()
+        net = pa.from_graph(g, b)
+        xi = customnet.make_input(1)
+        yn = net(pa.asarray(xi))                                    # asarray is numpy's under core(numpy)
+        ref = onp.OracleNet()
+        ref.load_json(g["input"], g["inits"], g["layers"], g["flow"])
+        ref.load_weights(b)
+        assert isinstance(yn, np.ndarray)
+        assert_close(yn, ref(xi.copy()), 1e-5, "customnet under core(numpy)")
+    finally:
+        pa.core("hip", silent=True)
+    d = pa.asarray(x)
+    assert isinstance(d, pa.hip.DeviceArray) and isinstance(pa.Conv2d(d, pa.asarray(K), pa.asarray(B)), pa.hip.DeviceArray)

@@ -54,7 +54,11 @@ EXACT = ["relu", "leakyrelu_0.1", "leakyrelu_default", "add", "batchnorm", "maxp
          "mul_shape_tensors", "scatternd_rows", "scatternd_elements", "nonzero_f32", "nonzero_bool", "nonzero_none",
          "nonzero_i64_1d", "topk_last", "topk_axis1", "topk_smallest_quirk", "topk_yolo_candidates", "topk_long_row",
          "topk_long_row_smallest", "add_bcast_rows", "sub_bcast_outer", "mul_bcast_cross", "div_bcast_lower_rank_lhs",
-         "add_bcast_batch", "mul_bcast_spatial", "resize_linear_frac", "resize_linear_down", "resize_linear_size"]
+         "add_bcast_batch", "mul_bcast_spatial", "resize_linear_frac", "resize_linear_down", "resize_linear_size",
+         # round 6: nearest Resize under every shifting (transform, rounding) pair, np.pad's index-map modes
+         "resize_asym_ceil", "resize_asym_prefer_ceil", "resize_asym_prefer_floor", "resize_half_floor", "resize_half_ceil",
+         "resize_half_floor_rows_only", "resize_asym_ceil_cols_only", "resize_unknown_modes", "resize_nearest_truncated",
+         "pad_reflect_hw", "pad_edge_hw", "pad_symmetric", "pad_wrap", "pad_reflect_wide", "pad_reflect_len1"]
 
 
 @pytest.mark.parametrize("name", EXACT)

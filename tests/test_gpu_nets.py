@@ -454,3 +454,29 @@ def test_two_host_threads_two_contexts(pa):
     assert not errs, errs
     for y, w in zip(got, want):
         assert_close(y, w, RTOL, "threaded")
+
+
+def test_launch_without_feed_runs_the_feed_time_part(pa):
+    """Round-5 advisor finding: where the stem + max-pool kernel runs at feed time (in front of the captured graph), a caller
+    that writes `plan.inputs[0]` itself and calls `plan.launch()` got the logits of the PREVIOUS batch's pooled tensor.
+    launch() now runs the feed-time part from the static tensor when no feed preceded it: latency and pipeline plans."""
+    g, b = resnet18.build()
+    net = pa.from_graph(g, b)
+    xs = [resnet18.make_input(4, size=64, seed=s) for s in (1, 2, 3)]
+    for mode in ("latency", "throughput"):
+        plan = net.compile(pa.asarray(xs[0], ctx=net.ctx), mode=mode)
+        reps = getattr(plan, "replicas", [plan])
+        fed_at_feed_time = any(s.prefed is not None or s.packed is not None for rp in reps for s in rp.inputs)
+        want = []
+        for x in xs:                                       # the documented way: feed, then launch
+            plan.feed([pa.asarray(x, ctx=net.ctx)])
+            plan.launch()
+            net.ctx.synchronize()
+            want.append(plan.outputs[0].get() if isinstance(plan.outputs, tuple) else plan.outputs.get())
+        for x, w in zip(xs[::-1], want[::-1]):             # writing the static input directly, no feed
+            rp = reps[getattr(plan, "turn", 0)] if hasattr(plan, "replicas") else plan
+            rp.inputs[0].set(x)
+            plan.launch()
+            net.ctx.synchronize()
+            out = plan.outputs[0] if isinstance(plan.outputs, tuple) else plan.outputs
+            np.testing.assert_array_equal(out.get(), w, "mode %s (feed-time stem: %s)" % (mode, fed_at_feed_time))

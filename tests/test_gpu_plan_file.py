@@ -137,3 +137,46 @@ def test_yolov3_and_customnet_plan_files(tmp_path):
         assert len(got) == len(want)
         for a, w in zip(got, want):
             assert_close(a, w, 1e-5, mod.__name__)
+
+
+def test_hostile_plan_files_are_refused_not_read_past_the_end(tmp_path):
+    """Round-5 advisor finding: lengths and offsets come from the file, and `p + n > end` / `offset + bytes > arena` /
+    `(len + 7) / 8 * 8` wrap for values near 2^64.  A tensor record whose offset wraps, a call whose name length or whose host
+    blob length is 2^64 - 1 (rounded up: 0), a header that promises more constants than the file holds: each must come back as
+    PL_EINVAL with a message, never a crash or a read past the buffer."""
+    import struct
+    import planer_amd
+    from planer_amd.export import export_plan
+    from planer_amd.irgen import customnet
+    lib = _bind()
+    g, b = customnet.build()
+    x = customnet.make_input(1)
+    good = export_plan(planer_amd.from_graph(g, b), x, path=str(tmp_path / "c.plplan"))
+    ctx = ctypes.c_void_p()
+    _ok(lib, lib.pl_ctx_create(0, ctypes.byref(ctx)))
+
+    def refused(blob, what):
+        plan = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(bytes(blob), len(blob))
+        rc = lib.pl_plan_build(ctx, buf, len(blob), ctypes.byref(plan))
+        assert rc == 1 and what in lib.pl_last_error(), (rc, lib.pl_last_error())      # PL_EINVAL
+
+    n_in, n_out = struct.unpack_from("<II", good, 24)
+    bad = bytearray(good)
+    struct.pack_into("<Q", bad, 40, 2 ** 64 - 8)                      # first tensor: offset + bytes wraps to a small number
+    refused(bad, b"bad tensor record")
+    first_call = 40 + (n_in + n_out) * 56
+    bad = bytearray(good)
+    struct.pack_into("<I", bad, first_call, 0xFFFFFFFF)               # a name as long as the address space
+    refused(bad, b"bad call record")
+    bad = bytearray(good)
+    struct.pack_into("<Q", bad, 8, len(good) * 4)                     # more constants than the file has bytes
+    refused(bad, b"constants")
+    # a call whose host-blob argument claims 2^64 - 1 bytes (rounds up to 0 under the 8-byte padding)
+    name = b"pl_memset"
+    rec = struct.pack("<I", len(name)) + name + b"\0" * (-len(name) % 4) + struct.pack("<I", 4)
+    rec += struct.pack("<IIQ", 6, 0, 0)                               # ctx
+    rec += struct.pack("<IIQ", 5, 0, 2 ** 64 - 1)                     # host blob, hostile length
+    tiny = b"PLPLAN1\0" + struct.pack("<QQIIII", 0, 64, 0, 0, 1, 0) + rec
+    refused(tiny, b"bad argument")
+    lib.pl_ctx_destroy(ctx)

@@ -20,7 +20,10 @@ def pa():
 
 SHAPES = [(2, 64, 56, 56, 64), (3, 128, 28, 28, 128), (5, 64, 14, 14, 256), (9, 32, 7, 7, 512), (1, 4, 1, 1, 4),
           (2, 8, 13, 13, 12), (3, 16, 26, 26, 32), (1, 16, 5, 9, 16), (2, 12, 4, 4, 72), (1, 32, 52, 52, 16),
-          (5, 20, 3, 17, 24), (1, 8, 70, 66, 8), (33, 4, 2, 2, 4)]
+          (5, 20, 3, 17, 24), (1, 8, 70, 66, 8), (33, 4, 2, 2, 4),
+          # 28-pixel maps at a batch where fewer tile rows x more images per block need fewer blocks (ResNet-18's layer2 in
+          # the shipped throughput plans: 1 tile row x 4 images x 8 columns): several images AND several row blocks per block grid
+          (32, 8, 28, 28, 72), (64, 4, 27, 26, 8)]
 
 
 def _patch_cells(h, w):
@@ -53,6 +56,20 @@ def test_fused_f4x4_conv_vs_oracle(pa, shape):
         yq = q4.ConvQ4(dev["xq"], u, dev["b"], dev["scale"], dev["shift"], dev["resq"], **kw)
         assert q4.logical_shape(yq) == (n, cout, h, w)
         assert_close(q4.from_q4(yq).get(), _oracle(host, tail), 3e-5, "%s %s [%s]" % (shape, tail, pa.hip.context().last_conv_plan()))
+
+
+def test_28_pixel_maps_take_the_one_row_four_image_block(pa):
+    """Round-5 advisor finding: the block shape the shipped throughput database runs on layer2 (`4x1x8`: NB = 4 images, BR = 1 tile
+    row, BC = 8 tile columns; 7 row blocks) must be what these shapes really launch -- the parity above then covers it."""
+    from planer_amd import q4
+    rng = np.random.default_rng(28)
+    for n, cin, h, w, cout in ((32, 8, 28, 28, 72), (64, 4, 27, 26, 8)):
+        x = q4.to_q4(pa.asarray(rng.standard_normal((n, cin, h, w)).astype(np.float32)))
+        k = pa.asarray((rng.standard_normal((cout, cin, 3, 3)) * 0.1).astype(np.float32))
+        q4.ConvQ4(x, q4.prepare_wf4_q4_weights(k), pads=(1, 1, 1, 1), w_layout=9)
+        plan = pa.hip.context().last_conv_plan()
+        assert "(4x1x8)" in plan, plan
+        assert "blocks=%d" % ((n // 4) * 7 * ((cout + 63) // 64)) in plan, plan
 
 
 PACKED = [(8, 64, 56, 56, 64), (16, 16, 56, 56, 24), (4, 8, 48, 48, 8), (8, 8, 54, 55, 12), (16, 4, 53, 56, 8), (5, 8, 20, 20, 8)]

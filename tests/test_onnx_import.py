@@ -118,3 +118,46 @@ def test_imported_graph_runs_on_the_gpu_like_the_oracle():
     net = planer_amd.from_graph(graph, blob)
     for _ in range(2):
         assert_close(net(x), want, RTOL)
+
+
+def _real_model(standin):
+    """The stand-in graph as a real onnx.ModelProto (only where the `onnx` package exists)."""
+    import onnx
+    from onnx import helper, numpy_helper
+    g = standin.graph
+    nodes = []
+    for nd in g.node:
+        attrs = {}
+        for a in nd.attribute:
+            if a.t is not None:
+                attrs[a.name] = numpy_helper.from_array(np.asarray(a.t.array), a.t.name)
+            elif a.ints:
+                attrs[a.name] = [int(v) for v in a.ints]
+            elif a.s:
+                attrs[a.name] = a.s
+            elif a.f != 0.0:
+                attrs[a.name] = float(a.f)
+            else:
+                attrs[a.name] = int(a.i)
+        nodes.append(helper.make_node(nd.op_type, list(nd.input), list(nd.output), name=nd.name, **attrs))
+    inits = [numpy_helper.from_array(np.asarray(t.array), t.name) for t in g.initializer]
+    vi = lambda n: helper.make_tensor_value_info(n, onnx.TensorProto.FLOAT, None)
+    graph = helper.make_graph(nodes, "standin", [vi(i.name) for i in g.input], [vi(o.name) for o in g.output], inits)
+    return helper.make_model(graph)
+
+
+@pytest.mark.parametrize("name", ["mini_resnet", "every_op"])
+def test_read_onnx_on_real_protobufs_where_onnx_is_installed(name, tmp_path):
+    """io.read_onnx (io.py:53-55) goes through onnx.load + onnx.numpy_helper.to_array; everywhere else in this file the
+    importer is fed stand-in objects.  Where the `onnx` package exists (not in the build image: skipped there) the same two
+    graphs, serialised as real ModelProtos, must import to the IR and the blob the REFERENCE's importer produced."""
+    onnx = pytest.importorskip("onnx")
+    path = str(tmp_path / (name + ".onnx"))
+    onnx.save(_real_model(st.MODELS[name]()), path)
+    graph, blob = onnx_import.read_onnx(path)
+    want, g = GOLD[name], norm(graph)
+    assert g["input"] == want["graph"]["input"] and g["inits"] == want["graph"]["inits"]
+    assert g["layers"] == want["graph"]["layers"] and g["flow"] == want["graph"]["flow"]
+    assert blob.size == want["blob_len"] and hashlib.sha256(blob.tobytes()).hexdigest() == want["blob_sha256"]
+    onnx_import.onnx2pla(path)                       # io.onnx2pla (io.py:289-299): the .pla next to the model
+    assert os.path.exists(path[:-5] + ".pla")
