@@ -43,7 +43,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0
 PER_GPU_BATCH = 32                 # BASELINE.json configs[2] / configs[3]: 32 images per GPU
 PROF_REPEAT = 10                   # launches of a step between its two stream markers in the per-layer passes
-PROFILE_TAG = "r05"
+PROFILE_TAG = "r06"
 
 
 def cdiv(a, b):
