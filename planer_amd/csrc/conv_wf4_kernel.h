@@ -54,6 +54,36 @@ struct Wf4Args {
 #ifndef WF4_KNOCK
 #define WF4_KNOCK 0
 #endif
+// 1: the filter fragments go global -> REGISTERS (16-byte loads that a wave issues as one contiguous 1 KB run, a rolling
+// prefetch WF4_GA_AHEAD MFMA groups deep) and never touch LDS; 0: the filter slice of a K step is staged in LDS by LDS-DMA and
+// read back as fragments (two readers per value).  The filter layout differs (pl_conv2d_prepare_wf4_f32 follows the same macro).
+#ifndef WF4_GLOBAL_A
+#define WF4_GLOBAL_A 0
+#endif
+#ifndef WF4_GA_AHEAD
+#define WF4_GA_AHEAD 5
+#endif
+// probe builds only (-DWF4_STAMP, tools/wf4_stamp.py): s_memtime of wave 0 / wave 4 of every block at kernel entry, after chunk 0
+// has landed, after the prologue, after the K loop and after the last output row
+#ifdef WF4_STAMP
+__device__ unsigned long long wf4_stamps[4096 * 2 * 8];
+#define WF4_MARK(i)                                                                                          \
+    do {                                                                                                     \
+        if ((wave == 0 || wave == 4) && lane == 0 && blockIdx.x < 4096)                                       \
+            wf4_stamps[(blockIdx.x * 2 + (wave >> 2)) * 8 + (i)] = __builtin_amdgcn_s_memtime();             \
+    } while (0)
+// ... and inside K steps 6 and 7 of every block, per wave: step entry, transform_first done, MFMAs done, transform_last done,
+// barrier passed
+__device__ unsigned long long wf4_step_stamps[512 * 8 * 2 * 8];
+#define WF4_STEP_MARK(c, i)                                                                                  \
+    do {                                                                                                     \
+        if (((c) == 6 || (c) == 7) && lane == 0 && blockIdx.x < 512)                                          \
+            wf4_step_stamps[((blockIdx.x * 8 + wave) * 2 + ((c) - 6)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define WF4_MARK(i)
+#define WF4_STEP_MARK(c, i)
+#endif
 constexpr int WF4_A_FLOATS = 36 * 256, WF4_V_FLOATS = 2 * 36 * 64, WF4_P_PASSES = 2;      // patch passes of 512 cells
 constexpr int WF4_P_CELLS = 1024, WF4_P_FLOATS = WF4_P_CELLS * 4;
 constexpr int WF4_LDS_BYTES = (2 * WF4_A_FLOATS + 2 * WF4_V_FLOATS + 2 * WF4_P_FLOATS) * 4;
@@ -288,7 +318,11 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
     static_assert(!PACK || !PLANAR, "packed blocks: 16-byte-cell patch layout only");
     // six separate LDS objects (not one dynamic array): the compiler orders LDS-DMA against later LDS accesses object by
     // object, so a DMA into A1 / P0 does not hold up the reads of A0 / P1 / V0 and the writes of V1
+#if WF4_GLOBAL_A
+    float *const As0 = nullptr, *const As1 = nullptr;          // (no filter slice in LDS: 73.7 KB fewer)
+#else
     __shared__ __attribute__((aligned(16))) float As0[WF4_A_FLOATS], As1[WF4_A_FLOATS];      // [4 cb][4 k][16 i][36 f]
+#endif
     __shared__ __attribute__((aligned(16))) float Vs0[WF4_V_FLOATS], Vs1[WF4_V_FLOATS];      // [2 wn][4 k][16 i][36 f]
     __shared__ __attribute__((aligned(16))) float Ps0[WF4_P_FLOATS], Ps1[WF4_P_FLOATS];      // [cells][4]  or  [4 ch][cells]
 
@@ -490,6 +524,52 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
     const int b_off = ((wn * 4 + lk) * 16 + li) * 36;      // ... of V[k = lk][tile 16 wn + li]
     // spread: the LDS-DMA requests of chunk c + 1's filter slice (into A[buf ^ 1]) and chunk c + 2's patch (into P[buf]) go
     // out one per MFMA group
+#if WF4_GLOBAL_A
+    // filter fragments: u[cout block][chunk][wm][g = 4 frequencies][lane][4] -- group g of chunk c for this wave is ONE load
+    // instruction over a contiguous 1 KB; a ring of AHEAD + 1 register slots, the load for group G + AHEAD goes out when group
+    // G's MFMAs do (G counts groups across K steps: 9 per step, two steps unrolled -> 18 = 3 rings of 6)
+    constexpr int GA_D = WF4_GA_AHEAD, GA_SLOTS = 6;
+    static_assert(GA_D >= 1 && GA_D < GA_SLOTS, "prefetch depth must leave one slot for the group in use");
+    float4 ga[GA_SLOTS];
+    const int ga_voff = lane << 4;
+    auto ga_load = [&](auto slot, int c, int g) {           // (past the last chunk: the range check returns zeros, nothing uses them)
+        const int soff = (int)((((unsigned)coutblk * (unsigned)p.nchunks + (unsigned)c) * 36u + (unsigned)(wm * 9 + g)) << 10);
+        ga[decltype(slot)::value] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ursrc, ga_voff, soff, 0));
+    };
+    auto mma_ga = [&](auto parity, int c, bool more2) {
+        constexpr int par = decltype(parity)::value;
+        const float4 *Vp = reinterpret_cast<const float4 *>((par ? Vs1 : Vs0) + b_off);
+        float4 fb[3];
+        fb[0] = Vp[0];
+        fb[1] = Vp[1];
+#pragma unroll
+        for (int g = 0; g < 9; ++g) {
+            if (g + 2 < 9) fb[(g + 2) % 3] = Vp[g + 2];
+            {
+                const int gn = g + GA_D;                    // the group AHEAD: same chunk or the next one
+                auto issue = [&](auto sl) { ga_load(sl, gn < 9 ? c : c + 1, gn < 9 ? gn : gn - 9); };
+                switch ((9 * par + g + GA_D) % GA_SLOTS) {
+                case 0: issue(std::integral_constant<int, 0>{}); break;
+                case 1: issue(std::integral_constant<int, 1>{}); break;
+                case 2: issue(std::integral_constant<int, 2>{}); break;
+                case 3: issue(std::integral_constant<int, 3>{}); break;
+                case 4: issue(std::integral_constant<int, 4>{}); break;
+                default: issue(std::integral_constant<int, 5>{}); break;
+                }
+            }
+            const float4 a = ga[(9 * par + g) % GA_SLOTS], b = fb[g % 3];
+            acc[4 * g + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[4 * g + 0], 0, 0, 0);
+            acc[4 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[4 * g + 1], 0, 0, 0);
+            acc[4 * g + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[4 * g + 2], 0, 0, 0);
+            acc[4 * g + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[4 * g + 3], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (g < WF4_P_PASSES) {
+                if (more2) load_p_piece(c + 2, par, g);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+#endif
     auto mma = [&](int buf, int c, bool more, bool more2, auto spread) {
         const float4 *Ap = reinterpret_cast<const float4 *>((buf ? As1 : As0) + a_off);
         const float4 *Vp = reinterpret_cast<const float4 *>((buf ? Vs1 : Vs0) + b_off);
@@ -531,16 +611,30 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
     };
 
     // ---- prologue: chunk 0 in LDS and transformed, chunk 1's patch in LDS ----
+    WF4_MARK(0);
     load_p(0, 0);
+#if WF4_GLOBAL_A
+    {
+        auto first = [&](auto sl) { ga_load(sl, 0, decltype(sl)::value); };      // groups 0 .. AHEAD - 1 of chunk 0
+        first(std::integral_constant<int, 0>{});
+        if (GA_D > 1) first(std::integral_constant<int, 1>{});
+        if (GA_D > 2) first(std::integral_constant<int, 2>{});
+        if (GA_D > 3) first(std::integral_constant<int, 3>{});
+        if (GA_D > 4) first(std::integral_constant<int, 4>{});
+    }
+#else
     load_a(0, 0);
+#endif
     store_p(0);
     store_a(0);
     __syncthreads();
+    WF4_MARK(1);
     if (p.nchunks > 1) load_p(1, 1);
     transform_first(0, 0);
     transform_last(0, 0);
     if (p.nchunks > 1) store_p(1);
     __syncthreads();
+    WF4_MARK(2);
     // (cache policy of the LDS-DMA requests, measured: non-temporal patch / filter / both 41.6 / 41.3 / 42.5 us against 39.0 us for
     //  the default policy -- neighbouring workgroups share halo pixels and every workgroup the filter -- sc0 39.2 us)
     // one K step; the buffer parity is a compile-time constant, so the compiler can tell the LDS-DMA destinations
@@ -553,7 +647,12 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
             // Waves 4-7 transform BEFORE they request their share of the next operands (the patch they read landed a step
             // ago; an LDS-DMA instruction holds a wave's issue slot ~100 cycles, seven of them would delay the transform
             // their MFMAs wait for): 38.2 -> 37.6 us
+            WF4_STEP_MARK(c, 0);
             if (more) transform_first(nxt, nxt);
+            WF4_STEP_MARK(c, 1);
+#if WF4_GLOBAL_A
+            mma_ga(parity, c, more2);
+#else
             if constexpr (SPREAD) {
                 mma(cur, c, more, more2, std::true_type{});
             } else {
@@ -561,7 +660,10 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
                 if (more2) load_p(c + 2, cur);
                 mma(cur, c, more, more2, std::false_type{});
             }
+#endif
+            WF4_STEP_MARK(c, 2);
             if (more) transform_last(nxt, nxt);
+            WF4_STEP_MARK(c, 3);
         } else {
             if (more) load_a(c + 1, nxt);
             if (more2) load_p(c + 2, cur);
@@ -574,6 +676,7 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
         if (more) store_a(nxt);
         if (more2) store_p(cur);
         __syncthreads();
+        WF4_STEP_MARK(c, 4);
     };
     // static priority for the waves that multiply first (0-3; their SIMD partners 4-7 open every step with the patch
     // transform): 39.2 -> 38.5-38.8 us per layer1 conv; the other half at priority 1 instead: 41.3 us
@@ -584,6 +687,7 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
     }
 
     // ---- lane-local output transform; fused tail and stores through the wave's exchange buffer ----
+    WF4_MARK(3);
     const int coq = (int)coutblk * 16 + wm * 4 + lk;
     const int cqc = min(coq, p.Coq - 1);
     const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
@@ -595,7 +699,11 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
     const float4 shift = plain ? reinterpret_cast<const float4 *>(p.ep.shift)[cqc] : z4;        // parameters, held in registers
     // the tail is the same for the whole launch: scalar branches pick the straight-line form where it applies and whether a
     // residual is fetched
+#if WF4_GLOBAL_A
+    float4 *xb = reinterpret_cast<float4 *>(wave < 4 ? Vs0 : Vs1) + (wave & 3) * (4 * 68);      // the K loop is over: V is free (4 x 4.25 KB each)
+#else
     float4 *xb = reinterpret_cast<float4 *>(As0) + wave * (4 * 68);      // the K loop is over: A0 is free (8 x 4.25 KB)
+#endif
     const int te = lane >> 2, be = lane & 3;
     const int oj2 = wn * 16 + te;
     int n2 = n0 + (oj2 >> lT), ty2 = ty0 + ((oj2 >> LBC) & BRm), tx2 = tx0 + (oj2 & BCm);
@@ -632,6 +740,11 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
         if (p.ep.res) rows(std::true_type{}, std::false_type{});
         else rows(std::false_type{}, std::false_type{});
     }
+    WF4_MARK(4);
+#ifdef WF4_STAMP
+    __builtin_amdgcn_s_waitcnt(0);             // (probe: when have this wave's stores left?)
+    WF4_MARK(5);
+#endif
 }
 
 template <bool DMA_A, bool PLANAR, bool STAGGER, int LBC, bool PACK = false>
@@ -657,15 +770,26 @@ __global__ void __launch_bounds__(256) wf4_filter_kernel(const float *w, float *
         t[5][j] = g2;
     }
     const int nchunks = Cin / 4;
-    float *up = u + ((size_t)(co >> 6) * nchunks + (c >> 2)) * WF4_A_FLOATS + (((((co >> 4) & 3) * 4 + (c & 3)) * 16) + (co & 15)) * 36;
+    float f[36];
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
         const float g0 = t[a][0], g1 = t[a][1], g2 = t[a][2];
-        up[a * 6 + 0] = g0 * 0.25f;
-        up[a * 6 + 1] = -(g0 + g1 + g2) * (1.f / 6.f);
-        up[a * 6 + 2] = (-g0 + g1 - g2) * (1.f / 6.f);
-        up[a * 6 + 3] = g0 * (1.f / 24.f) + g1 * (1.f / 12.f) + g2 * (1.f / 6.f);
-        up[a * 6 + 4] = g0 * (1.f / 24.f) - g1 * (1.f / 12.f) + g2 * (1.f / 6.f);
-        up[a * 6 + 5] = g2;
+        f[a * 6 + 0] = g0 * 0.25f;
+        f[a * 6 + 1] = -(g0 + g1 + g2) * (1.f / 6.f);
+        f[a * 6 + 2] = (-g0 + g1 - g2) * (1.f / 6.f);
+        f[a * 6 + 3] = g0 * (1.f / 24.f) + g1 * (1.f / 12.f) + g2 * (1.f / 6.f);
+        f[a * 6 + 4] = g0 * (1.f / 24.f) - g1 * (1.f / 12.f) + g2 * (1.f / 6.f);
+        f[a * 6 + 5] = g2;
     }
+    float *blk = u + ((size_t)(co >> 6) * nchunks + (c >> 2)) * WF4_A_FLOATS;
+#if WF4_GLOBAL_A
+    // [wm = 16-channel block][g = 4 frequencies][lane = k * 16 + channel][4]: what one wave loads for one MFMA group is contiguous
+    float *up = blk + (((co >> 4) & 3) * 9 * 64 + (c & 3) * 16 + (co & 15)) * 4;
+#pragma unroll
+    for (int q = 0; q < 36; ++q) up[(q >> 2) * 256 + (q & 3)] = f[q];
+#else
+    float *up = blk + (((((co >> 4) & 3) * 4 + (c & 3)) * 16) + (co & 15)) * 36;
+#pragma unroll
+    for (int q = 0; q < 36; ++q) up[q] = f[q];
+#endif
 }

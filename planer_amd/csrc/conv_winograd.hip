@@ -1068,6 +1068,16 @@ int wf4_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const
 
 extern "C" {
 
+#ifdef WF4_STAMP
+// probe builds only: copies the fused kernel's time stamps out (tools/wf4_stamp.py)
+int pl_debug_wf4_stamps(void *dst, size_t bytes) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(wf4_stamps), bytes) == hipSuccess ? PL_OK : PL_EHIP;
+}
+int pl_debug_wf4_step_stamps(void *dst, size_t bytes) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(wf4_step_stamps), bytes) == hipSuccess ? PL_OK : PL_EHIP;
+}
+#endif
+
 int pl_conv2d_w1d4_q4_filter_elems(int Cout, int Cin, size_t *elems) {
     PL_REQUIRE(elems && Cout > 0 && Cin > 0, PL_EINVAL, "winograd-1d filter size: bad argument");
     *elems = (size_t)6 * (((size_t)3 * (Cin / 4) + 7) / 8 * 8) * Cout * 4;

@@ -1,5 +1,1 @@
-bash tools/profile_bench.sh r06 2>&1 | tail -30
-bash tools/other_workloads.sh r06 2>&1 | tail -12
-python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/prof/r06_bench_driver_form.json 2> gpurun_out/prof/r06_driver_form.err; tail -2 gpurun_out/prof/r06_driver_form.err
-python bench.py --steps 5000 --warmup 50 --repeats 1 --no-cpu-baseline --no-e2e --no-extra > gpurun_out/prof/r06_bench_sustained.json 2>/dev/null
-ls gpurun_out/prof | head -50
+PLANER_HIP_LIB=$PWD/planer_amd/build/ab/libga_stamp.so python tools/wf4_stamp.py 2>&1 | tee gpurun_out/r6h/wf4_stamps_ga.txt
