@@ -12,6 +12,12 @@
 //     frequencies -- so the output transform A^T m A is lane-local; the fused tail and the stores go through a wave-private
 //     LDS exchange that turns (tile, quad) lanes into (tile, pixel) lanes: one store covers a contiguous 1 KB run.  M never
 //     exists.  (The first version had 4 waves x 288 accumulators: 67 us against 48 us -- the compiler shuffled through AGPRs.)
+//   * The filter never touches LDS (round 6, WF4_GLOBAL_A): it is laid out [cout block][chunk][16-channel block][group of 4
+//     frequencies][lane][4], so the fragment a wave needs for one group of four MFMAs is ONE 16-byte load per lane over a
+//     contiguous 1 KB, requested five groups ahead into a ring of six register slots (profiles/r06_wf4_stalls.md: 39.2 / 60.2
+//     against 40.3 / 62.6 us per layer1 / layer2 conv, 110 KB less LDS traffic per K step, 69.6 instead of 143 KB of LDS).
+//     (WF4_GLOBAL_A = 0, the form of rounds 3-5: the filter slice A[4 cout blocks][4 k][16][36] of a chunk, 36.9 KB, staged in
+//     LDS by LDS-DMA and read back as fragments -- what the next item still describes.)
 //   * K runs over input channel quads (one quad = one chunk = one MFMA K step of 4).  Per chunk the workgroup
 //     holds in LDS: the filter slice A[4 cout blocks][4 k][16][36] (36.9 KB, by LDS-DMA straight from a filter laid out in
 //     exactly that order), the input patch P of the block's tiles -- (4 BR + 2) x (4 BC + 2) pixels per image,
@@ -58,7 +64,7 @@ struct Wf4Args {
 // prefetch WF4_GA_AHEAD MFMA groups deep) and never touch LDS; 0: the filter slice of a K step is staged in LDS by LDS-DMA and
 // read back as fragments (two readers per value).  The filter layout differs (pl_conv2d_prepare_wf4_f32 follows the same macro).
 #ifndef WF4_GLOBAL_A
-#define WF4_GLOBAL_A 0
+#define WF4_GLOBAL_A 1
 #endif
 #ifndef WF4_GA_AHEAD
 #define WF4_GA_AHEAD 5
@@ -462,7 +468,9 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
     constexpr int rs = PLANAR ? 4 * S : 16 * S, psz = PLANAR ? S : 4 * S, cst = PLANAR ? 1 : 4;
     auto item_bases = [&](int half, int &pbase, int &vbase) {
         const int tj = half * 16 + ti;
-        const int t_nb = tj >> lT, t_r = (tj >> LBC) & BRm, t_c = tj & BCm;
+        const int t_nb = tj >> lT, t_r = (tj >> LBC) & BRm;
+        int t_c = tj & BCm;
+        if (PACK && t_c >= p.tw) t_c += 1;                       // spare slots read the donor patch, one cell further right
         pbase = (PLANAR ? tch * p.cells : tch) + (((t_nb * p.R + 4 * t_r) * 4) * S + t_c) * cst;
         vbase = (((half * 4 + tch) * 16) + ti) * 36;
     };
@@ -665,9 +673,13 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
             if (more) transform_last(nxt, nxt);
             WF4_STEP_MARK(c, 3);
         } else {
+#if WF4_GLOBAL_A
+            mma_ga(parity, c, more2);
+#else
             if (more) load_a(c + 1, nxt);
             if (more2) load_p(c + 2, cur);
             mma(cur, c, more, more2, std::false_type{});
+#endif
             if (more) {
                 transform_first(nxt, nxt);
                 transform_last(nxt, nxt);

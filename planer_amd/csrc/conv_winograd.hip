@@ -986,6 +986,9 @@ int w1d_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const
 }
 
 #include "conv_wf4_kernel.h"
+#ifndef WF4_STAGGER
+#define WF4_STAGGER true      // (probe builds: false = every wave multiplies first, the patch transform follows)
+#endif
 
 int wf4_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const float *u, int Cout, const float *bias,
                float *yq, const float *scale, const float *shift, const float *resq, int act, double alpha) {
@@ -1046,13 +1049,13 @@ int wf4_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const
     // per block width, so that every patch read is base + immediate
     void (*kern)(const Wf4Args) = nullptr;
     switch (a.pack_g ? 10 + lBC : lBC) {
-    case 14: kern = conv_wf4_kernel<true, false, true, 4, true>; break;
-    case 13: kern = conv_wf4_kernel<true, false, true, 3, true>; break;
-    case 4: kern = conv_wf4_kernel<true, false, true, 4>; break;
-    case 3: kern = conv_wf4_kernel<true, false, true, 3>; break;
-    case 2: kern = conv_wf4_kernel<true, false, true, 2>; break;
-    case 1: kern = conv_wf4_kernel<true, false, true, 1>; break;
-    default: kern = conv_wf4_kernel<true, false, true, 0>; break;
+    case 14: kern = conv_wf4_kernel<true, false, WF4_STAGGER, 4, true>; break;
+    case 13: kern = conv_wf4_kernel<true, false, WF4_STAGGER, 3, true>; break;
+    case 4: kern = conv_wf4_kernel<true, false, WF4_STAGGER, 4>; break;
+    case 3: kern = conv_wf4_kernel<true, false, WF4_STAGGER, 3>; break;
+    case 2: kern = conv_wf4_kernel<true, false, WF4_STAGGER, 2>; break;
+    case 1: kern = conv_wf4_kernel<true, false, WF4_STAGGER, 1>; break;
+    default: kern = conv_wf4_kernel<true, false, WF4_STAGGER, 0>; break;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), 0, ctx->stream, a);      // LDS: static (WF4_LDS_BYTES)
     PL_LAUNCH_CHECK();
