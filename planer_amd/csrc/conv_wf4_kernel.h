@@ -69,6 +69,9 @@ struct Wf4Args {
 #ifndef WF4_GA_AHEAD
 #define WF4_GA_AHEAD 5
 #endif
+#ifndef WF4_GA_SLOTS
+#define WF4_GA_SLOTS 6
+#endif
 // probe builds only (-DWF4_STAMP, tools/wf4_stamp.py): s_memtime of wave 0 / wave 4 of every block at kernel entry, after chunk 0
 // has landed, after the prologue, after the K loop and after the last output row
 #ifdef WF4_STAMP
@@ -536,7 +539,8 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
     // filter fragments: u[cout block][chunk][wm][g = 4 frequencies][lane][4] -- group g of chunk c for this wave is ONE load
     // instruction over a contiguous 1 KB; a ring of AHEAD + 1 register slots, the load for group G + AHEAD goes out when group
     // G's MFMAs do (G counts groups across K steps: 9 per step, two steps unrolled -> 18 = 3 rings of 6)
-    constexpr int GA_D = WF4_GA_AHEAD, GA_SLOTS = 6;
+    constexpr int GA_D = WF4_GA_AHEAD, GA_SLOTS = WF4_GA_SLOTS;
+    static_assert(18 % GA_SLOTS == 0, "two K steps (18 groups) must be whole turns of the ring");
     static_assert(GA_D >= 1 && GA_D < GA_SLOTS, "prefetch depth must leave one slot for the group in use");
     float4 ga[GA_SLOTS];
     const int ga_voff = lane << 4;
@@ -562,7 +566,10 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
                 case 2: issue(std::integral_constant<int, 2>{}); break;
                 case 3: issue(std::integral_constant<int, 3>{}); break;
                 case 4: issue(std::integral_constant<int, 4>{}); break;
-                default: issue(std::integral_constant<int, 5>{}); break;
+                case 5: issue(std::integral_constant<int, 5 % GA_SLOTS>{}); break;
+                case 6: issue(std::integral_constant<int, 6 % GA_SLOTS>{}); break;
+                case 7: issue(std::integral_constant<int, 7 % GA_SLOTS>{}); break;
+                default: issue(std::integral_constant<int, 8 % GA_SLOTS>{}); break;
                 }
             }
             const float4 a = ga[(9 * par + g) % GA_SLOTS], b = fb[g % 3];
@@ -629,6 +636,9 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
         if (GA_D > 2) first(std::integral_constant<int, 2>{});
         if (GA_D > 3) first(std::integral_constant<int, 3>{});
         if (GA_D > 4) first(std::integral_constant<int, 4>{});
+        if (GA_D > 5) first(std::integral_constant<int, 5 % GA_SLOTS>{});
+        if (GA_D > 6) first(std::integral_constant<int, 6 % GA_SLOTS>{});
+        if (GA_D > 7) first(std::integral_constant<int, 7 % GA_SLOTS>{});
     }
 #else
     load_a(0, 0);
