@@ -1,2 +1,5 @@
-for lib in "" planer_amd/build/ab/libga9.so planer_amd/build/ab/libga3.so "" planer_amd/build/ab/libga9.so; do echo "== ${lib:-shipped (6 slots, 5 ahead)}"; env ${lib:+PLANER_HIP_LIB=$PWD/$lib} python tools/wf4_bench.py --shapes 64x56,128x28 --algos 9 2>&1 | tail -2; done
-PLANER_HIP_LIB=$PWD/planer_amd/build/ab/libga9.so python -m pytest tests/test_gpu_wf4.py -x -q 2>&1 | tail -2
+bash tools/profile_bench.sh r06 2>&1 | tail -3
+bash tools/other_workloads.sh r06 2>&1 | tail -8
+python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/prof/r06_bench_driver_form.json 2> gpurun_out/prof/r06_driver_form.err; tail -2 gpurun_out/prof/r06_driver_form.err
+python bench.py --steps 5000 --warmup 50 --repeats 1 --no-cpu-baseline --no-e2e --no-extra > gpurun_out/prof/r06_bench_sustained.json 2>/dev/null
+bash tools/wf4_stalls.sh > /dev/null 2>&1; tail -5 gpurun_out/wf4_stalls/digest.md
