@@ -66,6 +66,9 @@ struct Wf4Args {
 #ifndef WF4_GLOBAL_A
 #define WF4_GLOBAL_A 1
 #endif
+#ifndef WF4_HALF_TRIM
+#define WF4_HALF_TRIM 1      // (probe builds: 0 keeps the 32-tile block's LDS allocation for the 16-tile block)
+#endif
 #ifndef WF4_GA_AHEAD
 #define WF4_GA_AHEAD 5
 #endif
@@ -199,6 +202,45 @@ __device__ __forceinline__ void wf4_transform_row2(const float *P, float *V, int
     }
 }
 
+// TWO rows of B^T d B per wave-item, for blocks of 16 tiles (HALF): lane = [row select r][tile, 4 bits][channel pair].  The rows of a
+// pair share their loads up to a per-lane base (KIND 0: rows 0 / 5 read patch rows r, r + 2, r + 4) or read the same four patch
+// rows with per-lane coefficients (KIND 1: rows 1 / 2, KIND 2: rows 3 / 4 -- each is c1 d1 + c2 d2 + c3 d3 + d4): three wave-items
+// transform a 16-tile block where the one-row form would need six half-empty ones.  pbase: as for wf4_transform_row2, plus r rows
+// for KIND 0; vbase: float index of V[even channel][tile][6 A(r)].
+template <int KIND, int rs, int ps>
+__device__ __forceinline__ void wf4_transform_2rows(const float *P, float *V, int pbase, int vbase, int r) {
+    constexpr int NR = KIND == 0 ? 3 : 4;
+    wf4_v2 d[6][NR];
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+        const float *col = P + pbase + (b & 3) * ps + (b >> 2) * 4;
+#pragma unroll
+        for (int k = 0; k < NR; ++k)
+            d[b][k] = *reinterpret_cast<const wf4_v2 *>(col + (KIND == 0 ? 2 * k : k + 1) * rs);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    wf4_v2 m[6];
+    if constexpr (KIND == 0) {
+#pragma unroll
+        for (int b = 0; b < 6; ++b) m[b] = wf4_fma2(4.f, d[b][0], wf4_fma2(-5.f, d[b][1], d[b][2]));
+    } else {
+        // rows 1 / 2: (-4, -4, 1) / (4, -4, -1);  rows 3 / 4: (-2, -1, 2) / (2, -1, -2)
+        const float c1 = KIND == 1 ? (r ? 4.f : -4.f) : (r ? 2.f : -2.f);
+        const float c2 = KIND == 1 ? -4.f : -1.f;
+        const float c3 = KIND == 1 ? (r ? -1.f : 1.f) : (r ? -2.f : 2.f);
+#pragma unroll
+        for (int b = 0; b < 6; ++b) m[b] = wf4_fma2(c1, d[b][0], wf4_fma2(c2, d[b][1], wf4_fma2(c3, d[b][2], d[b][3])));
+    }
+    wf4_v2 o[6];
+    wf4_bt2(m, o);
+    float *v0 = V + vbase, *v1 = v0 + 16 * 36;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        v0[j] = o[j].x;
+        v1[j] = o[j].y;
+    }
+}
+
 // A^T m A on channel PAIRS (the accumulator's registers 0-1 and 2-3 are natural pairs): packed arithmetic throughout, the
 // operations and their order are those of w4_at4_row / w4_at4.
 template <int A>
@@ -318,8 +360,13 @@ __device__ __forceinline__ void wf4_output_row_coalesced(const Wf4Args &p, const
 // registers; PLANAR -- the patch is stored channel-planar (transform lanes = 16 tiles x 4 channels, tile fastest: conflict-free
 // patch reads AND 2-way instead of 4-way conflicts on the V writes) instead of as 16-byte cells (lanes channel fastest);
 // STAGGER -- waves 4-7 transform before their MFMAs and waves 0-3 after, so the two waves of a SIMD alternate on its matrix pipe.
-template <bool DMA_A, bool PLANAR, bool STAGGER, int LBC, bool PACK = false>
+// HALF (round 6, needs WF4_GLOBAL_A): a workgroup of FOUR waves carries 16 tiles x 64 output channels -- half the registers and
+// a quarter of the LDS of a CU, so two workgroups share it with barriers of their own: one's prologue, tail and barrier waits
+// run under the other's K loop.  Three two-row transform items (waves 1-3) per K step.
+template <bool DMA_A, bool PLANAR, bool STAGGER, int LBC, bool PACK = false, bool HALF = false>
 __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
+    constexpr int NT = HALF ? 256 : 512, LT = HALF ? 4 : 5;          // threads, log2(tiles) of a block
+    static_assert(!HALF || (WF4_GLOBAL_A && DMA_A && !PLANAR), "half blocks: filter in registers, 16-byte-cell patch");
     // the LDS-DMA requests of a step go out one per MFMA group (measured: 40.9 -> 39.8 us per layer1 conv against all seven
     // in a row at the head of the step)
     constexpr bool SPREAD = DMA_A && !PLANAR && STAGGER;
@@ -332,12 +379,13 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
 #else
     __shared__ __attribute__((aligned(16))) float As0[WF4_A_FLOATS], As1[WF4_A_FLOATS];      // [4 cb][4 k][16 i][36 f]
 #endif
-    __shared__ __attribute__((aligned(16))) float Vs0[WF4_V_FLOATS], Vs1[WF4_V_FLOATS];      // [2 wn][4 k][16 i][36 f]
-    __shared__ __attribute__((aligned(16))) float Ps0[WF4_P_FLOATS], Ps1[WF4_P_FLOATS];      // [cells][4]  or  [4 ch][cells]
+    // (HALF: one tile half of V, 512 patch cells -- 34.8 KB a workgroup, so that what else runs on the CU keeps its LDS)
+    __shared__ __attribute__((aligned(16))) float Vs0[WF4_V_FLOATS / (HALF && WF4_HALF_TRIM ? 2 : 1)], Vs1[WF4_V_FLOATS / (HALF && WF4_HALF_TRIM ? 2 : 1)];      // [2 wn][4 k][16 i][36 f]
+    __shared__ __attribute__((aligned(16))) float Ps0[WF4_P_FLOATS / (HALF && WF4_HALF_TRIM ? 2 : 1)], Ps1[WF4_P_FLOATS / (HALF && WF4_HALF_TRIM ? 2 : 1)];      // [cells][4]  or  [4 ch][cells]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;       // 16 output channels x 16 tiles per wave
+    const int wm = HALF ? wave : wave >> 1, wn = HALF ? 0 : wave & 1;       // 16 output channels x 16 tiles per wave
     const int li = lane & 15, lk = lane >> 4;      // MFMA: operand row / column i, k index (A, B) or row group (C)
 
     // ---- which block: cout block fastest (blocks that share input pixels are neighbours), then columns, rows, images ----
@@ -346,7 +394,7 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
     p.divCb.divmod(t1, t2, colblk);
     p.divRb.divmod(t2, ngrp, rowblk);
     const int BRm = (1 << p.lBR) - 1, BCm = (1 << LBC) - 1, lT = p.lBR + LBC;
-    int n0 = (int)ngrp << (5 - lT);
+    int n0 = (int)ngrp << (LT - lT);
     const int ty0 = (int)rowblk << p.lBR, tx0 = (int)colblk << LBC;
     // PACK: ngrp counts the RECEIVING images (G - 1 of every G); the donor's tile group of this block: (dgr, dgc)
     int dn = 0, dgr = 0, dgc = 0;
@@ -370,7 +418,7 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
     int pvoff[WF4_P_PASSES];
 #pragma unroll
     for (int ps = 0; ps < WF4_P_PASSES; ++ps) {
-        const unsigned ci = (unsigned)(ps * 512 + tid);
+        const unsigned ci = (unsigned)(ps * NT + tid);
         pvoff[ps] = OOB;
         if (ci < (unsigned)p.cells) {
             unsigned nb, rem, r_, rem2, m, s;
@@ -400,10 +448,10 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
         float *Pb = buf ? Ps1 : Ps0;
 #pragma unroll
         for (int ps = 0; ps < WF4_P_PASSES; ++ps)
-            if (ps * 512 < p.cells) {
+            if (ps * NT < p.cells) {
                 if constexpr (DMA_P) {
-                    if (ps * 512 + tid < p.cells)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_float *)(Pb + (ps * 512 + tid - lane) * 4), 16, pvoff[ps], soff, 0, 0);
+                    if (ps * NT + tid < p.cells)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_float *)(Pb + (ps * NT + tid - lane) * 4), 16, pvoff[ps], soff, 0, 0);
                 } else {
                     preg[ps] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, pvoff[ps], soff, 0));
                 }
@@ -414,15 +462,15 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
         float *Pb = buf ? Ps1 : Ps0;
 #pragma unroll
         for (int ps = 0; ps < WF4_P_PASSES; ++ps)
-            if (ps * 512 < p.cells && ps * 512 + tid < p.cells) {
+            if (ps * NT < p.cells && ps * NT + tid < p.cells) {
                 if constexpr (PLANAR) {
-                    float *d = Pb + ps * 512 + tid;
+                    float *d = Pb + ps * NT + tid;
                     d[0] = preg[ps].x;
                     d[p.cells] = preg[ps].y;
                     d[2 * p.cells] = preg[ps].z;
                     d[3 * p.cells] = preg[ps].w;
                 } else {
-                    *reinterpret_cast<float4 *>(Pb + (ps * 512 + tid) * 4) = preg[ps];
+                    *reinterpret_cast<float4 *>(Pb + (ps * NT + tid) * 4) = preg[ps];
                 }
             }
     };
@@ -453,8 +501,8 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
         const int soff = (c * HW) << 4;
         float *Pb = buf ? Ps1 : Ps0;
         if constexpr (WF4_KNOCK & 2) return;
-        if (ps * 512 < p.cells && ps * 512 + tid < p.cells)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_float *)(Pb + (ps * 512 + tid - lane) * 4), 16, pvoff[ps], soff, 0, 0);
+        if (ps * NT < p.cells && ps * NT + tid < p.cells)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_float *)(Pb + (ps * NT + tid - lane) * 4), 16, pvoff[ps], soff, 0, 0);
     };
     auto store_a = [&](int buf) {
         if constexpr (!DMA_A) {
@@ -483,7 +531,15 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
     // 16-byte-cell layout: a lane takes a channel PAIR of one of the block's 32 tiles (wf4_transform_row2), so a whole row of
     // B^T d B is ONE wave-item: six per step -- waves 4-7 rows 0-3, waves 0-1 rows 4-5
     int pb2 = 0, vb2 = 0;
-    if constexpr (!PLANAR) {
+    const int hr = lane >> 5;                                    // HALF: which row of its pair this lane transforms
+    if constexpr (HALF) {
+        const int tj = (lane >> 1) & 15, cp = lane & 1;
+        const int t_nb = tj >> lT, t_r = (tj >> LBC) & BRm;
+        int t_c = tj & BCm;
+        if (PACK && t_c >= p.tw) t_c += 1;
+        pb2 = 2 * cp + (((t_nb * p.R + 4 * t_r) * 4) * S + t_c) * 4;
+        vb2 = ((2 * cp * 16) + tj) * 36;
+    } else if constexpr (!PLANAR) {
         const int tj = lane >> 1, cp = lane & 1;
         const int t_nb = tj >> lT, t_r = (tj >> LBC) & BRm;
         int t_c = tj & BCm;
@@ -495,7 +551,11 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
         if constexpr (WF4_KNOCK & 4) return;
         const float *Pb = pbuf ? Ps1 : Ps0;
         float *Vb = vbuf ? Vs1 : Vs0;
-        if constexpr (!PLANAR) {
+        if constexpr (HALF) {                                     // waves 1-3: rows 0 / 5, 1 / 2, 3 / 4
+            if (wave == 1) wf4_transform_2rows<0, rs, psz>(Pb, Vb, pb2 + hr * rs, vb2 + hr * 30, hr);
+            else if (wave == 2) wf4_transform_2rows<1, rs, psz>(Pb, Vb, pb2, vb2 + 6 + hr * 6, hr);
+            else if (wave == 3) wf4_transform_2rows<2, rs, psz>(Pb, Vb, pb2, vb2 + 18 + hr * 6, hr);
+        } else if constexpr (!PLANAR) {
             if (wave == 4) wf4_transform_row2<0, rs, psz>(Pb, Vb, pb2, vb2);
             else if (wave == 5) wf4_transform_row2<1, rs, psz>(Pb, Vb, pb2, vb2);
             else if (wave == 6) wf4_transform_row2<2, rs, psz>(Pb, Vb, pb2, vb2);
@@ -516,7 +576,7 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
     };
     const int pbw = (wave & 1) ? pb1 : pb0, vbw = (wave & 1) ? vb1 : vb0;
     auto transform_last = [&](int pbuf, int vbuf) {            // waves 0-3: row 4 or 5 of one half
-        if constexpr (WF4_KNOCK & 4) return;
+        if constexpr (WF4_KNOCK & 4 || HALF) return;
         const float *Pb = pbuf ? Ps1 : Ps0;
         float *Vb = vbuf ? Vs1 : Vs0;
         if constexpr (!PLANAR) {
@@ -702,7 +762,7 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
     };
     // static priority for the waves that multiply first (0-3; their SIMD partners 4-7 open every step with the patch
     // transform): 39.2 -> 38.5-38.8 us per layer1 conv; the other half at priority 1 instead: 41.3 us
-    if (wave < 4) __builtin_amdgcn_s_setprio(1);
+    if (!HALF && wave < 4) __builtin_amdgcn_s_setprio(1);
     for (int c = 0; c < p.nchunks; c += 2) {
         kstep(std::integral_constant<int, 0>{}, c);
         if (c + 1 < p.nchunks) kstep(std::integral_constant<int, 1>{}, c + 1);
@@ -722,7 +782,9 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
     // the tail is the same for the whole launch: scalar branches pick the straight-line form where it applies and whether a
     // residual is fetched
 #if WF4_GLOBAL_A
-    float4 *xb = reinterpret_cast<float4 *>(wave < 4 ? Vs0 : Vs1) + (wave & 3) * (4 * 68);      // the K loop is over: V is free (4 x 4.25 KB each)
+    // the K loop is over: V (and, for half blocks, P) is free -- 4.25 KB of exchange buffer per wave
+    float4 *xb = HALF ? reinterpret_cast<float4 *>(wave == 0 ? Vs0 : wave == 1 ? Vs1 : wave == 2 ? Ps0 : Ps1)
+                      : reinterpret_cast<float4 *>(wave < 4 ? Vs0 : Vs1) + (wave & 3) * (4 * 68);
 #else
     float4 *xb = reinterpret_cast<float4 *>(As0) + wave * (4 * 68);      // the K loop is over: A0 is free (8 x 4.25 KB)
 #endif
@@ -769,9 +831,9 @@ __device__ __forceinline__ void conv_wf4_body(const Wf4Args &p) {
 #endif
 }
 
-template <bool DMA_A, bool PLANAR, bool STAGGER, int LBC, bool PACK = false>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) conv_wf4_kernel(const Wf4Args p) {
-    conv_wf4_body<DMA_A, PLANAR, STAGGER, LBC, PACK>(p);
+template <bool DMA_A, bool PLANAR, bool STAGGER, int LBC, bool PACK = false, bool HALF = false>
+__global__ void __launch_bounds__(HALF ? 256 : 512) __attribute__((amdgpu_waves_per_eu(2, 2))) conv_wf4_kernel(const Wf4Args p) {
+    conv_wf4_body<DMA_A, PLANAR, STAGGER, LBC, PACK, HALF>(p);
 }
 
 // filter: OIHW 3x3 -> u[cout block][chunk][cb][kk][i][f] = (G g G^T)[f] of channel (64 blk + 16 cb + i, 4 chunk + kk); zero beyond Cout

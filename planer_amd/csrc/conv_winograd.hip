@@ -986,6 +986,9 @@ int w1d_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const
 }
 
 #include "conv_wf4_kernel.h"
+#ifndef WF4_HALF_DEFAULT
+#define WF4_HALF_DEFAULT 1
+#endif
 #ifndef WF4_STAGGER
 #define WF4_STAGGER true      // (probe builds: false = every wave multiplies first, the patch transform follows)
 #endif
@@ -998,27 +1001,31 @@ int wf4_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const
     a.N = N; a.Cq = Cin / 4; a.Coq = Cout / 4; a.H = H; a.W = W;
     a.th = (H + 3) / 4; a.tw = (W + 3) / 4;
     a.nchunks = Cin / 4;
+    // blocks of 32 tiles on eight waves, or (PLANER_HIP_EXPERIMENT=wf4_half=1; needs the filter-in-registers build) of 16 tiles on
+    // four waves -- two workgroups per CU with barriers of their own
+    const bool half = WF4_GLOBAL_A && pl_experiment("wf4_half", WF4_HALF_DEFAULT) != 0;
+    const int TB = half ? 16 : 32;
     int BC = 1, BR = 1, lBC = 0, lBR = 0;
     while (BC < a.tw && BC < 16) BC *= 2, ++lBC;
-    while (BR < a.th && BR * BC < 32) BR *= 2, ++lBR;
+    while (BR < a.th && BR * BC < TB) BR *= 2, ++lBR;
     // Fewer tile rows per block and more images instead, where that needs fewer 32-tile blocks: 7 tile rows (a 28-pixel map) are
     // two blocks of 4 rows per image (64 slots for 49 tiles) but seven blocks of 1 row x 4 images (56 slots per image quartet's
     // 49 x 4 / 4) -- 112 instead of 128 workgroups for ResNet-18's layer2 at batch 32.  Ties keep the taller block (less halo in
     // the patch).  PLANER_HIP_EXPERIMENT=wf4_br=<rows> forces.
     {
-        auto blocks_of = [&](int br) { const int nb = 32 / (br * BC); return (long long)((N + nb - 1) / nb) * ((a.th + br - 1) / br); };
+        auto blocks_of = [&](int br) { const int nb = TB / (br * BC); return (long long)((N + nb - 1) / nb) * ((a.th + br - 1) / br); };
         int best_br = BR, best_l = lBR;
         for (int br = BR / 2, l = lBR - 1; br >= 1; br /= 2, --l)
-            if (blocks_of(br) < blocks_of(best_br) && (32 / (br * BC)) * (4 * br + 2) * 4 * (BC + 1) <= WF4_P_CELLS) best_br = br, best_l = l;
+            if (blocks_of(br) < blocks_of(best_br) && (TB / (br * BC)) * (4 * br + 2) * 4 * (BC + 1) <= (half ? 512 : WF4_P_CELLS)) best_br = br, best_l = l;
         const int force = pl_experiment("wf4_br", 0);
-        if (force > 0 && force <= BR && (force & (force - 1)) == 0 && (32 / (force * BC)) * (4 * force + 2) * 4 * (BC + 1) <= WF4_P_CELLS) {
+        if (force > 0 && force <= BR && (force & (force - 1)) == 0 && (TB / (force * BC)) * (4 * force + 2) * 4 * (BC + 1) <= (half ? 512 : WF4_P_CELLS)) {
             best_br = force;
             best_l = 0;
             while ((1 << best_l) < force) ++best_l;
         }
         BR = best_br; lBR = best_l;
     }
-    const int NB = 32 / (BR * BC);
+    const int NB = TB / (BR * BC);
     a.lBR = lBR; a.lBC = lBC;
     a.R = 4 * BR + 2; a.S = BC + 1;
     a.rblocks = (a.th + BR - 1) / BR; a.cblocks = (a.tw + BC - 1) / BC; a.cout_blocks = (Cout + 63) / 64;
@@ -1028,7 +1035,7 @@ int wf4_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const
     {
         const int sc = BC - a.tw;
         if (NB == 1 && a.cblocks == 1 && sc > 0 && a.tw % sc == 0 && a.th % BR == 0 && (lBC == 4 || lBC == 3) &&
-            N % (a.tw / sc + 1) == 0 && a.R * 4 * (BC + 2) <= WF4_P_CELLS && pl_experiment("wf4_pack", 1)) {
+            N % (a.tw / sc + 1) == 0 && a.R * 4 * (BC + 2) <= (half ? 512 : WF4_P_CELLS) && pl_experiment("wf4_pack", 1)) {
             a.pack_sc = sc; a.pack_g = a.tw / sc + 1; a.pack_gc = a.tw / sc;
             a.S = BC + 2;
         }
@@ -1038,7 +1045,7 @@ int wf4_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const
     const long long blocks = groups * a.rblocks * a.cblocks * a.cout_blocks;
     const size_t xb = (size_t)N * Cin * H * W * 4, yb = (size_t)N * Cout * H * W * 4;
     const size_t ub = (size_t)a.cout_blocks * a.nchunks * WF4_A_FLOATS * 4;
-    PL_REQUIRE(a.cells <= WF4_P_CELLS && blocks < (1ll << 31) && xb < (1ull << 31) && yb < (1ull << 31) && ub < (1ull << 31),
+    PL_REQUIRE(a.cells <= (half ? 512 : WF4_P_CELLS) && blocks < (1ll << 31) && xb < (1ull << 31) && yb < (1ull << 31) && ub < (1ull << 31),
                PL_EUNSUPPORTED, "fused winograd F(4x4,3x3): tensor too large");
     a.x_bytes = (unsigned)xb; a.y_bytes = (unsigned)yb; a.u_bytes = (unsigned)ub;
     a.divPlane = FastDiv(a.R * 4 * a.S); a.div4S = FastDiv(4 * a.S); a.divS = FastDiv(a.S);
@@ -1048,6 +1055,19 @@ int wf4_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const
     // against 51.4 us for register-staged operands with the waves in step, layer1 of ResNet-18 at batch 32); one instantiation
     // per block width, so that every patch read is base + immediate
     void (*kern)(const Wf4Args) = nullptr;
+#if WF4_GLOBAL_A
+    if (half) {
+        switch (a.pack_g ? 10 + lBC : lBC) {
+        case 14: kern = conv_wf4_kernel<true, false, WF4_STAGGER, 4, true, true>; break;
+        case 13: kern = conv_wf4_kernel<true, false, WF4_STAGGER, 3, true, true>; break;
+        case 4: kern = conv_wf4_kernel<true, false, WF4_STAGGER, 4, false, true>; break;
+        case 3: kern = conv_wf4_kernel<true, false, WF4_STAGGER, 3, false, true>; break;
+        case 2: kern = conv_wf4_kernel<true, false, WF4_STAGGER, 2, false, true>; break;
+        case 1: kern = conv_wf4_kernel<true, false, WF4_STAGGER, 1, false, true>; break;
+        default: kern = conv_wf4_kernel<true, false, WF4_STAGGER, 0, false, true>; break;
+        }
+    } else
+#endif
     switch (a.pack_g ? 10 + lBC : lBC) {
     case 14: kern = conv_wf4_kernel<true, false, WF4_STAGGER, 4, true>; break;
     case 13: kern = conv_wf4_kernel<true, false, WF4_STAGGER, 3, true>; break;
@@ -1057,13 +1077,13 @@ int wf4_launch(pl_ctx *ctx, const float *xq, int N, int Cin, int H, int W, const
     case 1: kern = conv_wf4_kernel<true, false, WF4_STAGGER, 1>; break;
     default: kern = conv_wf4_kernel<true, false, WF4_STAGGER, 0>; break;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), 0, ctx->stream, a);      // LDS: static (WF4_LDS_BYTES)
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(half ? 256 : 512), 0, ctx->stream, a);      // LDS: static
     PL_LAUNCH_CHECK();
     char buf[96];
-    snprintf(buf, sizeof buf, "wf4 64co x 32tiles (%dx%dx%d%s) blocks=%lld", NB, BR, BC, a.pack_g ? " packed" : "", blocks);
+    snprintf(buf, sizeof buf, "wf4 64co x %dtiles (%dx%dx%d%s) blocks=%lld", TB, NB, BR, BC, a.pack_g ? " packed" : "", blocks);
     ctx->last_plan = buf;
     ctx->last_gemm[0] = 36; ctx->last_gemm[1] = (long long)a.cout_blocks * 64;
-    ctx->last_gemm[2] = groups * a.rblocks * a.cblocks * 32; ctx->last_gemm[3] = Cin;
+    ctx->last_gemm[2] = groups * a.rblocks * a.cblocks * TB; ctx->last_gemm[3] = Cin;
     return PL_OK;
 }
 

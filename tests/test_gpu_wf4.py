@@ -26,28 +26,30 @@ SHAPES = [(2, 64, 56, 56, 64), (3, 128, 28, 28, 128), (5, 64, 14, 14, 256), (9, 
           (32, 8, 28, 28, 72), (64, 4, 27, 26, 8)]
 
 
-def _patch_cells(h, w):
-    """16-byte cells of one block's input patch (wf4_launch's geometry: 32 tiles = NB images x BR x BC tiles)."""
+def _patch_cells(h, w, tiles=32):
+    """16-byte cells of one block's input patch (wf4_launch's geometry: `tiles` = NB images x BR x BC tiles)."""
     th, tw = -(-h // 4), -(-w // 4)
     bc = 1
     while bc < tw and bc < 16:
         bc *= 2
     br = 1
-    while br < th and br * bc < 32:
+    while br < th and br * bc < tiles:
         br *= 2
-    return (32 // (br * bc)) * (4 * br + 2) * 4 * (bc + 1)
+    return (tiles // (br * bc)) * (4 * br + 2) * 4 * (bc + 1)
 
 
+@pytest.mark.parametrize("half", ["1", "0"], ids=["16-tile blocks", "32-tile blocks"])
 @pytest.mark.parametrize("shape", SHAPES, ids=["x".join(map(str, s)) for s in SHAPES])
-def test_fused_f4x4_conv_vs_oracle(pa, shape):
+def test_fused_f4x4_conv_vs_oracle(pa, shape, half, monkeypatch):
     from planer_amd import q4
+    monkeypatch.setenv("PLANER_HIP_EXPERIMENT", "wf4_half=" + half)
     n, cin, h, w, cout = shape
     rng = np.random.default_rng(11 + sum(shape))
     for tail in TAILS:
         host, dev = _operands(pa, rng, n, cin, h, w, cout, tail)
         u = q4.prepare_wf4_q4_weights(dev["k"])
         kw = dict(pads=(1, 1, 1, 1), act=_act(tail), alpha=0.1, w_layout=9)
-        if _patch_cells(h, w) > 1024:
+        if _patch_cells(h, w, 16 if half == "1" else 32) > (512 if half == "1" else 1024):
             # one-tile maps put 32 images into a block: more patch cells than the kernel's LDS buffers hold -> refused
             # (the plan compiler then keeps another algorithm), never computed wrongly
             with pytest.raises(NotImplementedError):
@@ -58,18 +60,21 @@ def test_fused_f4x4_conv_vs_oracle(pa, shape):
         assert_close(q4.from_q4(yq).get(), _oracle(host, tail), 3e-5, "%s %s [%s]" % (shape, tail, pa.hip.context().last_conv_plan()))
 
 
-def test_28_pixel_maps_take_the_one_row_four_image_block(pa):
-    """Round-5 advisor finding: the block shape the shipped throughput database runs on layer2 (`4x1x8`: NB = 4 images, BR = 1 tile
-    row, BC = 8 tile columns; 7 row blocks) must be what these shapes really launch -- the parity above then covers it."""
+def test_28_pixel_maps_take_the_one_row_four_image_block(pa, monkeypatch):
+    """Round-5 advisor finding: the block shape the shipped throughput database runs on layer2 (NB images x BR = 1 tile row x BC = 8
+    tile columns, 7 row blocks: `4x1x8` with 32-tile blocks, `2x1x8` with the 16-tile blocks of round 6) must be what these shapes
+    really launch -- the parity above then covers it; both block sizes are run."""
     from planer_amd import q4
     rng = np.random.default_rng(28)
-    for n, cin, h, w, cout in ((32, 8, 28, 28, 72), (64, 4, 27, 26, 8)):
+    for n, cin, h, w, cout, half in ((32, 8, 28, 28, 72, "1"), (64, 4, 27, 26, 8, "1"), (32, 8, 28, 28, 72, "0")):
+        monkeypatch.setenv("PLANER_HIP_EXPERIMENT", "wf4_half=" + half)
         x = q4.to_q4(pa.asarray(rng.standard_normal((n, cin, h, w)).astype(np.float32)))
         k = pa.asarray((rng.standard_normal((cout, cin, 3, 3)) * 0.1).astype(np.float32))
         q4.ConvQ4(x, q4.prepare_wf4_q4_weights(k), pads=(1, 1, 1, 1), w_layout=9)
         plan = pa.hip.context().last_conv_plan()
-        assert "(4x1x8)" in plan, plan
-        assert "blocks=%d" % ((n // 4) * 7 * ((cout + 63) // 64)) in plan, plan
+        nb = 2 if "16tiles" in plan else 4              # (round 6: blocks of 16 tiles on four waves by default; wf4_half=0: 32 on eight)
+        assert "(%dx1x8)" % nb in plan, plan
+        assert "blocks=%d" % ((n // nb) * 7 * ((cout + 63) // 64)) in plan, plan
 
 
 PACKED = [(8, 64, 56, 56, 64), (16, 16, 56, 56, 24), (4, 8, 48, 48, 8), (8, 8, 54, 55, 12), (16, 4, 53, 56, 8), (5, 8, 20, 20, 8)]
