@@ -12,6 +12,13 @@
 //     frequencies -- so the output transform A^T m A is lane-local; the fused tail and the stores go through a wave-private
 //     LDS exchange that turns (tile, quad) lanes into (tile, pixel) lanes: one store covers a contiguous 1 KB run.  M never
 //     exists.  (The first version had 4 waves x 288 accumulators: 67 us against 48 us -- the compiler shuffled through AGPRs.)
+//   * Round 6, what ships: BLOCKS OF 16 TILES ON FOUR WAVES (template parameter HALF; PLANER_HIP_EXPERIMENT=wf4_half=0 brings the
+//     32-tile / eight-wave block described below back).  A workgroup then holds half the registers of a CU and 34.8 KB of LDS,
+//     so two of them -- or one and another kernel's workgroups -- share a CU with barriers of their own: one's prologue, store
+//     tail and barrier waits run under the other's K loop.  Wave wm owns output channels [16 wm, 16 wm + 16) x the 16 tiles; the
+//     patch transform of a step is three TWO-ROW wave-items (wf4_transform_2rows: lane = row of a pair x tile x channel pair) on
+//     waves 1-3.  Layer2 conv of ResNet-18 at batch 32: 43.7 against 62.1 us alone (224 instead of 112 workgroups), bench.py
+//     58.1-58.4 k against 55.9-56.2 k img/s (profiles/r06_ab_wf4_half_blocks.txt).
 //   * The filter never touches LDS (round 6, WF4_GLOBAL_A): it is laid out [cout block][chunk][16-channel block][group of 4
 //     frequencies][lane][4], so the fragment a wave needs for one group of four MFMAs is ONE 16-byte load per lane over a
 //     contiguous 1 KB, requested five groups ahead into a ring of six register slots (profiles/r06_wf4_stalls.md: 39.2 / 60.2
