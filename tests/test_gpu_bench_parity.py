@@ -91,7 +91,12 @@ def test_throughput_plans_take_the_pipeline_judged_picks(pa, r18):
     net = pa.from_graph(g, b)
     net._load_algo_cache()
     if not net._algo_tp:
-        pytest.skip("no throughput table in the database of this device")
+        # the shipped table is empty when the isolated picks win under the pipeline too (round 6): the mechanism is exercised
+        # with a table of this test's own -- layer3 (mixed tiles alone) on the fused kernel for throughput plans only
+        for sig, v in list(net._algo.items()):
+            if sig[1][:2] == (32, 256) and len(sig[2]) == 4 and sig[2][2:] == (3, 3) and sig[1][2] == 14:
+                net._algo_tp[sig] = 9 if v != 9 else 7
+        assert net._algo_tp, "no layer3 signature in the database"
     lay = lambda plan: {a["layer"].split("@")[0].rstrip("+"): a["w_layout"] for a in plan.algos}
     tp = net.compile(d, mode="throughput")
     lat = net.compile(d, mode="latency")
