@@ -162,6 +162,30 @@ def test_bench_two_gpus_under_the_launcher():
     soft(rr["min"] >= 0.9 * per_gpu, "slowest rank >= 0.9 x mean", (rr, per_gpu), gross=rr["min"] < 0.7 * per_gpu)
 
 
+def test_bench_two_ranks_share_one_gpu_under_the_package_launcher():
+    """The N > 1 path end to end on whatever hardware there is: `python -m planer_amd.launch --nproc 2 bench.py --gpus 2` with both
+    ranks on device 0 (PLANER_HIP_DEVICE) and the same-node file transport asked for by name (RCCL refuses two ranks on one
+    device).  What it pins: the launcher's environment, batch shards per rank, the barrier / max-over-ranks timing contract, ONE
+    JSON line from rank 0 with the whole-job rate, full-shard parity -- and that the line says honestly which transport ran
+    (`rccl_ranks` 0, not a pretended RCCL world)."""
+    env = dict(os.environ, PLANER_DIST_TRANSPORT="file", PLANER_HIP_DEVICE="0")
+    for k in ("PLANER_HIP_STREAMS", "RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "PLANER_RDZV_FILE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "planer_amd.launch", "--nproc", "2", os.path.join(ROOT, "bench.py"), "--gpus", "2",
+                        "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-extra", "--no-e2e"],
+                       capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 10 and d["scaling"] == "weak" and d["config"]["global_batch"] == 64
+    assert d["parity_rel_err"] <= 1e-4 and d["parity_checked_images"] >= 2
+    assert d["config"]["rccl_ranks"] == 0 and "file" in d["config"]["weight_exchange"]
+    rr = d["config"]["rank_images_per_sec"]
+    assert 0 < rr["min"] <= rr["max"] and abs(d["value"] - 64 * 1e3 / d["ms_per_step"]) <= 0.01 * d["value"]
+    assert d["value"] > 10000
+
+
 def test_throughput_plan_does_not_depend_on_stream_creation_order():
     """The runtime maps streams onto its hardware queues in creation order, and a pipeline's rate depends on which queues its
     replicas land on (53.1 k or 50.4 k img/s for the same seven replicas).  The plan compiler therefore tries
