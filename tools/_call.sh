@@ -1,6 +1,9 @@
-for i in 1 2; do python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra --no-e2e 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
-print(d['value'], 'frac', r['frac'], 'b2b', r['frac_back_to_back'], 'rocprof', r['frac_rocprof'], 'marker_us', r['marker_us'], 'avg_launch_ms', r['avg_launch_ms'], r['avg_launch_ms_back_to_back'], 'eff', r['effective_frac'])"; done
-python -m pytest tests/test_zz_gpu_bench_cli.py -x -q -k "default_command" 2>&1 | tail -3
-cat gpurun_out/timing_warnings.jsonl 2>/dev/null | tail -2
+mkdir -p gpurun_out/prof
+python bench.py --steps 50 --warmup 10 > gpurun_out/prof/r06_bench_line.json 2>/dev/null
+python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/prof/r06_bench_driver_form.json 2>/dev/null
+python - <<'PY'
+import json
+for f in ('r06_bench_line','r06_bench_driver_form'):
+    d=json.loads(open('gpurun_out/prof/%s.json'%f).read().strip().splitlines()[-1]); r=d['roofline']; c=d['config']
+    print(f, d['value'], d['ms_per_step'], c['repeat_values']['all'], r['frac'], r['frac_back_to_back'], r['frac_rocprof'], c['pcie_inclusive_images_per_sec'], c['net_submit_images_per_sec'], c['net_call_images_per_sec'], c['net_call_host_images_per_sec'], r['whole_forward_timed_run']['mfma_util'])
+PY
